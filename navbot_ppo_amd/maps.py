@@ -1,0 +1,138 @@
+"""Static line-segment obstacle maps for the batched LiDAR simulator.
+
+A map is a float32 array ``[S, 4]`` of segments ``(ax, ay, bx, by)`` in world metres; a
+per-env map buffer is ``[N, S, 4]``.  Geometry is computed in float64 and rounded once.
+
+Only ``stage_1`` has reference geometry
+(``turtlebot3_simulations/turtlebot3_gazebo/worlds/train_world_new.world:85-416``: 4 outer
+walls + 4 inner boxes, the obstacles the env's goal-rejection rectangles at
+``project_ppo/src/environment_new.py:248-251,340-343`` are drawn around).  ``stage_2`` and
+``stage_4`` are AUTHORED here (the reference's ``turtlebot3_stage_2.world`` is referenced by
+``launch/turtlebot3_stage_2.launch:8`` but missing from the tree; "stage_4" appears nowhere),
+so results on them are "parity unpinned (no reference geometry)".
+"""
+import math
+
+import numpy as np
+
+# Reference goal-rejection rectangles (xmin, xmax, ymin, ymax), inclusive.
+RESET_RECTS_STAGE1 = np.array(  # environment_new.py:340-343
+    [[1.7, 2.3, -1.2, 1.2], [-2.3, -1.7, -1.2, 1.2], [-1.2, 1.2, 1.7, 2.3], [-1.2, 1.2, -2.3, -1.7]], dtype=np.float64)
+RESPAWN_RECTS_STAGE1 = np.array(  # environment_new.py:248-251
+    [[1.6, 2.4, -1.4, 1.4], [-2.4, -1.6, -1.4, 1.4], [-1.4, 1.4, 1.6, 2.4], [-1.4, 1.4, -2.4, -1.6]], dtype=np.float64)
+
+
+def box_to_segments(length, width, cx, cy, yaw):
+    """Footprint of an SDF ``<box><size>length width h</size>`` posed at (cx, cy, yaw): 4 segments, CCW."""
+    c, s = math.cos(yaw), math.sin(yaw)
+    hx, hy = length / 2.0, width / 2.0
+    corners = [(-hx, -hy), (hx, -hy), (hx, hy), (-hx, hy)]
+    pts = [(cx + c * px - s * py, cy + s * px + c * py) for px, py in corners]
+    return [[pts[i][0], pts[i][1], pts[(i + 1) % 4][0], pts[(i + 1) % 4][1]] for i in range(4)]
+
+
+def cylinder_to_segments(radius, cx, cy, sides=24, phase=0.0):
+    """Regular ``sides``-gon inscribed in an SDF ``<cylinder>`` footprint, CCW."""
+    pts = [(cx + radius * math.cos(phase + 2 * math.pi * k / sides), cy + radius * math.sin(phase + 2 * math.pi * k / sides))
+           for k in range(sides)]
+    return [[pts[k][0], pts[k][1], pts[(k + 1) % sides][0], pts[(k + 1) % sides][1]] for k in range(sides)]
+
+
+def _as_map(segs):
+    return np.asarray(segs, dtype=np.float64).astype(np.float32).reshape(-1, 4)
+
+
+# (length, width, cx, cy, yaw) exactly as written in train_world_new.world (link poses at
+# :122,:164,:206,:248,:290,:332,:374,:416; collision sizes at :89,:131,:173,:215,:257,:299,:341,:383)
+_STAGE1_BOXES = [
+    (8.0, 0.2, 4.0, 0.0, -1.5708),
+    (8.0002, 0.2, 0.0, -4.0, 3.14159),
+    (8.0, 0.2, -4.0, 0.0, 1.5708),
+    (8.0, 0.2, 0.0, 4.0, 0.0),
+    (2.0, 0.2, 2.0, 0.0, -1.5708),
+    (2.0, 0.2, 0.0, -2.0, 3.14159),
+    (2.0, 0.2, -2.0, 0.0, 1.5708),
+    (2.0, 0.2, 0.0, 2.0, 0.0),
+]
+
+
+def stage_1():
+    """8 boxes = 32 segments (reference geometry)."""
+    segs = []
+    for b in _STAGE1_BOXES:
+        segs += box_to_segments(*b)
+    return _as_map(segs)
+
+
+def stage_2(sides=24):
+    """AUTHORED: stage_1 shell + four r=0.3 m pillars at (+-2.6, +-2.6); 32 + 4*sides segments (128 by default)."""
+    segs = []
+    for b in _STAGE1_BOXES:
+        segs += box_to_segments(*b)
+    for sx in (1, -1):
+        for sy in (1, -1):
+            segs += cylinder_to_segments(0.3, 2.6 * sx, 2.6 * sy, sides=sides, phase=math.pi / sides)
+    return _as_map(segs)
+
+
+STAGE2_EXTRA_RECTS = np.array([[sx * 2.6 - 0.6, sx * 2.6 + 0.6, sy * 2.6 - 0.6, sy * 2.6 + 0.6]
+                               for sx in (1, -1) for sy in (1, -1)], dtype=np.float64)
+
+
+def stage_4():
+    """AUTHORED: stage_1 shell + a pinwheel of four 1.6 m walls and four corner posts; 64 segments."""
+    segs = []
+    for b in _STAGE1_BOXES:
+        segs += box_to_segments(*b)
+    for k in range(4):
+        a = k * math.pi / 2
+        cx, cy = 2.9 * math.cos(a + math.pi / 4), 2.9 * math.sin(a + math.pi / 4)
+        segs += box_to_segments(1.6, 0.15, cx, cy, a + 3 * math.pi / 4)
+        segs += box_to_segments(0.3, 0.3, 3.3 * math.cos(a + 0.35), 3.3 * math.sin(a + 0.35), a)
+    return _as_map(segs)
+
+
+STAGE4_EXTRA_RECTS = np.array(
+    [[2.05 * sx - 1.0, 2.05 * sx + 1.0, 2.05 * sy - 1.0, 2.05 * sy + 1.0] for sx in (1, -1) for sy in (1, -1)],
+    dtype=np.float64)
+
+
+def by_name(name):
+    table = {"stage_1": stage_1, "stage_2": stage_2, "stage_4": stage_4}
+    if name not in table:
+        raise KeyError(f"unknown map {name!r}; have {sorted(table)}")
+    return table[name]()
+
+
+def goal_rects(name):
+    """(reset_rects, respawn_rects) for a named map."""
+    if name == "stage_1":
+        return RESET_RECTS_STAGE1, RESPAWN_RECTS_STAGE1
+    if name == "stage_2":
+        return (np.concatenate([RESET_RECTS_STAGE1, STAGE2_EXTRA_RECTS]),
+                np.concatenate([RESPAWN_RECTS_STAGE1, STAGE2_EXTRA_RECTS]))
+    if name == "stage_4":
+        return (np.concatenate([RESET_RECTS_STAGE1, STAGE4_EXTRA_RECTS]),
+                np.concatenate([RESPAWN_RECTS_STAGE1, STAGE4_EXTRA_RECTS]))
+    raise KeyError(name)
+
+
+def replicate_per_env(seg, n_envs, seed=0, jitter=0.02, shuffle=True):
+    """Per-env segment buffers ``[N, S, 4]`` (BASELINE cfg 3: "per-env pose/segment buffers").
+
+    Every env gets its own copy of the map with a small random rigid offset (|d| <= jitter
+    metres, so the spawn pose and goal box stay valid) and, optionally, its own segment order,
+    so that per-env loads are real and no two envs read identical bytes.
+    """
+    rng = np.random.default_rng(seed)
+    seg = np.asarray(seg, dtype=np.float32).reshape(-1, 4)
+    S = seg.shape[0]
+    out = np.empty((n_envs, S, 4), dtype=np.float32)
+    off = rng.uniform(-jitter, jitter, size=(n_envs, 2))
+    for i in range(n_envs):
+        order = rng.permutation(S) if shuffle else np.arange(S)
+        s64 = seg[order].astype(np.float64)
+        s64[:, [0, 2]] += off[i, 0]
+        s64[:, [1, 3]] += off[i, 1]
+        out[i] = s64.astype(np.float32)
+    return out
