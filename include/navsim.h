@@ -1,0 +1,153 @@
+/*
+ * navsim.h -- C ABI of libnavsim.so: the MI355X (gfx950) batched LiDAR-navigation
+ * simulator and return scan that replace the reference's Gazebo/ROS-backed
+ * `Env.reset()/Env.step()` and `PPO.compute_rtgs()`.
+ *
+ * The reference exposes NO plugin / FFI / operator ABI for this path: its boundary is
+ * a duck-typed Python class.  Each entry point below therefore cites
+ * the reference *Python* interface it replaces; navbot_ppo_amd/env.py binds these with
+ * ctypes and re-creates that Python surface (same names, argument meaning, error
+ * behaviour).  INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; every function returns 0 on
+ *     success or a negative NAVSIM_E_* code and never throws; navsim_last_error()
+ *     gives the message for the calling thread.
+ *   - `*_dev` pointers are DEVICE (HIP) pointers owned by the caller (e.g.
+ *     torch.Tensor.data_ptr()); `*_host` pointers are host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *     asynchronous and stream-ordered unless stated otherwise; no internal threads; a
+ *     handle must not be used from two threads at once; distinct handles are independent.
+ *   - there is no CPU fallback: without a HIP device every call that touches the
+ *     device fails with NAVSIM_E_HIP.
+ */
+#ifndef NAVSIM_H
+#define NAVSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAVSIM_ABI_VERSION 1
+
+#define NAVSIM_OK 0
+#define NAVSIM_E_ARG (-1)   /* bad argument / unsupported configuration */
+#define NAVSIM_E_HIP (-2)   /* HIP runtime error (message has hipGetErrorString) */
+#define NAVSIM_E_STATE (-3) /* call order: e.g. step before set_map */
+
+typedef struct navsim navsim_t;
+
+/*
+ * Replaces the constructor arguments / module constants of the reference env:
+ *   Env(is_training, ...)                    project_ppo/src/environment_new.py:27
+ *   threshold_arrive 0.2 (train) / 0.4       environment_new.py:44-47
+ *   max_timesteps_per_episode                project_ppo/src/ppo.py:552 (the caller-side timeout)
+ *   spawn pose (0,0,0)                       turtlebot3_gazebo/launch/turtlebot3_stage_1.launch:3-5
+ *   goal box U(-3.6,3.6)^2                   environment_new.py:337-338
+ */
+typedef struct navsim_cfg {
+    int32_t n_envs;            /* N: envs simulated by this handle (one GPU's shard) */
+    int32_t n_beams;           /* B: LiDAR samples (10 = reference, gazebo.xacro:111; 36 supported) */
+    int32_t max_episode_steps; /* timeout in env steps; 0 = none */
+    int32_t auto_reset;        /* 1: envs that end are reset inside step (ppo.py:582-593) and obs is the post-reset obs */
+    int32_t respawn_on_arrive; /* 1: on arrival draw a new goal + re-base past_distance (environment_new.py:245-267) */
+    int32_t obs_f16;           /* 1: obs buffers are IEEE half instead of float */
+    uint64_t seed;             /* Philox key */
+    uint64_t env_id_base;      /* global id of env 0: RNG streams are keyed by (seed, env_id_base + i) */
+    double threshold_arrive;
+    double spawn_x, spawn_y, spawn_yaw;
+    double goal_lo, goal_hi;
+} navsim_cfg;
+
+/* ABI / build info.  navsim_version() == NAVSIM_ABI_VERSION. */
+int navsim_version(void);
+const char* navsim_last_error(void);
+
+/* Fills *cfg with the reference defaults (N=1, B=10, train threshold, stage_1 spawn and goal box). */
+void navsim_default_cfg(navsim_cfg* cfg);
+
+/* Env.__init__  (environment_new.py:27-47).  Allocates per-env state in HBM on the current device. */
+int navsim_create(const navsim_cfg* cfg, navsim_t** out);
+void navsim_destroy(navsim_t* h);
+
+/*
+ * The static world the reference gets from Gazebo (worlds/train_world_new.world:85-416):
+ * S line segments (ax,ay,bx,by) float32.  per_env=0: seg_dev is [S,4], shared by all envs;
+ * per_env=1: seg_dev is [N,S,4], env i reads its own S segments.  The buffer is NOT copied:
+ * it must stay alive and unchanged while the handle uses it.  Also ray-casts the spawn pose
+ * (the scan every reset observes) on `stream`.
+ */
+int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_t per_env, void* stream);
+
+/*
+ * Goal-rejection rectangles (xmin,xmax,ymin,ymax; inclusive), host pointer, copied.
+ * which=0: used by reset (environment_new.py:340-343); which=1: used by the arrival
+ * re-spawn (environment_new.py:248-251).  Defaults are the reference's stage_1 values.
+ * n_rects <= 16.  Synchronous.
+ */
+int navsim_set_goal_rects(navsim_t* h, int32_t which, const double* rects_host, int32_t n_rects);
+
+/*
+ * Env.reset()  (environment_new.py:312-382), masked and batched: for every env i with
+ * mask_dev[i] != 0 (all envs if mask_dev is NULL): pose <- spawn, goal <- sampled with the
+ * reset rejection rule, past_distance <- distance to goal, episode counters <- 0,
+ * past_action <- (0,0), and row i of obs_dev ([N, B+6]) <- the reset observation.
+ * Rows of unmasked envs are not written.
+ */
+int navsim_reset(navsim_t* h, const uint8_t* mask_dev, void* obs_dev, void* stream);
+
+/*
+ * Env.step(action, past_action)  (environment_new.py:272-310) for all N envs:
+ * action scaling (:273-278), 0.2 s of diff-drive motion, B-beam ray-cast, getOdometry
+ * (:138-181), getState (:183-207), observation assembly (:289-301), setReward (:209-270),
+ * plus the caller-side episode logic of PPO.rollout (ppo.py:543-593): episode step count,
+ * timeout, and -- if cfg.auto_reset -- the masked reset.
+ *
+ *   action_dev       [N,2] f32  in   (a0 in [0,1] -> v=a0/4 m/s ; a1 in [-1,1] -> w rad/s)
+ *   past_action_dev  [N,2] f32  in   nullable: NULL = the action of the previous step, (0,0)
+ *                                    after a reset (ppo.py:543,591); non-NULL = Env.step's argument
+ *   obs_dev          [N,B+6]    out  f32 (f16 if cfg.obs_f16): B lidar/3.5, past_action, dist/diag,
+ *                                    yaw/360, rel_theta/360, diff_angle/180
+ *   reward_dev       [N] f32    out
+ *   done_dev         [N] u8     out  collision flag (0 < min(scan) < 0.2)
+ *   arrive_dev       [N] u8     out  distance <= threshold_arrive
+ *   ended_dev        [N] u8     out  nullable: done | arrive | timeout (the RTG episode-end flag)
+ *   ep_return_dev    [N] f32    out  nullable: written only where ended: sum of the episode's rewards
+ *   ep_length_dev    [N] i32    out  nullable: written only where ended: episode length in steps
+ */
+int navsim_step(navsim_t* h, const float* action_dev, const float* past_action_dev, void* obs_dev,
+                float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,
+                float* ep_return_dev, int32_t* ep_length_dev, void* stream);
+
+/*
+ * Env attributes the reference's callers read or that tests / checkpoints need
+ * (position.x/.y: ppo.py:535; goal_position, past_distance: environment_new.py:29-41).
+ * HOST pointers, any of them may be NULL; SYNCHRONOUS (waits for `stream`).
+ *   pose [N,3] f64 (x,y,theta) ; goal [N,2] f64 ; past_dist [N] f64 ; past_action [N,2] f32 ;
+ *   ep_step [N] i32 ; rng_ctr [N] u32 (Philox draws consumed by env i)
+ */
+int navsim_get_state(navsim_t* h, double* pose_host, double* goal_host, double* past_dist_host,
+                     float* past_action_host, int32_t* ep_step_host, uint32_t* rng_ctr_host, void* stream);
+int navsim_set_state(navsim_t* h, const double* pose_host, const double* goal_host,
+                     const double* past_dist_host, const float* past_action_host,
+                     const int32_t* ep_step_host, const uint32_t* rng_ctr_host, void* stream);
+
+/*
+ * PPO.compute_rtgs()  (ppo.py:643-671) on the vectorised layout: rew_dev [T,N] f32,
+ * ended_dev [T,N] u8 (last step of an episode), out_dev [T,N] f32:
+ *   R[t,n] = rew[t,n] + gamma * (ended[t,n] ? 0 : R[t+1,n]),  R[T,n] = 0 (no bootstrap, ppo.py:601)
+ * accumulated in float64 and stored as float32 like the reference (:665,:669).
+ */
+int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, int32_t N, double gamma,
+                    float* out_dev, void* stream);
+
+/* LiDAR only (no state change): ranges_dev [N,B] f32 raw scan (inf = no return) for poses
+ * pose_dev [N,3] f64.  Used by tests and by map tooling (spawn_goal_sampler-style validation). */
+int navsim_raycast(navsim_t* h, const double* pose_dev, float* ranges_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAVSIM_H */

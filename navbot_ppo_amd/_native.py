@@ -1,0 +1,77 @@
+"""ctypes binding of libnavsim.so (C ABI: include/navsim.h).  No CPU fallback: if the shared
+library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnavsim.so")
+
+NAVSIM_ABI_VERSION = 1
+
+
+class NavsimError(RuntimeError):
+    pass
+
+
+class NavsimCfg(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32),
+        ("n_beams", C.c_int32),
+        ("max_episode_steps", C.c_int32),
+        ("auto_reset", C.c_int32),
+        ("respawn_on_arrive", C.c_int32),
+        ("obs_f16", C.c_int32),
+        ("seed", C.c_uint64),
+        ("env_id_base", C.c_uint64),
+        ("threshold_arrive", C.c_double),
+        ("spawn_x", C.c_double),
+        ("spawn_y", C.c_double),
+        ("spawn_yaw", C.c_double),
+        ("goal_lo", C.c_double),
+        ("goal_hi", C.c_double),
+    ]
+
+
+# every symbol include/navsim.h declares: (name, restype, argtypes)
+_vp, _i32, _d = C.c_void_p, C.c_int32, C.c_double
+SYMBOLS = [
+    ("navsim_version", C.c_int, []),
+    ("navsim_last_error", C.c_char_p, []),
+    ("navsim_default_cfg", None, [C.POINTER(NavsimCfg)]),
+    ("navsim_create", C.c_int, [C.POINTER(NavsimCfg), C.POINTER(_vp)]),
+    ("navsim_destroy", None, [_vp]),
+    ("navsim_set_map", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    ("navsim_set_goal_rects", C.c_int, [_vp, _i32, _vp, _i32]),
+    ("navsim_reset", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("navsim_step", C.c_int, [_vp] * 11),
+    ("navsim_get_state", C.c_int, [_vp] * 8),
+    ("navsim_set_state", C.c_int, [_vp] * 8),
+    ("navsim_rtg_scan", C.c_int, [_vp, _vp, _i32, _i32, _d, _vp, _vp]),
+    ("navsim_raycast", C.c_int, [_vp, _vp, _vp, _vp]),
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libnavsim.so (built by navbot_ppo_amd/build.py).  Raises if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NavsimError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc, gfx950).  There is no CPU implementation to fall back to.")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the library does not export the symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.navsim_version() != NAVSIM_ABI_VERSION:
+            raise NavsimError(f"libnavsim ABI {L.navsim_version()} != expected {NAVSIM_ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc, what="navsim"):
+    if rc != 0:
+        msg = lib().navsim_last_error()
+        raise NavsimError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,42 @@
+"""Builds navbot_ppo_amd/libnavsim.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "navsim.hip")
+INC = os.path.join(REPO, "include")
+LIB = os.path.join(HERE, "libnavsim.so")
+
+# -ffp-contract=off: the arithmetic contract writes every fused multiply-add explicitly
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libnavsim.so cannot be built (there is no CPU path)")
+    return exe
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in (SRC, os.path.join(INC, "navsim.h")))
+
+
+def build_native(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-I", INC, SRC, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

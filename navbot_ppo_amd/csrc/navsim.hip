@@ -1,0 +1,820 @@
+// navsim.hip -- gfx950 (MI355X / CDNA4) kernels + the C ABI of include/navsim.h.
+//
+// What runs here replaces, for N envs at once, the reference's
+//   Env.step / Env.reset            project_ppo/src/environment_new.py:272-382
+//   Env.getOdometry/getState/setReward               ... :138-270
+//   the Gazebo diff-drive + ray sensor they wait on   turtlebot3_fake.cpp:110-180 (motion model),
+//                                                     turtlebot3_burger.gazebo.xacro:104-127 (LiDAR)
+//   PPO.compute_rtgs                project_ppo/src/ppo.py:643-671
+//
+// Arithmetic contract (DESIGN.md "numerics"): pose, goal geometry, angles, reward in float64
+// (the reference's rounding rules -- round-half-even yaw, 1- and 2-decimal Python round() --
+// cannot be met in float32); ray/segment tests in float32 with explicit fmaf and one
+// correctly-rounded division per hit; min over hits is exact, so the result does not depend
+// on how segments are split over lanes.  Compiled with -ffp-contract=off: every fused
+// multiply-add is written out.
+//
+// Kernel layout: one workgroup = 4 waves = 64 consecutive envs.
+//   phase 1  wave 0, lane = env : integrate pose (f64), sensor origin + B beam directions -> LDS
+//   phase 2  all 4 waves        : nearest hit per (env, beam)
+//              shared map  : segments staged in LDS tiles, lane = env, wave w takes beams w, w+4, ...
+//                            (every lane reads the same segment: LDS broadcast, no conflicts)
+//              per-env map : wave w takes envs 16w..16w+15; lane = segment (16 B/lane coalesced
+//                            HBM loads, each segment read exactly once), B running minima per lane,
+//                            wavefront min-reduce per beam
+//   phase 3  wave 0, lane = env : getState / obs / reward / flags / timeout / auto-reset, state write-back
+//   phase 4  all 4 waves        : the block's 64 x (B+6) observation tile leaves LDS as one contiguous,
+//                                 fully coalesced store
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "navsim.h"
+
+namespace {
+
+constexpr double kWheelRadius = 0.033;  // turtlebot3_fake.h:39
+constexpr double kWheelSep = 0.160;     // turtlebot3_fake.cpp:44
+constexpr double kLidarX = -0.032;      // turtlebot3_burger.urdf.xacro:137
+constexpr double kAngleMin = -1.5707975, kAngleMax = 1.5707975;  // gazebo.xacro:113-114
+constexpr float kRangeMin = 0.12f, kRangeMax = 3.5f;             // gazebo.xacro:118-119
+constexpr int kSubsteps = 6;     // 30 Hz drive updates per 5 Hz scan (gazebo.xacro:62,107)
+constexpr int kMaxRects = 16;
+constexpr int kMaxGoalTries = 64;
+constexpr int EPB = 64;          // envs per workgroup
+constexpr int kThreads = 256;
+constexpr int kSegTile = 2048;   // shared-map LDS tile: 2048 segments = 32 KiB
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(NAVSIM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+struct Rects {
+    double r[2][kMaxRects][4];  // [which][k][xmin,xmax,ymin,ymax]
+    int n[2];
+};
+
+struct Params {
+    int N, B, S, per_env, max_ep_steps, auto_reset, respawn, obs_f16;
+    uint32_t key0, key1;
+    uint64_t env_id_base;
+    double thr, spawn_x, spawn_y, spawn_yaw, goal_lo, goal_hi, diag;
+    double *x, *y, *th, *gx, *gy, *past_dist, *ep_ret;
+    float2* past_action;
+    int32_t* ep_step;
+    uint32_t* rng_ctr;
+    const float4* seg;        // [S] or [N][S]
+    const float* spawn_scan;  // [B] or [N][B] raw ranges at the spawn pose
+    const double* beam_cs;    // [2][B]: cos(phi_b), sin(phi_b)
+    const Rects* rects;
+};
+
+// ---------------------------------------------------------------- device helpers
+
+// Python round(x, nd), s = 10^nd: decimal rounding, ties-to-even on the exact binary value
+// (environment_new.py:149-150,169-176).  x*s is held exactly as p + err.
+__device__ __forceinline__ double py_round(double x, double s) {
+    if (!isfinite(x)) return x;
+    const double p = x * s;
+    const double err = fma(x, s, -p);
+    const double fl = floor(p);
+    const double frac = p - fl;
+    double q = fl;
+    if (frac > 0.5) {
+        q = fl + 1.0;
+    } else if (frac == 0.5) {
+        if (err > 0.0) {
+            q = fl + 1.0;
+        } else if (err == 0.0) {
+            const double h = fl * 0.5;
+            if (h != floor(h)) q = fl + 1.0;  // fl odd -> the even neighbour is fl + 1
+        }
+    }
+    double r = q / s;
+    if (r == 0.0) r = copysign(0.0, x);
+    return r;
+}
+
+// Env.getOdometry, environment_new.py:138-181, for the yaw-only quaternion Gazebo publishes.
+__device__ __forceinline__ void goal_angles(double x, double y, double th, double gx, double gy,
+                                            double& yaw, double& rel_theta, double& diff) {
+    const double kPi = 3.14159265358979323846;
+    const double rad2deg = 180.0 / kPi;
+    const double qz = sin(th / 2), qw = cos(th / 2);
+    const double qx = 0.0, qy = 0.0;
+    yaw = rint(atan2(2 * (qx * qy + qw * qz), 1 - 2 * (qy * qy + qz * qz)) * rad2deg);  // :142
+    if (!(yaw >= 0)) yaw = yaw + 360;                                                    // :144-147
+    const double dx = py_round(gx - x, 10.0);                                            // :149
+    const double dy = py_round(gy - y, 10.0);                                            // :150
+    double theta;
+    if (dx > 0 && dy > 0)                                                                // :153-168
+        theta = atan(dy / dx);
+    else if (dx > 0 && dy < 0)
+        theta = 2 * kPi + atan(dy / dx);
+    else if (dx < 0 && dy < 0)
+        theta = kPi + atan(dy / dx);
+    else if (dx < 0 && dy > 0)
+        theta = kPi + atan(dy / dx);
+    else if (dx == 0 && dy > 0)
+        theta = 0.5 * kPi;
+    else if (dx == 0 && dy < 0)
+        theta = 1.5 * kPi;
+    else if (dy == 0 && dx > 0)
+        theta = 0;
+    else
+        theta = kPi;
+    rel_theta = py_round(theta * rad2deg, 100.0);                                        // :169
+    double d = yaw - rel_theta;                                                          // :170
+    if ((0 <= d && d <= 180) || (-180 <= d && d < 0))                                    // :171-176
+        d = py_round(d, 100.0);
+    else if (d < -180)
+        d = py_round(360 + d, 100.0);
+    else
+        d = py_round(-360 + d, 100.0);
+    diff = d;
+}
+
+// Parametric ray / segment test.  o + t d = a + u e  =>  t = cross(a-o, e) / cross(d, e),
+// u = cross(a-o, d) / cross(d, e); hit iff t >= 0 and 0 <= u <= 1, decided on the signs of the
+// numerators so the only division is the (correctly rounded) t of an actual hit.
+__device__ __forceinline__ float ray_seg(float rx, float ry, float ex, float ey, float k, float c, float s) {
+    const float den = fmaf(c, ey, -(s * ex));
+    const float un = fmaf(rx, s, -(ry * c));
+    const bool pos = (den > 0.0f) && (k >= 0.0f) && (un >= 0.0f) && (un <= den);
+    const bool neg = (den < 0.0f) && (k <= 0.0f) && (un <= 0.0f) && (un >= den);
+    return (pos || neg) ? (k / den) : INFINITY;
+}
+
+// raw LaserScan value from the nearest hit: >= max -> +inf, < min -> min (gazebo.xacro:117-120)
+__device__ __forceinline__ float scan_value(float best) {
+    if (!(best < kRangeMax)) return INFINITY;
+    return best < kRangeMin ? kRangeMin : best;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float o = __shfl_xor(v, m, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ bool goal_rejected(const Rects* R, int which, double gx, double gy) {
+    const int n = R->n[which];
+    for (int k = 0; k < n; ++k) {
+        const double* q = R->r[which][k];
+        if (q[0] <= gx && gx <= q[1] && q[2] <= gy && gy <= q[3]) return true;
+    }
+    return false;
+}
+
+// goal ~ U(lo,hi)^2 with rejection (environment_new.py:337-345 reset, :245-253 respawn);
+// one Philox call per attempt, counter = (env id, draws so far).
+__device__ __forceinline__ void sample_goal(const Params& P, int i, int which, uint32_t& ctr, double& gx, double& gy) {
+    const uint64_t gid = P.env_id_base + (uint64_t)i;
+    gx = 0;
+    gy = 0;
+    for (int tries = 0; tries < kMaxGoalTries; ++tries) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), ctr, 0x6e617673u, P.key0, P.key1, r);
+        ctr += 1;
+        const double ux = (double)((((uint64_t)r[0] << 32) | r[1]) >> 11) * 0x1.0p-53;
+        const double uy = (double)((((uint64_t)r[2] << 32) | r[3]) >> 11) * 0x1.0p-53;
+        gx = P.goal_lo + (P.goal_hi - P.goal_lo) * ux;
+        gy = P.goal_lo + (P.goal_hi - P.goal_lo) * uy;
+        if (!goal_rejected(P.rects, which, gx, gy)) break;
+    }
+}
+
+// Observation row (environment_new.py:289-301) into an LDS row of stride-1 floats.
+// `ranges` holds raw scan values for this env with element stride `rstride`.
+// Returns min(sanitised scan) for the collision rule (:200).
+__device__ __forceinline__ float write_obs_row(float* row, const float* ranges, int rstride, int B,
+                                               float pa0, float pa1, double dist, double yaw,
+                                               double rel_theta, double diff, double diag) {
+    float mn = INFINITY;
+    for (int b = 0; b < B; ++b) {
+        float r = ranges[b * rstride];
+        if (r == INFINITY) r = 3.5f;  // :193-194 (NaN / -inf cannot occur: scan_value())
+        mn = r < mn ? r : mn;
+        // (float)((double)r / 3.5) == r / 3.5f : double rounding is innocuous for a quotient of
+        // two float32 values (53 >= 2*24+2), so the float32 divide gives the reference's bits.
+        row[b] = r / 3.5f;            // :289
+    }
+    row[B + 0] = pa0;                 // :299-300
+    row[B + 1] = pa1;
+    row[B + 2] = (float)(dist / diag);       // :301
+    row[B + 3] = (float)(yaw / 360);
+    row[B + 4] = (float)(rel_theta / 360);
+    row[B + 5] = (float)(diff / 180);
+    return mn;
+}
+
+template <int NB>
+struct StepSmem {
+    float2 org[EPB];             // sensor origin per env
+    float2 dir[NB * EPB];        // [beam][env] unit direction
+    float rng[NB * EPB];         // [beam][env] raw scan value
+    float obs[EPB * (NB + 7)];   // [env][B+6 (+1 pad: odd row stride, conflict-free)] the block's output tile
+};
+
+// ---------------------------------------------------------------- the step kernel
+template <int NB, bool PER_ENV>
+__global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* __restrict__ action,
+                                                        const float2* __restrict__ past_override,
+                                                        void* __restrict__ obs_out, float* __restrict__ reward,
+                                                        uint8_t* __restrict__ done, uint8_t* __restrict__ arrive,
+                                                        uint8_t* __restrict__ ended, float* __restrict__ ep_return,
+                                                        int32_t* __restrict__ ep_length) {
+    __shared__ StepSmem<NB> sm;
+    __shared__ float4 seg_tile[PER_ENV ? 1 : kSegTile];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int base = blockIdx.x * EPB;
+    constexpr int B = NB;       // host dispatch guarantees P.B == NB
+    constexpr int D = B + 6;
+    constexpr int DP = D + 1;   // padded LDS row stride
+    const int nloc = min(EPB, P.N - base);  // envs in this block
+
+    // per-env registers of wave 0 that live across the phases
+    double x = 0, y = 0, th = 0, gx = 0, gy = 0, pdist = 0, dist = 0, yaw = 0, rel_theta = 0, diff = 0;
+    float2 act = make_float2(0.f, 0.f), pact = make_float2(0.f, 0.f);
+    const int i = base + lane;
+    const bool own = (wave == 0) && (lane < nloc);
+
+    // ---------------- phase 1: motion + sensor frame (wave 0, lane = env)
+    if (wave == 0) {
+        if (own) {
+            x = P.x[i]; y = P.y[i]; th = P.th[i];
+            gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
+            act = action[i];
+            pact = past_override ? past_override[i] : P.past_action[i];
+            // environment_new.py:273-278
+            const double v = (double)act.x / 4;
+            const double w = (double)act.y;
+            // turtlebot3_fake.cpp:117-118, :133-146, :154-155
+            const double vl = v - (w * kWheelSep / 2);
+            const double vr = v + (w * kWheelSep / 2);
+            const double dt = 1.0 / 30.0;
+            const double wl = vl / kWheelRadius, wr = vr / kWheelRadius;
+            const double wheel_l = wl * dt, wheel_r = wr * dt;
+            const double delta_s = kWheelRadius * (wheel_r + wheel_l) / 2.0;
+            const double delta_theta = kWheelRadius * (wheel_r - wheel_l) / kWheelSep;
+            for (int k = 0; k < kSubsteps; ++k) {  // :158-160
+                const double a = th + (delta_theta / 2.0);
+                x += delta_s * cos(a);
+                y += delta_s * sin(a);
+                th += delta_theta;
+            }
+        }
+        const double cth = cos(th), sth = sin(th);
+        const double ox = x + kLidarX * cth;
+        const double oy = y + kLidarX * sth;
+        sm.org[lane] = make_float2((float)ox, (float)oy);
+        for (int b = 0; b < B; ++b) {
+            const double bc = P.beam_cs[b], bs = P.beam_cs[B + b];
+            const double c = cth * bc - sth * bs;
+            const double s = sth * bc + cth * bs;
+            sm.dir[b * EPB + lane] = make_float2((float)c, (float)s);
+        }
+        if (own) {
+            goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
+            dist = hypot(gx - x, gy - y);  // environment_new.py:203
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: nearest hit per (env, beam)
+    if constexpr (PER_ENV) {
+        constexpr int EPW = EPB / (kThreads / 64);  // envs per wave
+        for (int q = 0; q < EPW; ++q) {
+            const int el = wave * EPW + q;
+            if (el >= nloc) break;  // wave-uniform
+            const float2 o = sm.org[el];
+            float dc[NB], ds[NB], best[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float2 d = sm.dir[b * EPB + el];
+                dc[b] = d.x;
+                ds[b] = d.y;
+                best[b] = INFINITY;
+            }
+            const float4* __restrict__ sp = P.seg + (size_t)(base + el) * P.S;
+            for (int j = lane; j < P.S; j += 64) {
+                const float4 g = sp[j];
+                const float rx = g.x - o.x, ry = g.y - o.y;
+                const float ex = g.z - g.x, ey = g.w - g.y;
+                const float k = fmaf(rx, ey, -(ry * ex));
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const float t = ray_seg(rx, ry, ex, ey, k, dc[b], ds[b]);
+                    best[b] = t < best[b] ? t : best[b];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float v = wave_min(best[b]);
+                if (lane == 0) sm.rng[b * EPB + el] = scan_value(v);
+            }
+        }
+    } else {
+        constexpr int MB = (NB + 3) / 4;  // beams per wave
+        const float2 o = sm.org[lane];
+        float dc[MB], ds[MB], best[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int b = wave + 4 * m;
+            const float2 d = sm.dir[(b < NB ? b : 0) * EPB + lane];
+            dc[m] = d.x;
+            ds[m] = d.y;
+            best[m] = INFINITY;
+        }
+        for (int s0 = 0; s0 < P.S; s0 += kSegTile) {
+            const int ns = min(kSegTile, P.S - s0);
+            if (s0 > 0) __syncthreads();
+            for (int j = tid; j < ns; j += kThreads) seg_tile[j] = P.seg[s0 + j];
+            __syncthreads();
+            for (int j = 0; j < ns; ++j) {
+                const float4 g = seg_tile[j];
+                const float rx = g.x - o.x, ry = g.y - o.y;
+                const float ex = g.z - g.x, ey = g.w - g.y;
+                const float k = fmaf(rx, ey, -(ry * ex));
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const float t = ray_seg(rx, ry, ex, ey, k, dc[m], ds[m]);
+                    best[m] = t < best[m] ? t : best[m];
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int b = wave + 4 * m;
+            if (b < NB) sm.rng[b * EPB + lane] = scan_value(best[m]);
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 3: rules of getState / step / setReward + episode logic (wave 0)
+    if (own) {
+        float* row = sm.obs + lane * DP;
+        const float mn = write_obs_row(row, sm.rng + lane, EPB, B, pact.x, pact.y, dist, yaw, rel_theta, diff, P.diag);
+        const bool d = (0.2 > (double)mn) && ((double)mn > 0);  // environment_new.py:200
+        const bool a = dist <= P.thr;                             // :204
+        // setReward, :209-222
+        double r = 500. * (pdist - dist);
+        pdist = dist;
+        if (d) r = -100.;
+        if (a) r = 120.;
+        uint32_t ctr = P.rng_ctr[i];
+        if (a && P.respawn) {  // :245-267
+            sample_goal(P, i, 1, ctr, gx, gy);
+            pdist = hypot(gx - x, gy - y);
+        }
+        int step = P.ep_step[i] + 1;
+        double ret = P.ep_ret[i] + r;
+        const bool timeout = (P.max_ep_steps > 0) && (step >= P.max_ep_steps);  // ppo.py:552
+        const bool end = d || a || timeout;
+        reward[i] = (float)r;
+        done[i] = d ? 1 : 0;
+        arrive[i] = a ? 1 : 0;
+        if (ended) ended[i] = end ? 1 : 0;
+        if (end) {
+            if (ep_return) ep_return[i] = (float)ret;
+            if (ep_length) ep_length[i] = step;
+        }
+        float2 next_pact = act;  // ppo.py:543
+        if (end && P.auto_reset) {  // ppo.py:582-593 + Env.reset, environment_new.py:312-382
+            x = P.spawn_x; y = P.spawn_y; th = P.spawn_yaw;
+            sample_goal(P, i, 0, ctr, gx, gy);
+            step = 0;
+            ret = 0;
+            next_pact = make_float2(0.f, 0.f);
+            goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
+            dist = hypot(gx - x, gy - y);
+            pdist = dist;  // getGoalDistace, :116-120,:359
+            const float* sp = P.spawn_scan + (PER_ENV ? (size_t)i * B : 0);
+            write_obs_row(row, sp, 1, B, 0.f, 0.f, dist, yaw, rel_theta, diff, P.diag);
+        }
+        P.x[i] = x; P.y[i] = y; P.th[i] = th;
+        P.gx[i] = gx; P.gy[i] = gy; P.past_dist[i] = pdist;
+        P.past_action[i] = next_pact;
+        P.ep_step[i] = step;
+        P.ep_ret[i] = ret;
+        P.rng_ctr[i] = ctr;
+    }
+    __syncthreads();
+
+    // ---------------- phase 4: coalesced store of the block's observation tile
+    const int n_out = nloc * D;
+    if (P.obs_f16) {
+        __half* o = reinterpret_cast<__half*>(obs_out) + (size_t)base * D;
+        for (int k = tid; k < n_out; k += kThreads) o[k] = __float2half_rn(sm.obs[(k / D) * DP + (k % D)]);
+    } else {
+        float* o = reinterpret_cast<float*>(obs_out) + (size_t)base * D;
+        for (int k = tid; k < n_out; k += kThreads) o[k] = sm.obs[(k / D) * DP + (k % D)];
+    }
+}
+
+// ---------------------------------------------------------------- reset (Env.reset, masked)
+__global__ void reset_kernel(Params P, const uint8_t* __restrict__ mask, void* __restrict__ obs_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.N) return;
+    if (mask && !mask[i]) return;
+    const int B = P.B, D = B + 6;
+    uint32_t ctr = P.rng_ctr[i];
+    double gx, gy, yaw, rel_theta, diff;
+    const double x = P.spawn_x, y = P.spawn_y, th = P.spawn_yaw;
+    sample_goal(P, i, 0, ctr, gx, gy);
+    goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
+    const double dist = hypot(gx - x, gy - y);
+    const float* sp = P.spawn_scan + (P.per_env ? (size_t)i * B : 0);
+    // row assembled straight in global memory for the f32 case, via registers for f16
+    if (P.obs_f16) {
+        __half* o = reinterpret_cast<__half*>(obs_out) + (size_t)i * D;
+        for (int b = 0; b < B; ++b) {
+            float r = sp[b];
+            if (r == INFINITY) r = 3.5f;
+            o[b] = __float2half_rn(r / 3.5f);
+        }
+        o[B] = __float2half_rn(0.f);
+        o[B + 1] = __float2half_rn(0.f);
+        o[B + 2] = __float2half_rn((float)(dist / P.diag));
+        o[B + 3] = __float2half_rn((float)(yaw / 360));
+        o[B + 4] = __float2half_rn((float)(rel_theta / 360));
+        o[B + 5] = __float2half_rn((float)(diff / 180));
+    } else {
+        float* o = reinterpret_cast<float*>(obs_out) + (size_t)i * D;
+        write_obs_row(o, sp, 1, B, 0.f, 0.f, dist, yaw, rel_theta, diff, P.diag);
+    }
+    P.x[i] = x; P.y[i] = y; P.th[i] = th;
+    P.gx[i] = gx; P.gy[i] = gy; P.past_dist[i] = dist;
+    P.past_action[i] = make_float2(0.f, 0.f);
+    P.ep_step[i] = 0;
+    P.ep_ret[i] = 0;
+    P.rng_ctr[i] = ctr;
+}
+
+// ---------------------------------------------------------------- LiDAR only (spawn scans, tests, tooling)
+// thread = env; pose [n,3] f64 (or one shared pose when pose_stride == 0)
+__global__ void raycast_kernel(Params P, const double* __restrict__ pose, int pose_stride, int n,
+                               float* __restrict__ ranges) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = pose[(size_t)i * pose_stride + 0], y = pose[(size_t)i * pose_stride + 1],
+                 th = pose[(size_t)i * pose_stride + 2];
+    const double cth = cos(th), sth = sin(th);
+    const float ox = (float)(x + kLidarX * cth), oy = (float)(y + kLidarX * sth);
+    const float4* __restrict__ sp = P.seg + (P.per_env ? (size_t)i * P.S : 0);
+    for (int b = 0; b < P.B; ++b) {
+        const double bc = P.beam_cs[b], bs = P.beam_cs[P.B + b];
+        const float c = (float)(cth * bc - sth * bs);
+        const float s = (float)(sth * bc + cth * bs);
+        float best = INFINITY;
+        for (int j = 0; j < P.S; ++j) {
+            const float4 g = sp[j];
+            const float rx = g.x - ox, ry = g.y - oy;
+            const float ex = g.z - g.x, ey = g.w - g.y;
+            const float k = fmaf(rx, ey, -(ry * ex));
+            const float t = ray_seg(rx, ry, ex, ey, k, c, s);
+            best = t < best ? t : best;
+        }
+        ranges[(size_t)i * P.B + b] = scan_value(best);
+    }
+}
+
+// ---------------------------------------------------------------- return scan (PPO.compute_rtgs)
+// thread = env column, reverse over T; loads are independent of the recurrence so they pipeline.
+__global__ void rtg_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ ended, int T, int N,
+                           double gamma, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double disc = 0;  // ppo.py:660
+#pragma unroll 8
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t k = (size_t)t * N + n;
+        const float r = rew[k];
+        if (ended[k]) disc = 0;
+        disc = (double)r + disc * gamma;  // ppo.py:665
+        out[k] = (float)disc;             // ppo.py:669
+    }
+}
+
+}  // namespace
+
+// ==================================================================== host side / C ABI
+struct navsim {
+    navsim_cfg cfg;
+    Params P;
+    void* state_block = nullptr;   // one allocation for all per-env state
+    double* beam_cs_dev = nullptr;
+    Rects* rects_dev = nullptr;
+    Rects rects_host;
+    float* spawn_scan_dev = nullptr;
+    double* spawn_pose_dev = nullptr;
+    bool has_map = false;
+};
+
+template <int NB>
+static void launch_step(const navsim* h, const float* action, const float* past, void* obs, float* reward,
+                        uint8_t* done, uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len,
+                        hipStream_t st) {
+    const dim3 grid((h->P.N + EPB - 1) / EPB), block(kThreads);
+    if (h->P.per_env)
+        hipLaunchKernelGGL((step_kernel<NB, true>), grid, block, 0, st, h->P, (const float2*)action,
+                           (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len);
+    else
+        hipLaunchKernelGGL((step_kernel<NB, false>), grid, block, 0, st, h->P, (const float2*)action,
+                           (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len);
+}
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int navsim_version(void) { return NAVSIM_ABI_VERSION; }
+
+const char* navsim_last_error(void) { return g_err.c_str(); }
+
+void navsim_default_cfg(navsim_cfg* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->n_envs = 1;
+    c->n_beams = 10;            // gazebo.xacro:111
+    c->threshold_arrive = 0.2;  // environment_new.py:45
+    c->goal_lo = -3.6;          // environment_new.py:337
+    c->goal_hi = 3.6;
+}
+
+static const double kResetRects[4][4] = {  // environment_new.py:340-343
+    {1.7, 2.3, -1.2, 1.2}, {-2.3, -1.7, -1.2, 1.2}, {-1.2, 1.2, 1.7, 2.3}, {-1.2, 1.2, -2.3, -1.7}};
+static const double kRespawnRects[4][4] = {  // environment_new.py:248-251
+    {1.6, 2.4, -1.4, 1.4}, {-2.4, -1.6, -1.4, 1.4}, {-1.4, 1.4, 1.6, 2.4}, {-1.4, 1.4, -2.4, -1.6}};
+
+int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
+    if (!cfg || !out) return fail(NAVSIM_E_ARG, "navsim_create: null argument");
+    *out = nullptr;
+    if (cfg->n_envs < 1) return fail(NAVSIM_E_ARG, "navsim_create: n_envs must be >= 1");
+    if (cfg->n_beams != 10 && cfg->n_beams != 36)
+        return fail(NAVSIM_E_ARG, "navsim_create: n_beams must be 10 or 36");
+    if (!(cfg->goal_hi > cfg->goal_lo)) return fail(NAVSIM_E_ARG, "navsim_create: empty goal box");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(NAVSIM_E_HIP, "navsim_create: no HIP device (there is no CPU path)");
+
+    navsim* h = new navsim();
+    h->cfg = *cfg;
+    const size_t N = (size_t)cfg->n_envs;
+    const int B = cfg->n_beams;
+    // one block: 7 f64 arrays, float2 past_action, i32 ep_step, u32 rng_ctr
+    const size_t bytes = N * (7 * sizeof(double) + sizeof(float2) + sizeof(int32_t) + sizeof(uint32_t));
+    hipError_t e = hipMalloc(&h->state_block, bytes);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(NAVSIM_E_HIP, std::string("hipMalloc(state): ") + hipGetErrorString(e));
+    }
+    HIP_TRY(hipMemset(h->state_block, 0, bytes));
+    Params& P = h->P;
+    std::memset(&P, 0, sizeof(P));
+    double* d = reinterpret_cast<double*>(h->state_block);
+    P.x = d; P.y = d + N; P.th = d + 2 * N; P.gx = d + 3 * N; P.gy = d + 4 * N;
+    P.past_dist = d + 5 * N; P.ep_ret = d + 6 * N;
+    P.past_action = reinterpret_cast<float2*>(d + 7 * N);
+    P.ep_step = reinterpret_cast<int32_t*>(P.past_action + N);
+    P.rng_ctr = reinterpret_cast<uint32_t*>(P.ep_step + N);
+    P.N = cfg->n_envs;
+    P.B = B;
+    P.max_ep_steps = cfg->max_episode_steps;
+    P.auto_reset = cfg->auto_reset;
+    P.respawn = cfg->respawn_on_arrive;
+    P.obs_f16 = cfg->obs_f16;
+    P.key0 = (uint32_t)cfg->seed;
+    P.key1 = (uint32_t)(cfg->seed >> 32);
+    P.env_id_base = cfg->env_id_base;
+    P.thr = cfg->threshold_arrive;
+    P.spawn_x = cfg->spawn_x; P.spawn_y = cfg->spawn_y; P.spawn_yaw = cfg->spawn_yaw;
+    P.goal_lo = cfg->goal_lo; P.goal_hi = cfg->goal_hi;
+    P.diag = std::sqrt(2.0) * (3.8 + 3.8);  // environment_new.py:21
+
+    // beam table: samples evenly over [min_angle, max_angle] (gazebo.xacro:110-115)
+    double cs[2 * 64];
+    for (int i = 0; i < B; ++i) {
+        const double phi = kAngleMin + (double)i * ((kAngleMax - kAngleMin) / (double)(B - 1));
+        cs[i] = std::cos(phi);
+        cs[B + i] = std::sin(phi);
+    }
+    HIP_TRY(hipMalloc(&h->beam_cs_dev, sizeof(double) * 2 * B));
+    HIP_TRY(hipMemcpy(h->beam_cs_dev, cs, sizeof(double) * 2 * B, hipMemcpyHostToDevice));
+    P.beam_cs = h->beam_cs_dev;
+
+    std::memset(&h->rects_host, 0, sizeof(Rects));
+    std::memcpy(h->rects_host.r[0], kResetRects, sizeof(kResetRects));
+    std::memcpy(h->rects_host.r[1], kRespawnRects, sizeof(kRespawnRects));
+    h->rects_host.n[0] = h->rects_host.n[1] = 4;
+    HIP_TRY(hipMalloc(&h->rects_dev, sizeof(Rects)));
+    HIP_TRY(hipMemcpy(h->rects_dev, &h->rects_host, sizeof(Rects), hipMemcpyHostToDevice));
+    P.rects = h->rects_dev;
+
+    // pose state starts at the spawn pose (the robot's pose before the first reset)
+    {
+        const double sp[3] = {cfg->spawn_x, cfg->spawn_y, cfg->spawn_yaw};
+        HIP_TRY(hipMalloc(&h->spawn_pose_dev, sizeof(sp)));
+        HIP_TRY(hipMemcpy(h->spawn_pose_dev, sp, sizeof(sp), hipMemcpyHostToDevice));
+    }
+    *out = h;
+    return NAVSIM_OK;
+}
+
+void navsim_destroy(navsim_t* h) {
+    if (!h) return;
+    (void)hipFree(h->state_block);
+    (void)hipFree(h->beam_cs_dev);
+    (void)hipFree(h->rects_dev);
+    (void)hipFree(h->spawn_scan_dev);
+    (void)hipFree(h->spawn_pose_dev);
+    delete h;
+}
+
+int navsim_set_goal_rects(navsim_t* h, int32_t which, const double* rects_host, int32_t n_rects) {
+    if (!h || (which != 0 && which != 1) || n_rects < 0 || n_rects > kMaxRects || (n_rects && !rects_host))
+        return fail(NAVSIM_E_ARG, "navsim_set_goal_rects: bad argument");
+    HIP_TRY(hipDeviceSynchronize());
+    std::memcpy(h->rects_host.r[which], rects_host, sizeof(double) * 4 * n_rects);
+    h->rects_host.n[which] = n_rects;
+    HIP_TRY(hipMemcpy(h->rects_dev, &h->rects_host, sizeof(Rects), hipMemcpyHostToDevice));
+    return NAVSIM_OK;
+}
+
+int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_t per_env, void* stream) {
+    if (!h || !seg_dev || n_segments < 1) return fail(NAVSIM_E_ARG, "navsim_set_map: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    Params& P = h->P;
+    P.seg = reinterpret_cast<const float4*>(seg_dev);
+    P.S = n_segments;
+    P.per_env = per_env ? 1 : 0;
+    const size_t n_scan = (size_t)(per_env ? P.N : 1) * P.B;
+    if (h->spawn_scan_dev) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipFree(h->spawn_scan_dev));
+        h->spawn_scan_dev = nullptr;
+    }
+    HIP_TRY(hipMalloc(&h->spawn_scan_dev, n_scan * sizeof(float)));
+    P.spawn_scan = h->spawn_scan_dev;
+    const int n = per_env ? P.N : 1;
+    hipLaunchKernelGGL(raycast_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, h->spawn_pose_dev, 0, n,
+                       h->spawn_scan_dev);
+    HIP_TRY(hipGetLastError());
+    h->has_map = true;
+    return NAVSIM_OK;
+}
+
+int navsim_reset(navsim_t* h, const uint8_t* mask_dev, void* obs_dev, void* stream) {
+    if (!h || !obs_dev) return fail(NAVSIM_E_ARG, "navsim_reset: bad argument");
+    if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_reset: call navsim_set_map first");
+    hipLaunchKernelGGL(reset_kernel, dim3((h->P.N + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, mask_dev,
+                       obs_dev);
+    HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
+}
+
+int navsim_step(navsim_t* h, const float* action_dev, const float* past_action_dev, void* obs_dev,
+                float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,
+                float* ep_return_dev, int32_t* ep_length_dev, void* stream) {
+    if (!h || !action_dev || !obs_dev || !reward_dev || !done_dev || !arrive_dev)
+        return fail(NAVSIM_E_ARG, "navsim_step: null required buffer");
+    if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_step: call navsim_set_map first");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->P.B == 10)
+        launch_step<10>(h, action_dev, past_action_dev, obs_dev, reward_dev, done_dev, arrive_dev, ended_dev,
+                        ep_return_dev, ep_length_dev, st);
+    else
+        launch_step<36>(h, action_dev, past_action_dev, obs_dev, reward_dev, done_dev, arrive_dev, ended_dev,
+                        ep_return_dev, ep_length_dev, st);
+    HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
+}
+
+int navsim_raycast(navsim_t* h, const double* pose_dev, float* ranges_dev, void* stream) {
+    if (!h || !pose_dev || !ranges_dev) return fail(NAVSIM_E_ARG, "navsim_raycast: bad argument");
+    if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_raycast: call navsim_set_map first");
+    hipLaunchKernelGGL(raycast_kernel, dim3((h->P.N + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, pose_dev, 3,
+                       h->P.N, ranges_dev);
+    HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
+}
+
+int navsim_get_state(navsim_t* h, double* pose, double* goal, double* past_dist, float* past_action,
+                     int32_t* ep_step, uint32_t* rng_ctr, void* stream) {
+    if (!h) return fail(NAVSIM_E_ARG, "navsim_get_state: null handle");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    const size_t N = (size_t)h->P.N;
+    const Params& P = h->P;
+    if (pose) {
+        double* tmp = new double[3 * N];
+        hipError_t e = hipMemcpy(tmp, P.x, sizeof(double) * 3 * N, hipMemcpyDeviceToHost);  // x,y,th are adjacent
+        if (e == hipSuccess)
+            for (size_t i = 0; i < N; ++i) {
+                pose[3 * i] = tmp[i];
+                pose[3 * i + 1] = tmp[N + i];
+                pose[3 * i + 2] = tmp[2 * N + i];
+            }
+        delete[] tmp;
+        HIP_TRY(e);
+    }
+    if (goal) {
+        double* tmp = new double[2 * N];
+        hipError_t e = hipMemcpy(tmp, P.gx, sizeof(double) * 2 * N, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (size_t i = 0; i < N; ++i) {
+                goal[2 * i] = tmp[i];
+                goal[2 * i + 1] = tmp[N + i];
+            }
+        delete[] tmp;
+        HIP_TRY(e);
+    }
+    if (past_dist) HIP_TRY(hipMemcpy(past_dist, P.past_dist, sizeof(double) * N, hipMemcpyDeviceToHost));
+    if (past_action) HIP_TRY(hipMemcpy(past_action, P.past_action, sizeof(float2) * N, hipMemcpyDeviceToHost));
+    if (ep_step) HIP_TRY(hipMemcpy(ep_step, P.ep_step, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    if (rng_ctr) HIP_TRY(hipMemcpy(rng_ctr, P.rng_ctr, sizeof(uint32_t) * N, hipMemcpyDeviceToHost));
+    return NAVSIM_OK;
+}
+
+int navsim_set_state(navsim_t* h, const double* pose, const double* goal, const double* past_dist,
+                     const float* past_action, const int32_t* ep_step, const uint32_t* rng_ctr, void* stream) {
+    if (!h) return fail(NAVSIM_E_ARG, "navsim_set_state: null handle");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    const size_t N = (size_t)h->P.N;
+    const Params& P = h->P;
+    if (pose) {
+        double* tmp = new double[3 * N];
+        for (size_t i = 0; i < N; ++i) {
+            tmp[i] = pose[3 * i];
+            tmp[N + i] = pose[3 * i + 1];
+            tmp[2 * N + i] = pose[3 * i + 2];
+        }
+        hipError_t e = hipMemcpy(P.x, tmp, sizeof(double) * 3 * N, hipMemcpyHostToDevice);
+        delete[] tmp;
+        HIP_TRY(e);
+    }
+    if (goal) {
+        double* tmp = new double[2 * N];
+        for (size_t i = 0; i < N; ++i) {
+            tmp[i] = goal[2 * i];
+            tmp[N + i] = goal[2 * i + 1];
+        }
+        hipError_t e = hipMemcpy(P.gx, tmp, sizeof(double) * 2 * N, hipMemcpyHostToDevice);
+        delete[] tmp;
+        HIP_TRY(e);
+    }
+    if (past_dist) HIP_TRY(hipMemcpy(P.past_dist, past_dist, sizeof(double) * N, hipMemcpyHostToDevice));
+    if (past_action) HIP_TRY(hipMemcpy(P.past_action, past_action, sizeof(float2) * N, hipMemcpyHostToDevice));
+    if (ep_step) HIP_TRY(hipMemcpy(P.ep_step, ep_step, sizeof(int32_t) * N, hipMemcpyHostToDevice));
+    if (rng_ctr) HIP_TRY(hipMemcpy(P.rng_ctr, rng_ctr, sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+    return NAVSIM_OK;
+}
+
+int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, int32_t N, double gamma,
+                    float* out_dev, void* stream) {
+    if (!rew_dev || !ended_dev || !out_dev || T < 0 || N < 0) return fail(NAVSIM_E_ARG, "navsim_rtg_scan: bad argument");
+    if (T == 0 || N == 0) return NAVSIM_OK;
+    hipLaunchKernelGGL(rtg_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N,
+                       gamma, out_dev);
+    HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,285 @@
+"""Host-side mirror of the reference environment interface over libnavsim.so.
+
+``Env`` is the N=1 drop-in for ``project_ppo/src/environment_new.py:26`` (same constructor
+arguments, ``reset()``/``step(action, past_action)`` return types, and the attributes its callers
+read: ``position.x/.y`` (ppo.py:535, main.py:202), ``goal_position.position.x/.y``,
+``threshold_arrive``, ``past_distance``, ``use_vision``).  ``VecEnv`` is the batched form the
+rollout of ``ppo.py:463-641`` becomes on a GPU: N envs per call, device tensors in and out,
+auto-reset inside the step kernel.
+
+PyTorch is used for device memory and streams only; all simulation happens in the HIP kernels.
+"""
+import ctypes as C
+import math
+import types
+
+import numpy as np
+import torch
+
+from . import maps as _maps
+from ._native import NavsimCfg, NavsimError, check, lib
+
+__all__ = ["NavSim", "VecEnv", "Env", "NavsimError"]
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class NavSim:
+    """One libnavsim handle (= one GPU's shard of envs) with torch tensors as buffers."""
+
+    def __init__(self, n_envs, n_beams=10, max_episode_steps=0, auto_reset=False, respawn_on_arrive=False,
+                 seed=0, env_id_base=0, threshold_arrive=0.2, spawn=(0.0, 0.0, 0.0), goal_box=(-3.6, 3.6),
+                 obs_f16=False, device=None):
+        if not torch.cuda.is_available():
+            raise NavsimError("navbot_ppo_amd needs a HIP device (MI355X); there is no CPU path")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.N, self.B, self.D = int(n_envs), int(n_beams), int(n_beams) + 6
+        self.obs_dtype = torch.float16 if obs_f16 else torch.float32
+        self.cfg = NavsimCfg(self.N, self.B, int(max_episode_steps), int(bool(auto_reset)), int(bool(respawn_on_arrive)),
+                             int(bool(obs_f16)), int(seed), int(env_id_base), float(threshold_arrive),
+                             float(spawn[0]), float(spawn[1]), float(spawn[2]), float(goal_box[0]), float(goal_box[1]))
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().navsim_create(C.byref(self.cfg), C.byref(self._h)), "navsim_create")
+        self._seg = None  # keeps the map tensor alive: the handle only borrows the pointer
+
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            lib().navsim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- world
+    def set_map(self, seg, per_env=None):
+        seg = torch.as_tensor(np.asarray(seg, dtype=np.float32) if not torch.is_tensor(seg) else seg)
+        seg = seg.to(device=self.device, dtype=torch.float32).contiguous()
+        if per_env is None:
+            per_env = seg.dim() == 3
+        if seg.shape[-1] != 4 or seg.dim() != (3 if per_env else 2) or (per_env and seg.shape[0] != self.N):
+            raise NavsimError(f"bad map shape {tuple(seg.shape)} for per_env={per_env}, N={self.N}")
+        with torch.cuda.device(self.device):
+            check(lib().navsim_set_map(self._h, _ptr(seg), int(seg.shape[-2]), int(bool(per_env)), _stream()), "navsim_set_map")
+        self._seg = seg
+        self.S, self.per_env = int(seg.shape[-2]), bool(per_env)
+
+    def set_goal_rects(self, which, rects):
+        r = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
+        check(lib().navsim_set_goal_rects(self._h, int(which), _np_ptr(r), r.shape[0]), "navsim_set_goal_rects")
+
+    # -- buffers
+    def alloc_io(self):
+        dev, N = self.device, self.N
+        return types.SimpleNamespace(
+            obs=torch.zeros((N, self.D), dtype=self.obs_dtype, device=dev),
+            reward=torch.zeros(N, dtype=torch.float32, device=dev),
+            done=torch.zeros(N, dtype=torch.uint8, device=dev),
+            arrive=torch.zeros(N, dtype=torch.uint8, device=dev),
+            ended=torch.zeros(N, dtype=torch.uint8, device=dev),
+            ep_return=torch.zeros(N, dtype=torch.float32, device=dev),
+            ep_length=torch.zeros(N, dtype=torch.int32, device=dev))
+
+    # -- calls (all asynchronous on torch's current stream)
+    def reset(self, obs, mask=None):
+        with torch.cuda.device(self.device):
+            check(lib().navsim_reset(self._h, _ptr(mask), _ptr(obs), _stream()), "navsim_reset")
+        return obs
+
+    def step(self, action, obs, reward, done, arrive, ended=None, ep_return=None, ep_length=None, past_action=None):
+        with torch.cuda.device(self.device):
+            check(lib().navsim_step(self._h, _ptr(action), _ptr(past_action), _ptr(obs), _ptr(reward), _ptr(done),
+                                    _ptr(arrive), _ptr(ended), _ptr(ep_return), _ptr(ep_length), _stream()), "navsim_step")
+
+    def raycast(self, pose):
+        pose = pose.to(device=self.device, dtype=torch.float64).contiguous()
+        out = torch.empty((self.N, self.B), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().navsim_raycast(self._h, _ptr(pose), _ptr(out), _stream()), "navsim_raycast")
+        return out
+
+    def get_state(self):
+        N = self.N
+        st = dict(pose=np.empty((N, 3)), goal=np.empty((N, 2)), past_dist=np.empty(N),
+                  past_action=np.empty((N, 2), np.float32), ep_step=np.empty(N, np.int32), rng_ctr=np.empty(N, np.uint32))
+        with torch.cuda.device(self.device):
+            check(lib().navsim_get_state(self._h, *[_np_ptr(st[k]) for k in
+                                                    ("pose", "goal", "past_dist", "past_action", "ep_step", "rng_ctr")],
+                                         _stream()), "navsim_get_state")
+        return st
+
+    def set_state(self, pose=None, goal=None, past_dist=None, past_action=None, ep_step=None, rng_ctr=None):
+        def cv(a, dt, shape):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt)
+            if a.shape != shape:
+                raise NavsimError(f"set_state: expected shape {shape}, got {a.shape}")
+            return a
+        N = self.N
+        arrs = [cv(pose, np.float64, (N, 3)), cv(goal, np.float64, (N, 2)), cv(past_dist, np.float64, (N,)),
+                cv(past_action, np.float32, (N, 2)), cv(ep_step, np.int32, (N,)), cv(rng_ctr, np.uint32, (N,))]
+        with torch.cuda.device(self.device):
+            check(lib().navsim_set_state(self._h, *[_np_ptr(a) for a in arrs], _stream()), "navsim_set_state")
+
+
+def rtg_scan(rew, ended, gamma, out=None):
+    """PPO.compute_rtgs (ppo.py:643-671) on [T,N] device tensors; see navsim_rtg_scan."""
+    if not rew.is_cuda:
+        raise NavsimError("rtg_scan needs device tensors; there is no CPU path")
+    T, N = rew.shape
+    rew = rew.contiguous()
+    ended = ended.contiguous()
+    assert rew.dtype == torch.float32 and ended.dtype == torch.uint8 and ended.shape == rew.shape
+    if out is None:
+        out = torch.empty_like(rew)
+    with torch.cuda.device(rew.device):
+        check(lib().navsim_rtg_scan(_ptr(rew), _ptr(ended), T, N, float(gamma), _ptr(out), _stream()), "navsim_rtg_scan")
+    return out
+
+
+class VecEnv:
+    """N environments stepped by one kernel launch; tensors stay on the GPU.
+
+    ``step(action)`` mirrors ``Env.step`` per env and the episode bookkeeping of
+    ``PPO.rollout`` (ppo.py:543-593): past_action tracking, timeout after
+    ``max_episode_steps``, and -- with ``auto_reset`` -- the reset, in which case the returned
+    observation is the post-reset one (what ``rollout`` stores next, ppo.py:508,593).
+    """
+
+    def __init__(self, n_envs, map="stage_1", n_beams=10, max_episode_steps=500, auto_reset=True, is_training=True,
+                 seed=0, env_id_base=0, per_env_map=False, map_seed=0, obs_f16=False, device=None):
+        thr = 0.2 if is_training else 0.4  # environment_new.py:44-47
+        self.sim = NavSim(n_envs, n_beams=n_beams, max_episode_steps=max_episode_steps, auto_reset=auto_reset,
+                          respawn_on_arrive=False, seed=seed, env_id_base=env_id_base, threshold_arrive=thr,
+                          obs_f16=obs_f16, device=device)
+        self.N, self.B, self.D, self.device = self.sim.N, self.sim.B, self.sim.D, self.sim.device
+        self.threshold_arrive = thr
+        self.use_vision = False
+        if isinstance(map, str):
+            seg = _maps.by_name(map)
+            reset_rects, respawn_rects = _maps.goal_rects(map)
+            self.sim.set_goal_rects(0, reset_rects)
+            self.sim.set_goal_rects(1, respawn_rects)
+        else:
+            seg = map
+        if per_env_map and not (torch.is_tensor(seg) and seg.dim() == 3) and np.ndim(seg) == 2:
+            seg = _maps.replicate_per_env(seg, self.N, seed=map_seed)
+        self.sim.set_map(seg)
+        self.io = self.sim.alloc_io()
+
+    def close(self):
+        self.sim.close()
+
+    def reset(self, mask=None):
+        return self.sim.reset(self.io.obs, mask)
+
+    def step(self, action, io=None):
+        """action: [N,2] float32 device tensor.  Returns (obs, reward, done, arrive); `ended`,
+        `ep_return`, `ep_length` are in ``self.io`` (or the `io` passed in)."""
+        io = io or self.io
+        action = action.to(device=self.device, dtype=torch.float32).contiguous()
+        self.sim.step(action, io.obs, io.reward, io.done, io.arrive, io.ended, io.ep_return, io.ep_length)
+        return io.obs, io.reward, io.done, io.arrive
+
+
+class _XY:
+    __slots__ = ("x", "y", "z")
+
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        self.x, self.y, self.z = x, y, z
+
+
+class _Pose:
+    def __init__(self):
+        self.position = _XY()
+
+
+class Env:
+    """Single-env drop-in for the reference ``Env`` (environment_new.py:26-382).
+
+    >>> env = Env(is_training=True)
+    >>> obs = env.reset()                              # np.ndarray (16,) float64
+    >>> obs, reward, done, arrive = env.step(action, past_action)
+
+    Differences from the reference, all deliberate: the world is simulated on the GPU instead of
+    Gazebo (so ``step`` does not block on a 5 Hz scan), goal sampling uses a seeded counter-based
+    RNG instead of the unseeded global ``random``, and service failures raise instead of being
+    swallowed.  The episode loop stays with the caller exactly as in ``PPO.rollout``: ``step`` never
+    resets, and on arrival it re-spawns the goal like ``setReward`` does (environment_new.py:245-267).
+    """
+
+    def __init__(self, is_training, use_vision=False, vision_dim=64, map="stage_1", seed=0, device=None):
+        if use_vision:
+            raise NotImplementedError("camera modality is outside the LiDAR hot path (SURVEY.md 2a)")
+        self.use_vision = False
+        self.vision_dim = vision_dim
+        self.threshold_arrive = 0.2 if is_training else 0.4
+        self._sim = NavSim(1, n_beams=10, max_episode_steps=0, auto_reset=False, respawn_on_arrive=True, seed=seed,
+                           threshold_arrive=self.threshold_arrive, device=device)
+        if isinstance(map, str):
+            seg = _maps.by_name(map)
+            rr, rs = _maps.goal_rects(map)
+            self._sim.set_goal_rects(0, rr)
+            self._sim.set_goal_rects(1, rs)
+        else:
+            seg = map
+        self._sim.set_map(seg)
+        self._io = self._sim.alloc_io()
+        dev = self._sim.device
+        self._act = torch.zeros((1, 2), dtype=torch.float32, device=dev)
+        self._past = torch.zeros((1, 2), dtype=torch.float32, device=dev)
+        self.position = _XY()
+        self.goal_position = _Pose()
+        self.past_distance = 0.0
+        self._sync_attrs()
+
+    def _sync_attrs(self):
+        st = self._sim.get_state()
+        self.position = _XY(float(st["pose"][0, 0]), float(st["pose"][0, 1]))
+        self.yaw_rad = float(st["pose"][0, 2])
+        self.goal_position.position.x = float(st["goal"][0, 0])
+        self.goal_position.position.y = float(st["goal"][0, 1])
+        self.past_distance = float(st["past_dist"][0])
+
+    def reset(self):
+        self._sim.reset(self._io.obs)
+        obs = self._io.obs[0].double().cpu().numpy()
+        self._sync_attrs()
+        return obs
+
+    def step(self, action, past_action):
+        a = np.asarray(action, dtype=np.float32).reshape(-1)
+        p = np.asarray(past_action, dtype=np.float32).reshape(-1)
+        if a.shape[0] < 2 or p.shape[0] < 2:
+            raise IndexError("action and past_action need two components")  # as action[1] would in the reference
+        self._act.copy_(torch.from_numpy(a[:2]).view(1, 2))
+        self._past.copy_(torch.from_numpy(p[:2]).view(1, 2))
+        io = self._io
+        self._sim.step(self._act, io.obs, io.reward, io.done, io.arrive, io.ended, None, None, past_action=self._past)
+        obs = io.obs[0].double().cpu().numpy()
+        reward = float(io.reward[0].item())
+        done = bool(io.done[0].item())
+        arrive = bool(io.arrive[0].item())
+        self._sync_attrs()
+        return obs, reward, done, arrive
+
+    def getLatestImage(self):
+        return None
+
+    def close(self):
+        self._sim.close()

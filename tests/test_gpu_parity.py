@@ -1,0 +1,370 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, libnavsim.so) against the CPU oracle
+on the same seeded inputs, against golden vectors recorded from the reference, and through
+size-independent properties at BASELINE sizes.
+
+Tolerances (BASELINE.json north_star): collision / arrival / ended flags BIT-EXACT; float
+observations and rewards within 1e-5 (we assert 1e-6 absolute on observations, which are O(1),
+and 1e-5 relative on rewards).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from navbot_ppo_amd import maps
+from oracle import navsim_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+OBS_ATOL = 1e-6
+REW_RTOL = 1e-5
+
+
+def _mk(N, seg, per_env=False, B=10, **kw):
+    from navbot_ppo_amd.env import NavSim
+    gpu = NavSim(N, n_beams=B, **kw)
+    cpu = O.OracleSim(N, n_beams=B, **{k: v for k, v in kw.items() if k != "obs_f16"})
+    gpu.set_map(seg, per_env=per_env)
+    cpu.set_map(seg, per_env=per_env)
+    return gpu, cpu
+
+
+def _actions(rng, K, N):
+    a = np.stack([rng.uniform(0, 1, (K, N)), rng.uniform(-1, 1, (K, N))], 2).astype(np.float32)
+    a[:, : N // 4, 1] *= 0.1  # a quarter of the envs drive nearly straight: collisions and arrivals happen
+    return a
+
+
+def _lockstep(gpu, cpu, actions, check_state_every=25):
+    N = gpu.N
+    io = gpu.alloc_io()
+    obs_g = gpu.reset(io.obs).float().cpu().numpy()
+    obs_c = cpu.reset()
+    np.testing.assert_allclose(obs_g, obs_c, rtol=0, atol=OBS_ATOL)
+    stats = dict(done=0, arrive=0, ended=0, exact_obs=0, total=0)
+    for k in range(actions.shape[0]):
+        a = torch.from_numpy(actions[k]).to(gpu.device)
+        gpu.step(a, io.obs, io.reward, io.done, io.arrive, io.ended, io.ep_return, io.ep_length)
+        out = cpu.step(actions[k])
+        og = io.obs.float().cpu().numpy()
+        np.testing.assert_array_equal(io.done.cpu().numpy(), out["done"], err_msg=f"done, step {k}")
+        np.testing.assert_array_equal(io.arrive.cpu().numpy(), out["arrive"], err_msg=f"arrive, step {k}")
+        np.testing.assert_array_equal(io.ended.cpu().numpy(), out["ended"], err_msg=f"ended, step {k}")
+        np.testing.assert_allclose(og, out["obs"], rtol=0, atol=OBS_ATOL, err_msg=f"obs, step {k}")
+        np.testing.assert_allclose(io.reward.cpu().numpy(), out["reward"], rtol=REW_RTOL, atol=1e-5, err_msg=f"reward, step {k}")
+        e = out["ended"].astype(bool)
+        np.testing.assert_array_equal(io.ep_length.cpu().numpy()[e], out["ep_length"][e])
+        np.testing.assert_allclose(io.ep_return.cpu().numpy()[e], out["ep_return"][e], rtol=REW_RTOL, atol=1e-4)
+        stats["done"] += int(out["done"].sum())
+        stats["arrive"] += int(out["arrive"].sum())
+        stats["ended"] += int(e.sum())
+        stats["exact_obs"] += int((og == out["obs"]).all(axis=1).sum())
+        stats["total"] += N
+        if (k + 1) % check_state_every == 0 or k == actions.shape[0] - 1:
+            sg, sc = gpu.get_state(), cpu.get_state()
+            np.testing.assert_allclose(sg["pose"], sc["pose"], rtol=0, atol=1e-11)
+            np.testing.assert_array_equal(sg["goal"], sc["goal"])  # same Philox stream, same rejection decisions
+            np.testing.assert_allclose(sg["past_dist"], sc["past_dist"], rtol=1e-14)
+            np.testing.assert_array_equal(sg["ep_step"], sc["ep_step"])
+            np.testing.assert_array_equal(sg["rng_ctr"], sc["rng_ctr"])
+            np.testing.assert_array_equal(sg["past_action"], sc["past_action"])
+    return stats
+
+
+def test_step_parity_stage1_shared_map_autoreset():
+    rng = np.random.default_rng(11)
+    gpu, cpu = _mk(512, maps.stage_1(), max_episode_steps=60, auto_reset=True, seed=5)
+    st = _lockstep(gpu, cpu, _actions(rng, 180, 512))
+    assert st["done"] > 20 and st["ended"] > 512  # collisions and timeouts both exercised
+    assert st["exact_obs"] > 0.99 * st["total"]   # nearly every row is bit-identical to the oracle
+
+
+def test_step_parity_arrivals_and_respawn():
+    # goals pulled in close to the spawn so arrivals are frequent; respawn_on_arrive path (Env drop-in mode)
+    rng = np.random.default_rng(12)
+    N = 256
+    gpu, cpu = _mk(N, maps.stage_1(), max_episode_steps=0, auto_reset=False, respawn_on_arrive=True, seed=7,
+                   goal_box=(-0.6, 0.6))
+    for s in (gpu, cpu):
+        s.set_goal_rects(0, np.zeros((0, 4)))
+        s.set_goal_rects(1, np.zeros((0, 4)))
+    a = _actions(rng, 120, N)
+    a[..., 0] = np.maximum(a[..., 0], 0.5)
+    st = _lockstep(gpu, cpu, a)
+    assert st["arrive"] > 30
+
+
+def test_step_parity_per_env_maps_stage2():
+    rng = np.random.default_rng(13)
+    N = 320  # five full blocks
+    seg = maps.replicate_per_env(maps.stage_2(), N, seed=3)
+    gpu, cpu = _mk(N, seg, per_env=True, max_episode_steps=40, auto_reset=True, seed=9)
+    rr, rs = maps.goal_rects("stage_2")
+    for s in (gpu, cpu):
+        s.set_goal_rects(0, rr)
+        s.set_goal_rects(1, rs)
+    st = _lockstep(gpu, cpu, _actions(rng, 100, N))
+    assert st["ended"] > N
+
+
+@pytest.mark.parametrize("N", [1, 63, 65, 100])
+def test_ragged_env_counts(N):
+    rng = np.random.default_rng(14 + N)
+    gpu, cpu = _mk(N, maps.stage_1(), max_episode_steps=15, auto_reset=True, seed=N)
+    _lockstep(gpu, cpu, _actions(rng, 40, N))
+    segp = maps.replicate_per_env(maps.stage_4(), N, seed=1)  # S=64 per env
+    gpu, cpu = _mk(N, segp, per_env=True, max_episode_steps=15, auto_reset=True, seed=N)
+    _lockstep(gpu, cpu, _actions(rng, 25, N))
+
+
+def test_36_beams_stage4():
+    rng = np.random.default_rng(15)
+    gpu, cpu = _mk(192, maps.stage_4(), B=36, max_episode_steps=30, auto_reset=True, seed=2)
+    assert gpu.D == 42
+    _lockstep(gpu, cpu, _actions(rng, 70, 192))
+    segp = maps.replicate_per_env(maps.stage_1(), 128, seed=2)  # S=32 < 64 lanes
+    gpu, cpu = _mk(128, segp, per_env=True, B=36, max_episode_steps=30, auto_reset=True, seed=2)
+    _lockstep(gpu, cpu, _actions(rng, 40, 128))
+
+
+def test_large_shared_map_tiles_through_lds():
+    # 5000 segments > one 2048-segment LDS tile: a dense random clutter far from the robot + stage_1
+    rng = np.random.default_rng(16)
+    clutter = rng.uniform(-3.8, 3.8, (5000 - 32, 2))
+    d = rng.uniform(-0.05, 0.05, (5000 - 32, 2))
+    seg = np.concatenate([maps.stage_1(), np.concatenate([clutter, clutter + d], 1).astype(np.float32)])
+    keep = np.hypot(seg[:, 0], seg[:, 1]) > 0.5  # keep the spawn clear
+    seg = seg[keep]
+    gpu, cpu = _mk(96, seg, max_episode_steps=20, auto_reset=True, seed=3)
+    st = _lockstep(gpu, cpu, _actions(rng, 30, 96))
+    assert st["done"] > 0
+
+
+def test_raycast_entry_point_matches_oracle():
+    from navbot_ppo_amd.env import NavSim
+    rng = np.random.default_rng(17)
+    N = 300
+    seg = maps.stage_2()
+    gpu = NavSim(N)
+    gpu.set_map(seg)
+    pose = np.stack([rng.uniform(-3.7, 3.7, N), rng.uniform(-3.7, 3.7, N), rng.uniform(-7, 7, N)], 1)
+    got = gpu.raycast(torch.from_numpy(pose)).cpu().numpy()
+    want = np.stack([O.raycast(seg, *p) for p in pose])
+    np.testing.assert_array_equal(np.isinf(got), np.isinf(want))
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=0, atol=1e-6)
+    assert (got[fin] == want[fin]).mean() > 0.999
+
+
+def test_g9_closed_loop_against_reference_outputs():
+    """GPU sim replays the G9 action tape; obs/reward/flags must match what the REFERENCE Env.step
+    produced for the same trajectory (recorded by tests/golden/generate_golden.py)."""
+    from navbot_ppo_amd.env import NavSim
+    d = np.load(os.path.join(G, "g9_closed_loop.npz"))
+    K, E = d["actions"].shape[:2]
+    gpu = NavSim(E, seed=int(d["seed"]))
+    gpu.set_map(maps.stage_1())
+    io = gpu.alloc_io()
+    gpu.reset(io.obs)
+    goals = d["goals"]
+    gpu.set_state(goal=goals, past_dist=np.hypot(goals[:, 0], goals[:, 1]))
+    past = torch.zeros((E, 2), dtype=torch.float32, device=gpu.device)
+    n = 0
+    for k in range(K):
+        a = torch.from_numpy(d["actions"][k]).to(gpu.device)
+        gpu.step(a, io.obs, io.reward, io.done, io.arrive, io.ended, past_action=past)
+        al = d["alive"][k].astype(bool)
+        np.testing.assert_allclose(io.obs.cpu().numpy()[al], d["ref_obs"][k][al].astype(np.float32), rtol=0, atol=OBS_ATOL)
+        np.testing.assert_allclose(io.reward.cpu().numpy()[al], d["ref_rew"][k][al], rtol=REW_RTOL, atol=1e-5)
+        np.testing.assert_array_equal(io.done.cpu().numpy()[al], d["ref_flags"][k][al, 0])
+        np.testing.assert_array_equal(io.arrive.cpu().numpy()[al], d["ref_flags"][k][al, 1])
+        n += int(al.sum())
+        past = a
+    assert n > 1000
+
+
+def test_g1_goal_angles_through_the_kernel():
+    """Reference getOdometry goldens (yaw-only, unit quaternions) pushed through the GPU step with a zero
+    action: obs[13:16] = yaw/360, rel_theta/360, diff/180."""
+    from navbot_ppo_amd.env import NavSim
+    d = np.load(os.path.join(G, "g1_odometry.npz"))
+    inp, out = d["inp"], d["out"]
+    sel = (inp[:, 2] == 0) & (inp[:, 3] == 0) & (np.abs(inp[:, 4] ** 2 + inp[:, 5] ** 2 - 1) < 1e-12)
+    inp, out = inp[sel], out[sel]
+    th = 2 * np.arctan2(inp[:, 4], inp[:, 5])
+    deg = np.degrees(th)
+    not_tie = np.abs(deg - np.round(deg) - 0.5) % 1 > 1e-9  # exact .5-degree ties depend on the last ulp of sin/cos
+    tie = np.abs(np.abs(deg - np.floor(deg)) - 0.5) < 1e-9
+    N = len(inp)
+    gpu = NavSim(N)
+    gpu.set_map(np.array([[50, 50, 51, 50]], dtype=np.float32))  # nothing in range
+    io = gpu.alloc_io()
+    gpu.reset(io.obs)
+    pose = np.stack([inp[:, 0], inp[:, 1], th], 1)
+    gpu.set_state(pose=pose, goal=inp[:, 6:8], past_dist=np.ones(N))
+    gpu.step(torch.zeros((N, 2), device=gpu.device), io.obs, io.reward, io.done, io.arrive, io.ended)
+    o = io.obs.cpu().numpy()
+    ok = ~tie
+    assert ok.sum() > 1500
+    np.testing.assert_array_equal(o[ok, 13], (out[ok, 0] / 360).astype(np.float32))
+    np.testing.assert_array_equal(o[ok, 14], (out[ok, 1] / 360).astype(np.float32))
+    np.testing.assert_array_equal(o[ok, 15], (out[ok, 2] / 180).astype(np.float32))
+    assert np.all(o[:, :10] == 1.0)  # +inf -> 3.5 -> 1.0
+
+
+def test_rtg_scan_parity_and_golden():
+    from navbot_ppo_amd.env import rtg_scan
+    rng = np.random.default_rng(18)
+    for T, N in [(1, 1), (7, 3), (512, 100), (128, 4096), (33, 65)]:
+        rew = rng.uniform(-25, 25, (T, N)).astype(np.float32)
+        rew[rng.random((T, N)) < 0.02] = 120.0
+        ended = (rng.random((T, N)) < 0.03).astype(np.uint8)
+        got = rtg_scan(torch.from_numpy(rew).cuda(), torch.from_numpy(ended).cuda(), 0.99).cpu().numpy()
+        np.testing.assert_array_equal(got, O.compute_rtgs_tn(rew, ended, 0.99))  # bit-exact: same f64 recurrence
+    # reference golden (ragged episodes of one env -> one column)
+    d = np.load(os.path.join(G, "g5_rtgs.npz"))
+    rews, lens, gammas, out = d["rews"], d["lens"], d["gammas"], d["out"]
+    ro = oo = k = 0
+    case = []
+    for L in lens:
+        if L >= 0:
+            case.append(rews[ro:ro + L])
+            ro += L
+            continue
+        flat = np.concatenate(case) if case else np.zeros(0)
+        n = len(flat)
+        if n and np.all(flat.astype(np.float32).astype(np.float64) == flat):
+            e = np.zeros(n, np.uint8)
+            e[np.cumsum([len(c) for c in case if len(c)]) - 1] = 1
+            got = rtg_scan(torch.from_numpy(flat.astype(np.float32)[:, None]).cuda(), torch.from_numpy(e[:, None]).cuda(),
+                           float(gammas[k])).cpu().numpy()[:, 0]
+            np.testing.assert_array_equal(got, out[oo:oo + n])
+        oo += n
+        case = []
+        k += 1
+    # empty input is a no-op, not an error
+    rtg_scan(torch.zeros((0, 4), device="cuda"), torch.zeros((0, 4), dtype=torch.uint8, device="cuda"), 0.99)
+
+
+def test_shard_invariance_and_determinism():
+    """SURVEY 8e parity condition: env i's trajectory depends on (seed, global env id) only, so two
+    shards of 128 (env_id_base 0 / 128) reproduce one handle of 256 exactly."""
+    from navbot_ppo_amd.env import NavSim
+    rng = np.random.default_rng(19)
+    acts = _actions(rng, 60, 256)
+
+    def run(N, base, a):
+        s = NavSim(N, max_episode_steps=25, auto_reset=True, seed=77, env_id_base=base)
+        s.set_map(maps.stage_1())
+        io = s.alloc_io()
+        s.reset(io.obs)
+        obs, rew = [], []
+        for k in range(a.shape[0]):
+            s.step(torch.from_numpy(a[k]).to(s.device), io.obs, io.reward, io.done, io.arrive, io.ended)
+            obs.append(io.obs.cpu().numpy().copy())
+            rew.append(io.reward.cpu().numpy().copy())
+        return np.stack(obs), np.stack(rew)
+
+    o_all, r_all = run(256, 0, acts)
+    o_a, r_a = run(128, 0, acts[:, :128])
+    o_b, r_b = run(128, 128, acts[:, 128:])
+    np.testing.assert_array_equal(o_all, np.concatenate([o_a, o_b], 1))
+    np.testing.assert_array_equal(r_all, np.concatenate([r_a, r_b], 1))
+    o2, r2 = run(256, 0, acts)
+    np.testing.assert_array_equal(o_all, o2)
+
+
+def test_f16_observations():
+    rng = np.random.default_rng(20)
+    from navbot_ppo_amd.env import NavSim
+    N = 128
+    g16 = NavSim(N, max_episode_steps=20, auto_reset=True, seed=4, obs_f16=True)
+    g32 = NavSim(N, max_episode_steps=20, auto_reset=True, seed=4)
+    for s in (g16, g32):
+        s.set_map(maps.stage_1())
+    i16, i32 = g16.alloc_io(), g32.alloc_io()
+    assert i16.obs.dtype == torch.float16
+    g16.reset(i16.obs)
+    g32.reset(i32.obs)
+    acts = _actions(rng, 30, N)
+    for k in range(30):
+        a = torch.from_numpy(acts[k]).cuda()
+        g16.step(a, i16.obs, i16.reward, i16.done, i16.arrive, i16.ended)
+        g32.step(a, i32.obs, i32.reward, i32.done, i32.arrive, i32.ended)
+        assert torch.equal(i16.obs, i32.obs.half())  # same values, rounded once to half
+        assert torch.equal(i16.reward, i32.reward) and torch.equal(i16.ended, i32.ended)
+
+
+def test_env_dropin_surface():
+    """The N=1 Python surface of the reference Env (environment_new.py:27,272,312)."""
+    from navbot_ppo_amd.env import Env
+    env = Env(is_training=True, seed=3)
+    assert env.threshold_arrive == 0.2 and env.use_vision is False
+    obs = env.reset()
+    assert isinstance(obs, np.ndarray) and obs.shape == (16,) and obs.dtype == np.float64
+    assert env.position.x == 0.0 and env.position.y == 0.0
+    gx, gy = env.goal_position.position.x, env.goal_position.position.y
+    assert abs(env.past_distance - math.hypot(gx, gy)) < 1e-12
+    o2, rew, done, arrive = env.step(np.array([1.0, 0.0]), np.array([0.25, -0.5]))
+    assert o2.shape == (16,) and isinstance(rew, float) and isinstance(done, bool) and isinstance(arrive, bool)
+    assert o2[10] == 0.25 and o2[11] == -0.5                 # past_action argument honoured
+    assert abs(env.position.x - 0.05) < 1e-12                 # 0.25 m/s for 0.2 s
+    assert abs(rew - 500 * (math.hypot(gx, gy) - math.hypot(gx - 0.05, gy))) < 1e-3
+    with pytest.raises(IndexError):
+        env.step(np.array([1.0]), np.array([0.0, 0.0]))
+    assert Env(is_training=False).threshold_arrive == 0.4
+
+
+def test_errors_are_reported_not_swallowed():
+    from navbot_ppo_amd.env import NavSim, NavsimError
+    s = NavSim(8)
+    io = s.alloc_io()
+    with pytest.raises(NavsimError, match="set_map"):
+        s.reset(io.obs)
+    with pytest.raises(NavsimError):
+        NavSim(8, n_beams=7)
+    with pytest.raises(NavsimError):
+        s.set_map(np.zeros((3, 5), dtype=np.float32))
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_full_size_properties(cfg):
+    """BASELINE sizes (4096 shared stage_1 ; 16384 per-env stage_2): size-independent properties.
+    * a sample of envs replayed on the oracle matches (flags exact, obs 1e-6)
+    * observation ranges of SURVEY A3#10
+    * episode accounting: sum(ep_length at ended) + live ep_step == steps * N
+    """
+    from navbot_ppo_amd.env import NavSim
+    rng = np.random.default_rng(21)
+    if cfg == "cfg2":
+        N, K, seg, per_env = 4096, 64, maps.stage_1(), False
+    else:
+        N, K, per_env = 16384, 24, True
+        seg = maps.replicate_per_env(maps.stage_2(), N, seed=0)
+    s = NavSim(N, max_episode_steps=50, auto_reset=True, seed=1)
+    s.set_map(seg, per_env=per_env)
+    io = s.alloc_io()
+    s.reset(io.obs)
+    sample = np.sort(rng.choice(N, 96, replace=False))
+    cpu = [O.OracleSim(1, max_episode_steps=50, auto_reset=True, seed=1, env_id_base=int(i)) for i in sample]
+    for c, i in zip(cpu, sample):
+        c.set_map(seg[i] if per_env else seg)
+        c.reset()
+    total_len = 0
+    for k in range(K):
+        a = np.stack([rng.uniform(0, 1, N), rng.uniform(-1, 1, N)], 1).astype(np.float32)
+        s.step(torch.from_numpy(a).cuda(), io.obs, io.reward, io.done, io.arrive, io.ended, io.ep_return, io.ep_length)
+        o = io.obs.cpu().numpy()
+        e = io.ended.cpu().numpy().astype(bool)
+        total_len += int(io.ep_length.cpu().numpy()[e].sum())
+        assert np.all((o[:, :10] >= 0.12 / 3.5 - 1e-7) & (o[:, :10] <= 1.0))
+        assert np.all((o[:, 13] >= 0) & (o[:, 13] < 1) & (o[:, 14] >= 0) & (o[:, 14] < 1) & (np.abs(o[:, 15]) <= 1))
+        for c, i in zip(cpu, sample):
+            out = c.step(a[i:i + 1])
+            np.testing.assert_allclose(o[i], out["obs"][0], rtol=0, atol=OBS_ATOL)
+            assert io.done[i].item() == out["done"][0] and io.arrive[i].item() == out["arrive"][0]
+            assert io.ended[i].item() == out["ended"][0]
+    assert total_len + int(s.get_state()["ep_step"].sum()) == K * N
