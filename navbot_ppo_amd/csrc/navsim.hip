@@ -808,8 +808,9 @@ int navsim_set_state(navsim_t* h, const double* pose, const double* goal, const 
 
 int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, int32_t N, double gamma,
                     float* out_dev, void* stream) {
-    if (!rew_dev || !ended_dev || !out_dev || T < 0 || N < 0) return fail(NAVSIM_E_ARG, "navsim_rtg_scan: bad argument");
-    if (T == 0 || N == 0) return NAVSIM_OK;
+    if (T < 0 || N < 0) return fail(NAVSIM_E_ARG, "navsim_rtg_scan: negative size");
+    if (T == 0 || N == 0) return NAVSIM_OK;  // empty batch: nothing to scan (pointers may be null)
+    if (!rew_dev || !ended_dev || !out_dev) return fail(NAVSIM_E_ARG, "navsim_rtg_scan: null buffer");
     hipLaunchKernelGGL(rtg_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N,
                        gamma, out_dev);
     HIP_TRY(hipGetLastError());

@@ -1,0 +1,378 @@
+"""PPO-clip rollout / return-scan / update loop over the batched simulator.
+
+Follows ``project_ppo/src/ppo.py`` of the reference function by function, vectorised over N envs:
+
+  rollout()        ppo.py:463-641   T policy steps x N envs; every buffer is a [T,N,...] device tensor
+                                    the step kernel writes into directly (no host round trip)
+  sample_action    ppo.py:673-706   MVN(mean, var*I) sample, clamp, log-prob of the CLAMPED action
+  compute returns  ppo.py:643-671   navsim_rtg_scan (HIP): reward-to-go, no bootstrap
+  evaluate         ppo.py:708-737
+  update           ppo.py:275-397   A = rtg - V, normalised with the unbiased std (+1e-10); 50 full-batch
+                                    epochs of clipped surrogate + MSE critic, Adam(lr 3e-4), no entropy
+                                    term, no value clip, no gradient clipping
+  learn            ppo.py:218-461   iteration loop, timing, checkpoints (actor_iter%04d_step%08d.pth)
+
+Multi-GPU (absent in the reference): one process per GPU, each owns a contiguous shard
+of env ids; after each backward ONE all-reduce (RCCL over xGMI; gloo on CPU for tests) of the single
+flat gradient buffer holding actor+critic; the advantage mean/std come from all-reduced
+(sum, sum of squares, count) so they equal the single-process values of ppo.py:284.
+"""
+import dataclasses
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import nets
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+@dataclasses.dataclass
+class PPOConfig:
+    rollout_len: int = 512                 # T: policy steps per env per iteration
+    max_episode_steps: int = 500           # main.py / arguments.py:30 (timesteps_per_episode)
+    gamma: float = 0.99                    # main.py:470
+    n_updates_per_iteration: int = 50      # main.py:471
+    lr: float = 3e-4                       # main.py:472
+    clip: float = 0.2                      # main.py:473
+    policy: str = "resmlp512"              # reference nets; "mlp64x2" = BASELINE config 2
+    init_var: float = 0.8                  # ppo.py:123
+    var_decay: float = 0.995               # ppo.py:695
+    var_floor: float = 0.1                 # ppo.py:694
+    var_decay_after: int = 50000           # ppo.py:694
+    save_freq: int = 2                     # ppo.py:774
+    seed: int = 0
+    use_graph: bool = True                 # capture the T-step rollout in one hipGraph
+    output_dir: str = ""                   # "" = no checkpoints / logs
+    method_name: str = "baseline"
+
+
+# --------------------------------------------------------------------------- distributed context
+class DistCtx:
+    """torch.distributed wrapper that degrades to a no-op for a single process."""
+
+    def __init__(self, device=None):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.enabled = self.world > 1
+        if device is None:
+            device = torch.device(f"cuda:{self.local_rank}") if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        if self.enabled and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            backend = "nccl" if self.device.type == "cuda" else "gloo"  # "nccl" is RCCL on ROCm
+            kw = {"device_id": self.device} if backend == "nccl" else {}
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+
+    def all_reduce_sum(self, t):
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def all_reduce_max(self, t):
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t
+
+    def broadcast(self, t, src=0):
+        if self.enabled:
+            dist.broadcast(t, src=src)
+        return t
+
+    def barrier(self):
+        if self.enabled:
+            dist.barrier()
+
+    def shard(self, n_total):
+        """Contiguous env-id shard [lo, hi) of this rank."""
+        per = n_total // self.world
+        if per * self.world != n_total:
+            raise ValueError(f"n_envs {n_total} not divisible by world size {self.world}")
+        return self.rank * per, (self.rank + 1) * per
+
+
+# --------------------------------------------------------------------------- flat parameters
+class FlatParams:
+    """All trainable tensors of actor + critic as views into ONE flat buffer, and their gradients as
+    views into ONE flat gradient buffer: a single all-reduce and a single Adam update per epoch.
+    (The reference's unused BatchNorm parameters never receive gradients -- net_actor.py:44,48 -- and
+    stay ordinary tensors so state_dict keys are unchanged.)"""
+
+    def __init__(self, modules, device):
+        self.params = [p for m in modules for n, p in m.named_parameters() if ".bn" not in "." + n and not n.startswith("bn")]
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view_as(p)
+            p.grad = self.grad[off:off + n].view_as(p)
+            off += n
+        self.numel = total
+        self.proxy = torch.nn.Parameter(self.flat, requires_grad=True)
+        self.proxy.data = self.flat
+        self.proxy.grad = self.grad
+
+
+def gaussian_log_prob(mean, action, var):
+    """log N(action; mean, var*I) for a 2-D isotropic Gaussian = MultivariateNormal(mean, diag(var)).log_prob
+    (ppo.py:696,704,734-735)."""
+    k = mean.shape[-1]
+    return -0.5 * (((action - mean) ** 2).sum(-1) / var) - 0.5 * k * LOG_2PI - 0.5 * k * torch.log(var)
+
+
+def ppo_losses(actor, critic, obs, acts, logp_old, rtg, adv, var, clip):
+    """One evaluation of ppo.py:307-343.  Returns (actor_loss, critic_loss, ratios, logp)."""
+    V = critic(obs).squeeze(-1)
+    mean = actor(obs)
+    lo = mean.new_tensor([0.0, -1.0])
+    hi = mean.new_tensor([1.0, 1.0])
+    mean = torch.max(torch.min(mean, hi), lo)              # ppo.py:730-733 (no-op after sigmoid/tanh)
+    logp = gaussian_log_prob(mean, acts, var)
+    ratios = torch.exp(logp - logp_old)                    # ppo.py:316
+    surr1 = ratios * adv                                   # ppo.py:319
+    surr2 = torch.clamp(ratios, 1 - clip, 1 + clip) * adv  # ppo.py:320
+    actor_loss = (-torch.min(surr1, surr2)).mean()         # ppo.py:342
+    critic_loss = torch.nn.functional.mse_loss(V, rtg)     # ppo.py:343
+    return actor_loss, critic_loss, ratios, logp, V
+
+
+def normalise_advantages(adv, ctx=None):
+    """(A - mean) / (std + 1e-10) with torch.std's unbiased estimator (ppo.py:284); with several ranks the
+    moments are all-reduced so every rank uses the global mean/std."""
+    a64 = adv.double()
+    m = torch.stack([a64.sum(), (a64 * a64).sum(), torch.tensor(float(adv.numel()), dtype=torch.float64, device=adv.device)])
+    if ctx is not None:
+        ctx.all_reduce_sum(m)
+    n = m[2]
+    mean = m[0] / n
+    var = (m[1] - n * mean * mean) / (n - 1)
+    std = torch.sqrt(torch.clamp(var, min=0.0))
+    return ((adv - mean.float()) / (std.float() + 1e-10))
+
+
+class PPOUpdater:
+    """The update half of PPO.learn (ppo.py:275-397) on a fixed batch; device-agnostic PyTorch."""
+
+    def __init__(self, actor, critic, cfg, ctx=None, device=None):
+        self.actor, self.critic, self.cfg, self.ctx = actor, critic, cfg, ctx
+        self.device = device or next(actor.parameters()).device
+        self.fp = FlatParams([actor, critic], self.device)
+        if ctx is not None:
+            ctx.broadcast(self.fp.flat, 0)  # identical replicas; identical Adam steps keep them in sync
+        fused = self.device.type == "cuda"
+        self.opt = torch.optim.Adam([self.fp.proxy], lr=cfg.lr, fused=fused)  # == the two Adam(lr) of ppo.py:116-117
+        self.stats = {}
+
+    def update(self, obs, acts, logp_old, rtg, var):
+        cfg, ctx = self.cfg, self.ctx
+        world = ctx.world if ctx is not None else 1
+        with torch.no_grad():
+            V0 = self.critic(obs).squeeze(-1)
+            adv = normalise_advantages(rtg - V0, ctx)          # ppo.py:275-284
+        n_ep = cfg.n_updates_per_iteration
+        acc = torch.zeros(6, device=obs.device)                # sums over epochs of diagnostics
+        self.loss_history = torch.zeros((n_ep, 2), device=obs.device)  # per-epoch (actor, critic) loss, ppo.py:396-397
+        for ep in range(n_ep):                                 # ppo.py:305
+            a_loss, c_loss, ratios, logp, _ = ppo_losses(self.actor, self.critic, obs, acts, logp_old, rtg, adv, var, cfg.clip)
+            self.fp.grad.zero_()
+            (a_loss + c_loss).backward()                       # disjoint nets: same grads as the two backward()s of :349,:386
+            if world > 1:
+                ctx.all_reduce_sum(self.fp.grad)
+                self.fp.grad.div_(world)
+            self.opt.step()                                    # ppo.py:381,392
+            with torch.no_grad():                              # ppo.py:323-336
+                lr_ = logp.detach() - logp_old
+                self.loss_history[ep] = torch.stack([a_loss.detach(), c_loss.detach()])
+                acc += torch.stack([a_loss.detach(), c_loss.detach(), ((ratios.detach() - 1) - lr_).mean(),
+                                    ((ratios.detach() - 1).abs() > cfg.clip).float().mean(),
+                                    self.fp.grad.norm(), V0.mean()])
+        acc = acc / max(n_ep, 1)
+        if ctx is not None and world > 1:
+            ctx.all_reduce_sum(acc)
+            acc = acc / world
+        self.stats = dict(zip(["actor_loss", "critic_loss", "approx_kl", "clip_frac", "grad_norm", "value_mean"],
+                              [float(v) for v in acc.tolist()]))
+        self.last_losses = (a_loss.detach(), c_loss.detach())
+        return self.stats
+
+
+# --------------------------------------------------------------------------- trainer
+class PPOTrainer:
+    """PPO.learn for a ``VecEnv`` shard.  Construct one per process (= per GPU)."""
+
+    def __init__(self, env, cfg=None, ctx=None):
+        self.env, self.cfg = env, cfg or PPOConfig()
+        self.ctx = ctx
+        self.device = env.device
+        cfg = self.cfg
+        N, T, D = env.N, cfg.rollout_len, env.D
+        torch.manual_seed(cfg.seed)  # same initial weights on every rank (then broadcast anyway)
+        self.actor, self.critic = nets.make_policy(cfg.policy, D, 2)
+        self.actor.to(self.device)
+        self.critic.to(self.device)
+        self.updater = PPOUpdater(self.actor, self.critic, cfg, ctx, self.device)
+        rank = ctx.rank if ctx is not None else 0
+        torch.manual_seed(cfg.seed * 1000003 + 17 + rank)  # exploration noise differs per shard
+        dev = self.device
+        f32, u8 = torch.float32, torch.uint8
+        self.obs_buf = torch.zeros((T + 1, N, D), dtype=f32, device=dev)
+        self.act_buf = torch.zeros((T, N, 2), dtype=f32, device=dev)
+        self.logp_buf = torch.zeros((T, N), dtype=f32, device=dev)
+        self.rew_buf = torch.zeros((T, N), dtype=f32, device=dev)
+        self.done_buf = torch.zeros((T, N), dtype=u8, device=dev)
+        self.arrive_buf = torch.zeros((T, N), dtype=u8, device=dev)
+        self.ended_buf = torch.zeros((T, N), dtype=u8, device=dev)
+        self.epret_buf = torch.zeros((T, N), dtype=f32, device=dev)
+        self.eplen_buf = torch.zeros((T, N), dtype=torch.int32, device=dev)
+        self.rtg_buf = torch.zeros((T, N), dtype=f32, device=dev)
+        self.var = torch.full((), cfg.init_var, dtype=f32, device=dev)  # ppo.py:123-124 (0.8 * I)
+        self._lo = torch.tensor([0.0, -1.0], device=dev)
+        self._hi = torch.tensor([1.0, 1.0], device=dev)
+        self._graph = None
+        self.t_so_far = 0     # completed-episode steps, as the reference counts (ppo.py:258)
+        self.env_steps = 0    # all simulated steps
+        self.i_so_far = 0
+        self.episode_starts = 0
+        self.logger = {}
+
+    # ---- ppo.py:673-706 + env.step, for rollout step t (all envs)
+    def _rollout_step(self, t):
+        obs = self.obs_buf[t]
+        mean = self.actor(obs)
+        std = torch.sqrt(self.var)
+        raw = torch.addcmul(mean, torch.randn_like(mean), std)          # dist.sample(), ppo.py:698
+        act = self.act_buf[t]
+        torch.clamp(raw, self._lo, self._hi, out=act)                   # ppo.py:700-703
+        self.logp_buf[t] = gaussian_log_prob(mean, act, self.var)       # log-prob of the clamped action, :704
+        self.env.sim.step(act, self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.arrive_buf[t],
+                          self.ended_buf[t], self.epret_buf[t], self.eplen_buf[t])
+
+    def _rollout_body(self):
+        for t in range(self.cfg.rollout_len):
+            self._rollout_step(t)
+
+    @torch.no_grad()
+    def rollout(self):
+        cfg = self.cfg
+        self._decay_exploration()
+        self.epret_buf.zero_()
+        self.eplen_buf.zero_()
+        self.env.sim.reset(self.obs_buf[0])  # ppo.py:486: every batch starts from a reset
+        if cfg.use_graph and self.device.type == "cuda":
+            if self._graph is None:
+                s = torch.cuda.Stream(self.device)
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):  # warm-up outside capture (allocator, hipBLASLt workspaces)
+                    self._rollout_step(0)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                self.env.sim.reset(self.obs_buf[0])
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._rollout_body()
+            self._graph.replay()
+        else:
+            self._rollout_body()
+        from .env import rtg_scan
+        rtg_scan(self.rew_buf, self.ended_buf, cfg.gamma, out=self.rtg_buf)  # ppo.py:619 -> 643-671
+        self.env_steps += cfg.rollout_len * self.env.N
+
+    def _decay_exploration(self):
+        """ppo.py:694-695 multiplies the covariance by 0.995 at every episode start once t_so_far > 50000 while
+        it is >= 0.1, with t_so_far frozen during a rollout.  With N envs there are N x more episode starts per
+        iteration, so the decay is applied once per N episode starts (per mean episode) -- identical for N=1
+        up to being applied at the rollout boundary; documented deviation."""
+        cfg = self.cfg
+        if self.t_so_far > cfg.var_decay_after:
+            k = int(round(self.episode_starts / max(self.env.N, 1)))
+            v = float(self.var)
+            for _ in range(k):
+                if v >= cfg.var_floor:
+                    v *= cfg.var_decay
+            self.var.fill_(v)
+        self.episode_starts = 0
+
+    def _rollout_metrics(self):
+        ended = self.ended_buf.bool()
+        arrive = self.arrive_buf.bool() & ended
+        done = self.done_buf.bool() & ended
+        m = torch.stack([ended.sum(), arrive.sum(), (done & ~arrive).sum(), (ended & ~done & ~arrive).sum(),
+                         self.eplen_buf.sum()]).double()
+        m = torch.cat([m, (self.epret_buf.double() * ended).sum().view(1)])
+        if self.ctx is not None:
+            self.ctx.all_reduce_sum(m)
+        ep, succ, coll, tmo, steps, ret = [float(x) for x in m.tolist()]
+        self.episode_starts = ep / (self.ctx.world if self.ctx is not None else 1) + self.env.N
+        return dict(episodes=int(ep), successes=int(succ), collisions=int(coll), timeouts=int(tmo),
+                    completed_steps=int(steps), avg_ep_rews=(ret / ep if ep else 0.0),       # ppo.py:833
+                    avg_ep_lens=(steps / ep if ep else 0.0), success_rate=(succ / ep if ep else 0.0))
+
+    def iteration(self):
+        cfg = self.cfg
+        sync = (lambda: torch.cuda.synchronize(self.device)) if self.device.type == "cuda" else (lambda: None)
+        t0 = time.time()
+        self.rollout()
+        sync()
+        t1 = time.time()
+        T, N, D = cfg.rollout_len, self.env.N, self.env.D
+        metrics = self._rollout_metrics()
+        self.t_so_far += metrics["completed_steps"]
+        self.i_so_far += 1
+        stats = self.updater.update(self.obs_buf[:T].reshape(T * N, D), self.act_buf.reshape(T * N, 2),
+                                    self.logp_buf.reshape(T * N), self.rtg_buf.reshape(T * N), self.var)
+        sync()
+        t2 = time.time()
+        world = self.ctx.world if self.ctx is not None else 1
+        self.logger = dict(metrics, **stats, iteration=self.i_so_far, t_so_far=self.t_so_far,
+                           rollout_time=t1 - t0, update_time=t2 - t1, iter_time=t2 - t0,
+                           steps_per_sec=T * N * world / (t2 - t0),                      # ppo.py:855
+                           rollout_steps_per_sec=T * N * world / (t1 - t0), var=float(self.var))
+        if cfg.output_dir and self.i_so_far % cfg.save_freq == 0 and (self.ctx is None or self.ctx.rank == 0):
+            self.save_checkpoint()
+        return self.logger
+
+    def learn(self, total_timesteps, log=print):
+        while self.t_so_far < total_timesteps:  # ppo.py:245
+            lg = self.iteration()
+            if log and (self.ctx is None or self.ctx.rank == 0):
+                log(f"[iter {lg['iteration']:4d}] t={lg['t_so_far']:>10d} mean_ep_rew={lg['avg_ep_rews']:8.2f} "
+                    f"succ={lg['success_rate']:.3f} ep_len={lg['avg_ep_lens']:6.1f} a_loss={lg['actor_loss']:.4f} "
+                    f"c_loss={lg['critic_loss']:.2f} kl={lg['approx_kl']:.4f} steps/s={lg['steps_per_sec']:.0f} "
+                    f"(rollout {lg['rollout_time']:.3f}s update {lg['update_time']:.3f}s)")
+        return self.logger
+
+    # ---- ppo.py:452-457 file naming; state_dict keys match the reference's nets for policy resmlp512
+    def checkpoint_dir(self):
+        return os.path.join(self.cfg.output_dir, self.cfg.method_name, "checkpoints")
+
+    def save_checkpoint(self):
+        d = self.checkpoint_dir()
+        os.makedirs(d, exist_ok=True)
+        tag = f"iter{self.i_so_far:04d}_step{self.t_so_far:08d}.pth"
+        pa, pc = os.path.join(d, "actor_" + tag), os.path.join(d, "critic_" + tag)
+        torch.save({k: v.detach().cpu().clone() for k, v in self.actor.state_dict().items()}, pa)
+        torch.save({k: v.detach().cpu().clone() for k, v in self.critic.state_dict().items()}, pc)
+        return pa, pc
+
+    def load_checkpoint(self, actor_path, critic_path):
+        """main.py:52-89: state_dicts only (optimiser state and covariance are not part of a checkpoint)."""
+        sa = torch.load(actor_path, map_location="cpu")
+        sc = torch.load(critic_path, map_location="cpu")
+        with torch.no_grad():
+            for mod, sd in ((self.actor, sa), (self.critic, sc)):
+                own = mod.state_dict()
+                missing = set(own) - set(sd)
+                if missing:
+                    raise KeyError(f"checkpoint lacks keys {sorted(missing)}")
+                for k, v in own.items():
+                    v.copy_(sd[k])  # in place: parameters stay views of the flat buffer
