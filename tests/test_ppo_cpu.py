@@ -205,3 +205,25 @@ def test_checkpoint_roundtrip_reference_naming(tmp_path):
     t.load_checkpoint(pa, pc)
     for k, v in a.state_dict().items():
         assert torch.equal(v, a2.state_dict()[k])
+
+
+def test_split_k_linear_same_gradients_and_keys():
+    """nets.Linear switches to the batched (split-K) weight gradient for huge batches: same numbers."""
+    torch.manual_seed(0)
+    a, _ = nets.make_policy("mlp64x2")
+    assert list(a.state_dict().keys())[:2] == ["layer1.weight", "layer1.bias"]
+    x = torch.randn(1 << 17, 16)
+
+    def grads(split):
+        nets.Linear.SPLIT_ROWS = (1 << 16) if split else (1 << 40)
+        for p in a.parameters():
+            p.grad = None
+        (a(x) ** 2).sum().backward()
+        return [p.grad.clone() for p in a.parameters()]
+
+    try:
+        g1, g0 = grads(True), grads(False)
+    finally:
+        nets.Linear.SPLIT_ROWS = 1 << 16
+    for u, v in zip(g1, g0):
+        np.testing.assert_allclose(u.numpy(), v.numpy(), rtol=1e-4, atol=1e-4 * float(v.abs().max()))
