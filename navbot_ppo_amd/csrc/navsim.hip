@@ -14,12 +14,12 @@
 // on how segments are split over lanes.  Compiled with -ffp-contract=off: every fused
 // multiply-add is written out.
 //
-// Kernel layout: one workgroup = 4 waves = 64 consecutive envs.
+// Kernel layout: one workgroup = 4 waves = EPB (16) consecutive envs.
 //   phase 1  wave 0, lane = env : integrate pose (f64), sensor origin + B beam directions -> LDS
 //   phase 2  all 4 waves        : nearest hit per (env, beam)
-//              shared map  : segments staged in LDS tiles, lane = env, wave w takes beams w, w+4, ...
-//                            (every lane reads the same segment: LDS broadcast, no conflicts)
-//              per-env map : wave w takes envs 16w..16w+15; lane = segment (16 B/lane coalesced
+//              shared map  : segments staged in LDS tiles, lane = ray (env, beam); every lane of a wave
+//                            reads the same segment at the same time: LDS broadcast, no conflicts
+//              per-env map : wave w takes envs 4w..4w+3; lane = segment (16 B/lane coalesced
 //                            HBM loads, each segment read exactly once), B running minima per lane,
 //                            wavefront min-reduce per beam
 //   phase 3  wave 0, lane = env : getState / obs / reward / flags / timeout / auto-reset, state write-back
@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -46,8 +47,6 @@ constexpr float kRangeMin = 0.12f, kRangeMax = 3.5f;             // gazebo.xacro
 constexpr int kSubsteps = 6;     // 30 Hz drive updates per 5 Hz scan (gazebo.xacro:62,107)
 constexpr int kMaxRects = 16;
 constexpr int kMaxGoalTries = 64;
-constexpr int EPB = 64;          // envs per workgroup
-constexpr int kThreads = 256;
 constexpr int kSegTile = 2048;   // shared-map LDS tile: 2048 segments = 32 KiB
 
 thread_local std::string g_err;
@@ -243,24 +242,93 @@ __device__ __forceinline__ float write_obs_row(float* row, const float* ranges, 
     return mn;
 }
 
-template <int NB>
+template <int NB, int EPB>
 struct StepSmem {
     float2 org[EPB];             // sensor origin per env
     float2 dir[NB * EPB];        // [beam][env] unit direction
-    float rng[NB * EPB];         // [beam][env] raw scan value
+    unsigned rng[NB * EPB];      // [beam][env] nearest hit as float bits (non-negative floats order like uints)
     float obs[EPB * (NB + 7)];   // [env][B+6 (+1 pad: odd row stride, conflict-free)] the block's output tile
+    // pose-wave values parked here while wave 0 ray-casts (keeps the kernel under 128 VGPRs = 4 blocks per CU)
+    double sv_d[11][EPB];
+    float2 sv_act[EPB], sv_pact[EPB];
+    uint32_t sv_ctr[EPB];
+    int sv_step[EPB];
 };
 
+// Sign-normalised ray / segment test: with sd = sign bit of den, K = k^sd, U = un^sd, Dn = |den| the
+// hit conditions of ray_seg() become  K >= 0, 0 <= U <= Dn  (Dn == 0 gives K/Dn = inf or NaN, which
+// never wins the min), and K/Dn == k/den bit for bit.  Returns the candidate range (+inf if no hit).
+__device__ __forceinline__ float ray_seg_fast(float rx, float ry, float ex, float ey, float k, float c, float s) {
+    const float den = fmaf(c, ey, -(s * ex));
+    const float un = fmaf(rx, s, -(ry * c));
+    const unsigned sd = __float_as_uint(den) & 0x80000000u;
+    const float K = __uint_as_float(__float_as_uint(k) ^ sd);
+    const float U = __uint_as_float(__float_as_uint(un) ^ sd);
+    const float Dn = fabsf(den);
+    const bool ok = (fminf(K, U) >= 0.0f) && (U <= Dn);
+    const float t = K / Dn;
+    return ok ? t : INFINITY;
+}
+
+// Correctly rounded K / Dn for positive, normal-range operands (Dn in [2^-60, 2^20], K in {0} U [2^-60, 2^20]):
+// the reciprocal-refinement sequence the compiler emits for an IEEE float32 divide (v_rcp, 2 fma to refine,
+// quotient, two fma residual corrections), minus its exponent pre-scaling (v_div_scale x2) and special-case
+// fix-up (v_div_fixup, v_div_fmas), which are no-ops in this range: 22 instead of 36 pipe cycles on gfx950
+// (measured: v_fma/v_mul full rate, v_div_* half rate, v_rcp quarter rate).  Dn == 0 gives NaN.
+__device__ __forceinline__ float div_pos(float K, float Dn) {
+    float r = __builtin_amdgcn_rcpf(Dn);
+    const float f0 = fmaf(-Dn, r, 1.0f);
+    r = fmaf(f0, r, r);
+    float q = K * r;
+    float e = fmaf(-Dn, q, K);
+    q = fmaf(e, r, q);
+    e = fmaf(-Dn, q, K);
+    return fmaf(e, r, q);
+}
+
+// One ray/segment test, same decisions and the same range bits as ray_seg(), built from full-rate VALU ops
+// only (v_cmp / v_cndmask / v_min_f32 are half rate on gfx950):
+//   p1 = k*den + 0 >= 0  <=>  k and den agree in sign or k == 0   (no underflow: |k|,|den| are 0 or >= 2^-56;
+//   p2 = un*den + 0 >= 0,  w = |den| - |un| >= 0  <=>  0 <= u <= 1  the "+ 0" turns a -0 product into +0)
+//   t  = |k| / |den|  ==  k / den  when the signs agree; >= +0, +inf or NaN, so its bit pattern orders like a uint.
+// miss <=> sign bit of (p1 | p2 | w); an arithmetic shift makes that an all-ones mask OR-ed into t's bits, and the
+// running nearest hit is an unsigned min over bit patterns (inf = 0x7f800000 is the identity, NaN never wins).
+__device__ __forceinline__ unsigned ray_seg_bits(float rx, float ry, float ex, float ey, float k, float c, float s) {
+    const float den = fmaf(c, ey, -(s * ex));
+    const float un = fmaf(rx, s, -(ry * c));
+    const float p1 = fmaf(k, den, 0.0f);
+    const float p2 = fmaf(un, den, 0.0f);
+    const float w = fabsf(den) - fabsf(un);
+    const unsigned miss = (unsigned)((int)(__float_as_uint(p1) | __float_as_uint(p2) | __float_as_uint(w)) >> 31);
+    return __float_as_uint(div_pos(fabsf(k), fabsf(den))) | miss;
+}
+
+constexpr int kThreads = 256;   // 4 waves.  (A workgroup reserves ceil(waves/4) slots on EVERY SIMD of its CU, so
+                                // a 5-wave block costs as much residency as an 8-wave one: measured 1 block/CU.)
+
 // ---------------------------------------------------------------- the step kernel
-template <int NB, bool PER_ENV>
+// One workgroup = 4 waves = EPB consecutive envs.
+//   wave 0 (lane = env): state loads, motion, sensor frame -> LDS | barrier A | goal angles / distance, then
+//          joins the ray-cast | barrier B | rules, reward, reset, state stores | barrier C
+//   waves 1-3: prefetch the segments of their first env (HBM loads do not depend on the pose) | barrier A |
+//          ray-cast | barrier B | barrier C
+//   per-env maps: an env is one work item taken from an LDS counter (wave 0 arrives late, so static
+//          assignment would idle three waves); lane = segment, 16 B/lane coalesced, every segment read from HBM
+//          once; the next item's segments are in flight while the current one is computed; nearest hit per
+//          beam = per-lane min over its segments, then one LDS atomic-min per lane that saw a hit.
+//   shared map: lane = ray (env, beam); segments staged in LDS tiles, read two at a time as wave-wide broadcasts.
+//   all:   the EPB x (B+6) observation tile leaves LDS as one contiguous, fully coalesced store.
+template <int NB, bool PER_ENV, int EPB>
 __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* __restrict__ action,
                                                         const float2* __restrict__ past_override,
                                                         void* __restrict__ obs_out, float* __restrict__ reward,
                                                         uint8_t* __restrict__ done, uint8_t* __restrict__ arrive,
                                                         uint8_t* __restrict__ ended, float* __restrict__ ep_return,
                                                         int32_t* __restrict__ ep_length) {
-    __shared__ StepSmem<NB> sm;
+    static_assert(EPB <= 64 && EPB >= 4 && NB % 2 == 0, "EPB / NB");
+    __shared__ StepSmem<NB, EPB> sm;
     __shared__ float4 seg_tile[PER_ENV ? 1 : kSegTile];
+    __shared__ int next_env;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -269,130 +337,205 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     constexpr int B = NB;       // host dispatch guarantees P.B == NB
     constexpr int D = B + 6;
     constexpr int DP = D + 1;   // padded LDS row stride
+    constexpr int PF = 2;       // segment tiles (64 segments each) of one env held in registers
     const int nloc = min(EPB, P.N - base);  // envs in this block
+    const unsigned kInfBits = 0x7f800000u;
 
-    // per-env registers of wave 0 that live across the phases
-    double x = 0, y = 0, th = 0, gx = 0, gy = 0, pdist = 0, dist = 0, yaw = 0, rel_theta = 0, diff = 0;
+    // pose-wave registers that live across the phases
+    double x = 0, y = 0, th = 0, gx = 0, gy = 0, pdist = 0, dist = 0, yaw = 0, rel_theta = 0, diff = 0, ret0 = 0;
     float2 act = make_float2(0.f, 0.f), pact = make_float2(0.f, 0.f);
+    uint32_t ctr = 0;
+    int step0 = 0;
     const int i = base + lane;
     const bool own = (wave == 0) && (lane < nloc);
 
-    // ---------------- phase 1: motion + sensor frame (wave 0, lane = env)
+    float4 pre[PF];  // prefetched segments of the current work item (per-env maps)
+    auto prefetch = [&](int el, float4 (&dst)[PF]) {
+        const float4* __restrict__ sp = P.seg + (size_t)(base + el) * P.S;
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {
+            const int j = lane + 64 * t;
+            if (j < P.S) dst[t] = sp[j];
+        }
+    };
+
     if (wave == 0) {
-        if (own) {
-            x = P.x[i]; y = P.y[i]; th = P.th[i];
-            gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
-            act = action[i];
-            pact = past_override ? past_override[i] : P.past_action[i];
-            // environment_new.py:273-278
-            const double v = (double)act.x / 4;
-            const double w = (double)act.y;
-            // turtlebot3_fake.cpp:117-118, :133-146, :154-155
-            const double vl = v - (w * kWheelSep / 2);
-            const double vr = v + (w * kWheelSep / 2);
-            const double dt = 1.0 / 30.0;
-            const double wl = vl / kWheelRadius, wr = vr / kWheelRadius;
-            const double wheel_l = wl * dt, wheel_r = wr * dt;
-            const double delta_s = kWheelRadius * (wheel_r + wheel_l) / 2.0;
-            const double delta_theta = kWheelRadius * (wheel_r - wheel_l) / kWheelSep;
-            for (int k = 0; k < kSubsteps; ++k) {  // :158-160
-                const double a = th + (delta_theta / 2.0);
-                x += delta_s * cos(a);
-                y += delta_s * sin(a);
-                th += delta_theta;
+        // ---------------- pose wave, part 1: motion + sensor frame
+        if (lane < EPB) {
+            if (own) {
+                x = P.x[i]; y = P.y[i]; th = P.th[i];
+                gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
+                act = action[i];
+                pact = past_override ? past_override[i] : P.past_action[i];
+                ctr = P.rng_ctr[i];
+                step0 = P.ep_step[i];
+                ret0 = P.ep_ret[i];
+                // environment_new.py:273-278
+                const double v = (double)act.x / 4;
+                const double w = (double)act.y;
+                // turtlebot3_fake.cpp:117-118, :133-146, :154-155
+                const double vl = v - (w * kWheelSep / 2);
+                const double vr = v + (w * kWheelSep / 2);
+                const double dt = 1.0 / 30.0;
+                const double wl = vl / kWheelRadius, wr = vr / kWheelRadius;
+                const double wheel_l = wl * dt, wheel_r = wr * dt;
+                const double delta_s = kWheelRadius * (wheel_r + wheel_l) / 2.0;
+                const double delta_theta = kWheelRadius * (wheel_r - wheel_l) / kWheelSep;
+                for (int k = 0; k < kSubsteps; ++k) {  // :158-160
+                    const double a = th + (delta_theta / 2.0);
+                    x += delta_s * cos(a);
+                    y += delta_s * sin(a);
+                    th += delta_theta;
+                }
+            }
+            const double cth = cos(th), sth = sin(th);
+            const double ox = x + kLidarX * cth;
+            const double oy = y + kLidarX * sth;
+            sm.org[lane] = make_float2((float)ox, (float)oy);
+            for (int b = 0; b < B; ++b) {
+                const double bc = P.beam_cs[b], bs = P.beam_cs[B + b];
+                const double c = cth * bc - sth * bs;
+                const double s = sth * bc + cth * bs;
+                sm.dir[b * EPB + lane] = make_float2((float)c, (float)s);
             }
         }
-        const double cth = cos(th), sth = sin(th);
-        const double ox = x + kLidarX * cth;
-        const double oy = y + kLidarX * sth;
-        sm.org[lane] = make_float2((float)ox, (float)oy);
-        for (int b = 0; b < B; ++b) {
-            const double bc = P.beam_cs[b], bs = P.beam_cs[B + b];
-            const double c = cth * bc - sth * bs;
-            const double s = sth * bc + cth * bs;
-            sm.dir[b * EPB + lane] = make_float2((float)c, (float)s);
-        }
-        if (own) {
-            goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
-            dist = hypot(gx - x, gy - y);  // environment_new.py:203
+        if (lane == 0) next_env = 3;  // envs 0,1,2 are pre-assigned to waves 1,2,3
+    } else {
+        // ---------------- waves 1-3, part 1: nothing here depends on the pose
+        for (int k = tid - 64; k < NB * EPB; k += kThreads - 64) sm.rng[k] = kInfBits;
+        if constexpr (PER_ENV) {
+            if (wave - 1 < nloc) prefetch(wave - 1, pre);
+        } else {
+            const int ns = min(kSegTile, P.S);
+            for (int j = tid - 64; j < ns; j += kThreads - 64) seg_tile[j] = P.seg[j];
         }
     }
-    __syncthreads();
+    __syncthreads();  // barrier A: origins / directions / first segment tile visible
 
-    // ---------------- phase 2: nearest hit per (env, beam)
+    if (wave == 0 && own) {
+        // ---------------- pose wave, part 2 (the other waves are already ray-casting): goal geometry
+        goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
+        dist = hypot(gx - x, gy - y);  // environment_new.py:203
+        sm.sv_d[0][lane] = x; sm.sv_d[1][lane] = y; sm.sv_d[2][lane] = th; sm.sv_d[3][lane] = gx; sm.sv_d[4][lane] = gy;
+        sm.sv_d[5][lane] = pdist; sm.sv_d[6][lane] = dist; sm.sv_d[7][lane] = yaw; sm.sv_d[8][lane] = rel_theta;
+        sm.sv_d[9][lane] = diff; sm.sv_d[10][lane] = ret0;
+        sm.sv_act[lane] = act; sm.sv_pact[lane] = pact; sm.sv_ctr[lane] = ctr; sm.sv_step[lane] = step0;
+    }
     if constexpr (PER_ENV) {
-        constexpr int EPW = EPB / (kThreads / 64);  // envs per wave
-        for (int q = 0; q < EPW; ++q) {
-            const int el = wave * EPW + q;
-            if (el >= nloc) break;  // wave-uniform
-            const float2 o = sm.org[el];
-            float dc[NB], ds[NB], best[NB];
+        auto grab = [&]() {
+            int v = 0;
+            if (lane == 0) v = atomicAdd(&next_env, 1);
+            return __builtin_amdgcn_readfirstlane(v);
+        };
+        int cur = (wave == 0) ? grab() : wave - 1;
+        if (wave == 0 && cur < nloc) prefetch(cur, pre);
+        while (cur < nloc) {  // wave-uniform
+            const int nxt = grab();
+            float4 pre_nxt[PF];
+            if (nxt < nloc) prefetch(nxt, pre_nxt);
+            const float2 o = sm.org[cur];
+            float dc[NB], ds[NB];
+            unsigned best[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const float2 d = sm.dir[b * EPB + el];
+                const float2 d = sm.dir[b * EPB + cur];
                 dc[b] = d.x;
                 ds[b] = d.y;
-                best[b] = INFINITY;
+                best[b] = kInfBits;
             }
-            const float4* __restrict__ sp = P.seg + (size_t)(base + el) * P.S;
-            for (int j = lane; j < P.S; j += 64) {
-                const float4 g = sp[j];
+            auto accumulate = [&](const float4 g) {
                 const float rx = g.x - o.x, ry = g.y - o.y;
                 const float ex = g.z - g.x, ey = g.w - g.y;
                 const float k = fmaf(rx, ey, -(ry * ex));
+                // div_pos needs |den| in [2^-60, 2^20]: true unless the segment is degenerate-small
+                // (coordinates are documented to be < 2^19); such tiles take the plain IEEE divide.
+                const bool tiny = fmaxf(fabsf(ex), fabsf(ey)) < 0x1p-10f;
+                if (__builtin_expect(__any(tiny), 0)) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const float t = ray_seg(rx, ry, ex, ey, k, dc[b], ds[b]);
-                    best[b] = t < best[b] ? t : best[b];
+                    for (int b = 0; b < NB; ++b)
+                        best[b] = min(best[b], __float_as_uint(ray_seg(rx, ry, ex, ey, k, dc[b], ds[b])) & 0x7fffffffu);
+                    return;
                 }
-            }
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const float v = wave_min(best[b]);
-                if (lane == 0) sm.rng[b * EPB + el] = scan_value(v);
-            }
+                for (int b = 0; b < NB; ++b) best[b] = min(best[b], ray_seg_bits(rx, ry, ex, ey, k, dc[b], ds[b]));
+            };
+#pragma unroll
+            for (int t = 0; t < PF; ++t)
+                if (lane + 64 * t < P.S) accumulate(pre[t]);
+            const float4* __restrict__ sp = P.seg + (size_t)(base + cur) * P.S;
+            for (int j = lane + 64 * PF; j < P.S; j += 64) accumulate(sp[j]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (best[b] < kInfBits) atomicMin(&sm.rng[b * EPB + cur], best[b]);
+#pragma unroll
+            for (int t = 0; t < PF; ++t) pre[t] = pre_nxt[t];
+            cur = nxt;
         }
     } else {
-        constexpr int MB = (NB + 3) / 4;  // beams per wave
-        const float2 o = sm.org[lane];
-        float dc[MB], ds[MB], best[MB];
+        // lane = ray (env, beam); segments come from the LDS tile two at a time (wave-wide broadcast reads)
+        constexpr int NR = EPB * NB;                          // rays of this block
+        constexpr int RPT = (NR + kThreads - 1) / kThreads;   // rays per thread
+        float ox[RPT], oy[RPT], dc[RPT], ds[RPT];
+        unsigned best[RPT];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int b = wave + 4 * m;
-            const float2 d = sm.dir[(b < NB ? b : 0) * EPB + lane];
-            dc[m] = d.x;
-            ds[m] = d.y;
-            best[m] = INFINITY;
+        for (int m = 0; m < RPT; ++m) {
+            const int r = min(tid + m * kThreads, NR - 1);
+            const int el = r / NB, b = r % NB;
+            const float2 o = sm.org[el];
+            const float2 d = sm.dir[b * EPB + el];
+            ox[m] = o.x; oy[m] = o.y; dc[m] = d.x; ds[m] = d.y;
+            best[m] = kInfBits;
         }
-        for (int s0 = 0; s0 < P.S; s0 += kSegTile) {
+        for (int s0 = 0; s0 < P.S; s0 += kSegTile) {  // uniform trip count
             const int ns = min(kSegTile, P.S - s0);
-            if (s0 > 0) __syncthreads();
-            for (int j = tid; j < ns; j += kThreads) seg_tile[j] = P.seg[s0 + j];
-            __syncthreads();
+            if (s0 > 0) {
+                __syncthreads();
+                for (int j = tid; j < ns; j += kThreads) seg_tile[j] = P.seg[s0 + j];
+                __syncthreads();
+            }
             for (int j = 0; j < ns; ++j) {
                 const float4 g = seg_tile[j];
-                const float rx = g.x - o.x, ry = g.y - o.y;
                 const float ex = g.z - g.x, ey = g.w - g.y;
-                const float k = fmaf(rx, ey, -(ry * ex));
+                const bool tiny = fmaxf(fabsf(ex), fabsf(ey)) < 0x1p-10f;  // wave-uniform: the segment is broadcast
 #pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    const float t = ray_seg(rx, ry, ex, ey, k, dc[m], ds[m]);
-                    best[m] = t < best[m] ? t : best[m];
+                for (int m = 0; m < RPT; ++m) {
+                    const float rx = g.x - ox[m], ry = g.y - oy[m];
+                    const float k = fmaf(rx, ey, -(ry * ex));
+                    const unsigned t = __builtin_expect(tiny, 0)
+                                           ? (__float_as_uint(ray_seg(rx, ry, ex, ey, k, dc[m], ds[m])) & 0x7fffffffu)
+                                           : ray_seg_bits(rx, ry, ex, ey, k, dc[m], ds[m]);
+                    best[m] = min(best[m], t);
                 }
             }
         }
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int b = wave + 4 * m;
-            if (b < NB) sm.rng[b * EPB + lane] = scan_value(best[m]);
+        for (int m = 0; m < RPT; ++m) {
+            const int r = tid + m * kThreads;
+            if (r < NR) sm.rng[(r % NB) * EPB + (r / NB)] = best[m];
         }
     }
-    __syncthreads();
+    __syncthreads();  // barrier B: nearest hits complete
 
-    // ---------------- phase 3: rules of getState / step / setReward + episode logic (wave 0)
+    // ---------------- pose wave, part 3: rules of getState / step / setReward + episode logic
     if (own) {
+        x = sm.sv_d[0][lane]; y = sm.sv_d[1][lane]; th = sm.sv_d[2][lane]; gx = sm.sv_d[3][lane]; gy = sm.sv_d[4][lane];
+        pdist = sm.sv_d[5][lane]; dist = sm.sv_d[6][lane]; yaw = sm.sv_d[7][lane]; rel_theta = sm.sv_d[8][lane];
+        diff = sm.sv_d[9][lane]; ret0 = sm.sv_d[10][lane];
+        act = sm.sv_act[lane]; pact = sm.sv_pact[lane]; ctr = sm.sv_ctr[lane]; step0 = sm.sv_step[lane];
         float* row = sm.obs + lane * DP;
-        const float mn = write_obs_row(row, sm.rng + lane, EPB, B, pact.x, pact.y, dist, yaw, rel_theta, diff, P.diag);
+        float mn = INFINITY;
+        for (int b = 0; b < B; ++b) {
+            float r = scan_value(__uint_as_float(sm.rng[b * EPB + lane]));
+            if (r == INFINITY) r = 3.5f;  // environment_new.py:193-194
+            mn = r < mn ? r : mn;
+            row[b] = r / 3.5f;            // :289 (see write_obs_row on the float32 divide)
+        }
+        row[B + 0] = pact.x;              // :299-300
+        row[B + 1] = pact.y;
+        row[B + 2] = (float)(dist / P.diag);  // :301
+        row[B + 3] = (float)(yaw / 360);
+        row[B + 4] = (float)(rel_theta / 360);
+        row[B + 5] = (float)(diff / 180);
         const bool d = (0.2 > (double)mn) && ((double)mn > 0);  // environment_new.py:200
         const bool a = dist <= P.thr;                             // :204
         // setReward, :209-222
@@ -400,13 +543,12 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         pdist = dist;
         if (d) r = -100.;
         if (a) r = 120.;
-        uint32_t ctr = P.rng_ctr[i];
         if (a && P.respawn) {  // :245-267
             sample_goal(P, i, 1, ctr, gx, gy);
             pdist = hypot(gx - x, gy - y);
         }
-        int step = P.ep_step[i] + 1;
-        double ret = P.ep_ret[i] + r;
+        int step = step0 + 1;
+        double ret = ret0 + r;
         const bool timeout = (P.max_ep_steps > 0) && (step >= P.max_ep_steps);  // ppo.py:552
         const bool end = d || a || timeout;
         reward[i] = (float)r;
@@ -437,9 +579,9 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         P.ep_ret[i] = ret;
         P.rng_ctr[i] = ctr;
     }
-    __syncthreads();
+    __syncthreads();  // barrier C: observation tile complete in LDS
 
-    // ---------------- phase 4: coalesced store of the block's observation tile
+    // ---------------- coalesced store of the block's observation tile
     const int n_out = nloc * D;
     if (P.obs_f16) {
         __half* o = reinterpret_cast<__half*>(obs_out) + (size_t)base * D;
@@ -549,17 +691,31 @@ struct navsim {
     bool has_map = false;
 };
 
+int g_epb = 16;  // envs per workgroup (NAVSIM_EPB = 16 | 32 | 64 overrides; tuning knob)
+
+template <int NB, int EPB>
+static void launch_step_epb(const navsim* h, const float* action, const float* past, void* obs, float* reward,
+                            uint8_t* done, uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len,
+                            hipStream_t st) {
+    const dim3 grid((h->P.N + EPB - 1) / EPB), block(kThreads);
+    if (h->P.per_env)
+        hipLaunchKernelGGL((step_kernel<NB, true, EPB>), grid, block, 0, st, h->P, (const float2*)action,
+                           (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len);
+    else
+        hipLaunchKernelGGL((step_kernel<NB, false, EPB>), grid, block, 0, st, h->P, (const float2*)action,
+                           (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len);
+}
+
 template <int NB>
 static void launch_step(const navsim* h, const float* action, const float* past, void* obs, float* reward,
                         uint8_t* done, uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len,
                         hipStream_t st) {
-    const dim3 grid((h->P.N + EPB - 1) / EPB), block(kThreads);
-    if (h->P.per_env)
-        hipLaunchKernelGGL((step_kernel<NB, true>), grid, block, 0, st, h->P, (const float2*)action,
-                           (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len);
-    else
-        hipLaunchKernelGGL((step_kernel<NB, false>), grid, block, 0, st, h->P, (const float2*)action,
-                           (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len);
+    switch (g_epb) {
+        case 64: launch_step_epb<NB, 64>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
+        case 32: launch_step_epb<NB, 32>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
+        case 8: launch_step_epb<NB, 8>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
+        default: launch_step_epb<NB, 16>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
+    }
 }
 
 #pragma GCC visibility push(default)
@@ -595,6 +751,10 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(NAVSIM_E_HIP, "navsim_create: no HIP device (there is no CPU path)");
 
+    if (const char* e = std::getenv("NAVSIM_EPB")) {
+        const int v = std::atoi(e);
+        if (v == 8 || v == 16 || v == 32 || v == 64) g_epb = v;
+    }
     navsim* h = new navsim();
     h->cfg = *cfg;
     const size_t N = (size_t)cfg->n_envs;

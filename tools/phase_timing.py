@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Dev tool: per-phase timestamps (wall_clock64, 100 MHz -> 10 ns ticks) from the instrumented build."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from navbot_ppo_amd import _native, maps
+_native.LIB_PATH = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else "build/libnavsim_timing.so")
+from navbot_ppo_amd.env import NavSim
+N = 16384
+seg = maps.replicate_per_env(maps.stage_2(), N, seed=0)
+sim = NavSim(N, max_episode_steps=500, auto_reset=True, seed=0); sim.set_map(seg, per_env=True)
+io = sim.alloc_io(); sim.reset(io.obs)
+acts = torch.rand((N, 2), device="cuda"); acts[:, 1] = acts[:, 1] * 2 - 1
+for k in range(20): sim.step(acts, io.obs, io.reward, io.done, io.arrive, io.ended)
+torch.cuda.synchronize()
+sim.step(acts, io.obs, io.reward, io.done, io.arrive, io.ended); torch.cuda.synchronize()
+buf = np.zeros(512, dtype=np.int64)
+L = _native.lib(); L.navsim_dbg_read.argtypes = [C.c_void_p]; L.navsim_dbg_read(buf.ctypes.data_as(C.c_void_p))
+b = buf.reshape(8, 8, 8)  # [sampled block][wave][slot]
+t0 = b[:, :4, 0].min()
+names = ["start", "pre-A", "post-A", "pre-B", "post-B", "pre-C", "post-C", "end"]
+for blk in range(4):
+    print(f"block sample {blk}")
+    for w in range(4):
+        print("  wave", w, " ".join(f"{names[s]}={(b[blk, w, s] - t0) * 10:6d}ns" for s in range(8)))
+
+EPB = int(os.environ.get('NAVSIM_EPB', '16'))
+blk = np.zeros(8192 * 3, dtype=np.int64)
+L.navsim_blk_read.argtypes = [C.c_void_p]; L.navsim_blk_read(blk.ctypes.data_as(C.c_void_p))
+nb = (N + EPB - 1) // EPB
+blk = blk.reshape(8192, 3)[:nb]
+st, en, hw = blk[:, 0], blk[:, 1], blk[:, 2]
+t0 = st.min()
+st = (st - t0) * 10; en = (en - t0) * 10
+print("blocks", nb, "kernel span ns", en.max(), "mean block life ns", (en - st).mean())
+xcc = (hw >> 32) & 0xf; cu = (hw & 0xffffffff) >> 8 & 0xf; se = (hw & 0xffffffff) >> 13 & 0x7
+print("start time histogram (us):", np.histogram(st / 1000, bins=12)[0].tolist())
+for tq in range(0, int(en.max()), 5000):
+    print(f"  t={tq/1000:5.1f}us running blocks: {int(((st <= tq) & (en > tq)).sum())}")
+print("xcc counts", np.bincount(xcc.astype(int)).tolist())
+print("first 16 blocks xcc", xcc[:16].tolist(), "start", st[:16].tolist())
