@@ -60,14 +60,19 @@ class DistCtx:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.enabled = self.world > 1
         if device is None:
-            device = torch.device(f"cuda:{self.local_rank}") if torch.cuda.is_available() else torch.device("cpu")
+            if torch.cuda.is_available():
+                device = torch.device(f"cuda:{self.local_rank % torch.cuda.device_count()}")
+            else:
+                device = torch.device("cpu")
         self.device = torch.device(device)
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
         if self.enabled and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            backend = "nccl" if self.device.type == "cuda" else "gloo"  # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm.  NAVBOT_DIST_BACKEND=gloo lets several ranks share one GPU (tests only:
+            # RCCL refuses two ranks on the same device).
+            backend = os.environ.get("NAVBOT_DIST_BACKEND") or ("nccl" if self.device.type == "cuda" else "gloo")
             kw = {"device_id": self.device} if backend == "nccl" else {}
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
 

@@ -370,3 +370,24 @@ def test_full_size_properties(cfg):
             assert io.done[i].item() == out["done"][0] and io.arrive[i].item() == out["arrive"][0]
             assert io.ended[i].item() == out["ended"][0]
     assert total_len + int(s.get_state()["ep_step"].sum()) == K * N
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N>1 launch path of bench.py end to end (torch.distributed.run, env shards, flat-gradient all-reduce,
+    max-over-ranks timing, one JSON line from rank 0).  RCCL needs one GPU per rank, so on this 1-GPU box the two
+    ranks share cuda:0 and the collectives go over gloo; everything else is the production path."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NAVBOT_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--envs-per-gpu", "512", "--rollout", "64", "--epochs", "3"]
+    out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["config"]["n_envs_total"] == 1024 and js["scaling"] == "weak"
+    assert js["value"] > 0 and js["metric"] == "env_steps_per_sec"
