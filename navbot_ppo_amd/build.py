@@ -5,7 +5,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "navsim.hip")
+SRCS = [os.path.join(HERE, "csrc", "navsim.hip"), os.path.join(HERE, "csrc", "ppo_mlp64.hip")]
+HDRS = ["navsim.h", "navppo.h"]
 INC = os.path.join(REPO, "include")
 LIB = os.path.join(HERE, "libnavsim.so")
 
@@ -25,13 +26,13 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in (SRC, os.path.join(INC, "navsim.h")))
+    return any(os.path.getmtime(p) > t for p in SRCS + [os.path.join(INC, h) for h in HDRS])
 
 
 def build_native(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-I", INC, SRC, "-o", LIB]
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-I", INC] + SRCS + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

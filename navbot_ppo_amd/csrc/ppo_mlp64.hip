@@ -1,0 +1,366 @@
+// ppo_mlp64.hip -- fused PPO loss + gradient for the 16-64-64 actor / critic heads on gfx950 (f32 MFMA).
+//
+// Replaces, for one epoch of the update loop of the reference (project_ppo/src/ppo.py:305-397):
+//   evaluate()            ppo.py:708-737   V = critic(obs), mean = actor(obs), log_prob(batch_acts)
+//   ratios / surrogates   ppo.py:316-320
+//   actor_loss, critic_loss and both backward() calls   ppo.py:342-343, 349, 386
+// for the "mlp64x2" policy (BASELINE.json configs[1]; 16-64-64 MLP of NetActor_old / the tutorial network,
+// project_ppo/src/net_actor.py:147-189, graph_code/ppo_for_beginners/network.py:11-50).
+//
+// Why a kernel: in PyTorch every layer's activations ([2.1 M, 64] f32 = 537 MB) make a round trip through HBM per op
+// (profiles/r01_bench_v4_kernel_stats.csv: 3.8 ms per epoch, relu-backward alone 1 ms).  Here a workgroup
+// keeps a 128-sample tile and the net's weights in LDS (132 KB of the CU's 160 KB): per epoch the batch is read
+// once per net (84 B/sample) and nothing but 10,691 gradient floats per workgroup is written.
+//
+// Arithmetic: float32 throughout.  GEMMs use v_mfma_f32_32x32x2_f32, which is an exact k-ordered f32 fma chain
+// (no reduced-precision inputs); sums over samples are taken in tile order, so results agree with PyTorch
+// autograd to fp32 round-off, not bit for bit.
+//
+// One launch per net (template ACTOR): grid = persistent workgroups (1 per CU), each loops over tiles.
+//   F1  H1 = relu(X W1^T + b1)      [128x16]x[16x64]    wave w owns rows 32w..32w+31
+//   F2  H2 = relu(H1 W2^T + b2)     [128x64]x[64x64]
+//   heads + PPO loss / MSE (VALU, thread = sample) -> g3, g4 (dL/dz of the output units)
+//   dH2 = (g3 w3 + g4 w4) . [H2 > 0]                    (VALU, elementwise) ; db2, dW3, dW4, db3, db4 partial sums
+//   B2  dH1 = (dH2 W2) . [H1 > 0]   [128x64]x[64x64]    ; db1 partial sums
+//   G2  dW2 += dH2^T H1             [64x128]x[128x64]   wave w owns one 32x32 quadrant, accumulators persist over tiles
+//   G1  dW1 += dH1^T X              [64x128]x[128x16]
+// At the end every workgroup writes its partial gradient (one row of `partial`), and `reduce_partials` sums rows.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "navppo.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TM = 128;    // samples per tile
+constexpr int H = 64;      // hidden width
+constexpr int IN = 16;     // observation width
+constexpr int LDH = H + 1; // padded LDS row strides (odd: conflict-free for row-per-lane and column-per-lane reads)
+constexpr int LDX = IN + 1;
+constexpr int kThreads = 256;
+
+// flat parameter layout of one net (nn.Module.named_parameters order: layer1.weight, layer1.bias, layer2.weight,
+// layer2.bias, layer3.weight, layer3.bias [, layer4.weight, layer4.bias])
+constexpr int OFF_W1 = 0, OFF_B1 = OFF_W1 + H * IN, OFF_W2 = OFF_B1 + H, OFF_B2 = OFF_W2 + H * H, OFF_W3 = OFF_B2 + H,
+              OFF_B3 = OFF_W3 + H, OFF_W4 = OFF_B3 + 1, OFF_B4 = OFF_W4 + H;
+constexpr int P_ACTOR = OFF_B4 + 1;   // 5378
+constexpr int P_CRITIC = OFF_B3 + 1;  // 5313
+static_assert(P_ACTOR == NAVPPO_MLP64_ACTOR_PARAMS && P_CRITIC == NAVPPO_MLP64_CRITIC_PARAMS, "layout");
+
+struct Smem {
+    float X[TM * LDX];
+    float H1[TM * LDH];
+    float H2[TM * LDH];   // H2, later dH1
+    float dH2[TM * LDH];
+    float W1[H * LDX];
+    float W2[H * LDH];
+    float b1[H], b2[H], w3[H], w4[H];
+    float g3[TM], g4[TM];
+};
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// C/D element (row, col) of accumulator register r for lane l (32x32 shapes; cdna_hip_programming.md section 3)
+__device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <bool ACTOR>
+__global__ __launch_bounds__(kThreads) void mlp64_pass(const float* __restrict__ params, const float* __restrict__ obs,
+                                                       const float* __restrict__ act, const float* __restrict__ logp_old,
+                                                       const float* __restrict__ rtg, const float* __restrict__ adv,
+                                                       long long M, float var, float clip, float inv_n,
+                                                       float* __restrict__ partial, float* __restrict__ stats_partial) {
+    __shared__ Smem sm;
+    constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- weights -> LDS (once per workgroup)
+    for (int k = tid; k < H * IN; k += kThreads) sm.W1[(k / IN) * LDX + (k % IN)] = params[OFF_W1 + k];
+    for (int k = tid; k < H * H; k += kThreads) sm.W2[(k / H) * LDH + (k % H)] = params[OFF_W2 + k];
+    if (tid < H) {
+        sm.b1[tid] = params[OFF_B1 + tid];
+        sm.b2[tid] = params[OFF_B2 + tid];
+        sm.w3[tid] = params[OFF_W3 + tid];
+        sm.w4[tid] = ACTOR ? params[OFF_W4 + tid] : 0.f;
+    }
+    const float b3 = params[OFF_B3];
+    const float b4 = ACTOR ? params[OFF_B4] : 0.f;
+
+    // ---- accumulators that persist over this workgroup's tiles
+    f32x16 accW2 = zero16();             // quadrant (wave>>1, wave&1) of dW2
+    f32x16 accW1 = zero16();             // half (wave&1) of dW1 over the k-steps of parity (wave>>1)
+    float acc_db1[2] = {0.f, 0.f};       // columns l31 and 32+l31 of dH1 rows owned in B2
+    float acc_db2 = 0.f, acc_dw3 = 0.f, acc_dw4 = 0.f;  // column (tid & 63), rows (tid>>6) + 4 i
+    float acc_db3 = 0.f, acc_db4 = 0.f;  // sample-owner threads
+    float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;  // loss, (kl, clip-frac) sums
+
+    const long long n_tiles = (M + TM - 1) / TM;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long m_base = tile * TM;
+        __syncthreads();  // previous tile's LDS readers are done
+        // ---- X tile -> LDS (rows beyond M are zero)
+        for (int k = tid; k < TM * IN; k += kThreads) {
+            const int m = k / IN, c = k % IN;
+            sm.X[m * LDX + c] = (m_base + m < M) ? obs[(m_base + m) * IN + c] : 0.f;
+        }
+        __syncthreads();
+
+        // ---- F1: H1 = relu(X W1^T + b1), wave = 32-row strip, two 32-col tiles, K = 16
+        {
+            f32x16 c0 = zero16(), c1 = zero16();
+            const float* a_ptr = sm.X + (32 * wave + l31) * LDX + lhi;
+            const float* b0_ptr = sm.W1 + l31 * LDX + lhi;
+            const float* b1_ptr = sm.W1 + (32 + l31) * LDX + lhi;
+#pragma unroll
+            for (int k0 = 0; k0 < IN; k0 += 2) {
+                const float a = a_ptr[k0];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0_ptr[k0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1_ptr[k0], c1, 0, 0, 0);
+            }
+            const float bias0 = sm.b1[l31], bias1 = sm.b1[32 + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * wave + c_row(r, lane);
+                sm.H1[row * LDH + l31] = fmaxf(c0[r] + bias0, 0.f);
+                sm.H1[row * LDH + 32 + l31] = fmaxf(c1[r] + bias1, 0.f);
+            }
+        }
+        __syncthreads();
+
+        // ---- F2: H2 = relu(H1 W2^T + b2), K = 64
+        {
+            f32x16 c0 = zero16(), c1 = zero16();
+            const float* a_ptr = sm.H1 + (32 * wave + l31) * LDH + lhi;
+            const float* b0_ptr = sm.W2 + l31 * LDH + lhi;
+            const float* b1_ptr = sm.W2 + (32 + l31) * LDH + lhi;
+#pragma unroll 8
+            for (int k0 = 0; k0 < H; k0 += 2) {
+                const float a = a_ptr[k0];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0_ptr[k0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1_ptr[k0], c1, 0, 0, 0);
+            }
+            const float bias0 = sm.b2[l31], bias1 = sm.b2[32 + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * wave + c_row(r, lane);
+                sm.H2[row * LDH + l31] = fmaxf(c0[r] + bias0, 0.f);
+                sm.H2[row * LDH + 32 + l31] = fmaxf(c1[r] + bias1, 0.f);
+            }
+        }
+        __syncthreads();
+
+        // ---- output units + loss (thread = sample): g3 = dL/dz3, g4 = dL/dz4
+        if (tid < TM) {
+            const long long m = m_base + tid;
+            float g3 = 0.f, g4 = 0.f;
+            if (m < M) {
+                const float* h2 = sm.H2 + tid * LDH;
+                float z3 = b3, z4 = b4;
+#pragma unroll 8
+                for (int k = 0; k < H; ++k) {
+                    const float h = h2[k];
+                    z3 = fmaf(h, sm.w3[k], z3);
+                    if (ACTOR) z4 = fmaf(h, sm.w4[k], z4);
+                }
+                if (ACTOR) {
+                    const float mu0 = 1.0f / (1.0f + expf(-z3));   // torch.sigmoid, net_actor.py:185
+                    const float mu1 = tanhf(z4);                    // net_actor.py:186
+                    const float a0 = act[2 * m], a1 = act[2 * m + 1];
+                    const float d0 = a0 - mu0, d1 = a1 - mu1;
+                    // MultivariateNormal(mean, var*I).log_prob, ppo.py:734-735
+                    const float lp = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);
+                    const float lr = lp - logp_old[m];
+                    const float ratio = expf(lr);                  // ppo.py:316
+                    const float A = adv[m];
+                    const float s1 = ratio * A;                     // ppo.py:319
+                    const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+                    const float s2 = rc * A;                        // ppo.py:320
+                    st0 += -fminf(s1, s2);                          // ppo.py:342 (mean taken by inv_n at the end)
+                    st2 += (ratio - 1.0f) - lr;                     // approx KL, ppo.py:326
+                    st3 += (fabsf(ratio - 1.0f) > clip) ? 1.f : 0.f;  // clip fraction, ppo.py:335
+                    // d(-min(s1,s2))/d ratio: -A through s1 when s1 <= s2 inside the clip range (tie: both halves), or
+                    // when s1 < s2 outside it; 0 when the clipped (constant) branch is the minimum
+                    const bool inside = (ratio >= 1.0f - clip) && (ratio <= 1.0f + clip);
+                    const float dL_dratio = (inside || s1 < s2) ? -A : 0.f;
+                    const float dL_dlp = dL_dratio * ratio * inv_n;
+                    g3 = dL_dlp * (d0 / var) * (mu0 * (1.0f - mu0));
+                    g4 = dL_dlp * (d1 / var) * (1.0f - mu1 * mu1);
+                } else {
+                    const float V = z3;                             // critic(obs).squeeze(), ppo.py:724
+                    const float e = V - rtg[m];
+                    st1 += e * e;                                   // MSELoss, ppo.py:343
+                    g3 = 2.0f * e * inv_n;
+                }
+            }
+            sm.g3[tid] = g3;
+            sm.g4[tid] = g4;
+            acc_db3 += g3;
+            acc_db4 += g4;
+        }
+        __syncthreads();
+
+        // ---- dH2 = (g3 w3 + g4 w4) . [H2 > 0] ; column sums for db2, dW3, dW4
+        {
+            const int k = tid & 63;
+            const float w3k = sm.w3[k], w4k = sm.w4[k];
+#pragma unroll 4
+            for (int i = 0; i < TM / 4; ++i) {
+                const int m = (tid >> 6) + 4 * i;
+                const float h = sm.H2[m * LDH + k];
+                const float g3 = sm.g3[m], g4 = sm.g4[m];
+                const float d = (h > 0.f) ? fmaf(g3, w3k, g4 * w4k) : 0.f;
+                sm.dH2[m * LDH + k] = d;
+                acc_db2 += d;
+                acc_dw3 = fmaf(g3, h, acc_dw3);
+                acc_dw4 = fmaf(g4, h, acc_dw4);
+            }
+        }
+        __syncthreads();
+
+        // ---- B2: dH1 = (dH2 W2) . [H1 > 0] -> stored over H2 ; db1 partial sums
+        {
+            f32x16 c0 = zero16(), c1 = zero16();
+            const float* a_ptr = sm.dH2 + (32 * wave + l31) * LDH + lhi;
+            const float* b0_ptr = sm.W2 + lhi * LDH + l31;
+            const float* b1_ptr = sm.W2 + lhi * LDH + 32 + l31;
+#pragma unroll 8
+            for (int n0 = 0; n0 < H; n0 += 2) {
+                const float a = a_ptr[n0];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0_ptr[n0 * LDH], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1_ptr[n0 * LDH], c1, 0, 0, 0);
+            }
+            // all waves have finished reading H2 (dH2 pass + barrier); dH1 overwrites this wave's own rows only
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * wave + c_row(r, lane);
+                const float d0 = (sm.H1[row * LDH + l31] > 0.f) ? c0[r] : 0.f;
+                const float d1 = (sm.H1[row * LDH + 32 + l31] > 0.f) ? c1[r] : 0.f;
+                sm.H2[row * LDH + l31] = d0;
+                sm.H2[row * LDH + 32 + l31] = d1;
+                acc_db1[0] += d0;
+                acc_db1[1] += d1;
+            }
+        }
+        __syncthreads();
+
+        // ---- G2: dW2[n][k] += sum_m dH2[m][n] H1[m][k], quadrant (nt, kt) = (wave>>1, wave&1), K = 128 samples
+        {
+            const float* a_ptr = sm.dH2 + lhi * LDH + 32 * (wave >> 1) + l31;
+            const float* b_ptr = sm.H1 + lhi * LDH + 32 * (wave & 1) + l31;
+#pragma unroll 8
+            for (int m0 = 0; m0 < TM; m0 += 2)
+                accW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[m0 * LDH], b_ptr[m0 * LDH], accW2, 0, 0, 0);
+        }
+        // ---- G1: dW1[n][k] += sum_m dH1[m][n] X[m][k] (k < 16; columns 16..31 of the 32-wide tile are zero padding)
+        {
+            const float* a_ptr = sm.H2 + lhi * LDH + 32 * (wave & 1) + l31;
+            const float* b_ptr = sm.X + lhi * LDX + (l31 & 15);
+            const bool live = l31 < IN;
+#pragma unroll 8
+            for (int s = 0; s < TM / 4; ++s) {
+                const int m0 = 2 * (2 * s + (wave >> 1));
+                const float b = live ? b_ptr[m0 * LDX] : 0.f;
+                accW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[m0 * LDH], b, accW1, 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- workgroup reduction of the partial gradient in LDS, then one coalesced row of `partial`
+    __syncthreads();
+    float* red = sm.H1;  // P <= 5378 floats, H1 holds 8320
+    for (int k = tid; k < P + 4; k += kThreads) red[k] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = c_row(r, lane);
+        atomicAdd(&red[OFF_W2 + (32 * (wave >> 1) + row) * H + 32 * (wave & 1) + l31], accW2[r]);
+        if (l31 < IN) atomicAdd(&red[OFF_W1 + (32 * (wave & 1) + row) * IN + l31], accW1[r]);
+    }
+    atomicAdd(&red[OFF_B1 + l31], acc_db1[0]);
+    atomicAdd(&red[OFF_B1 + 32 + l31], acc_db1[1]);
+    atomicAdd(&red[OFF_B2 + (tid & 63)], acc_db2);
+    atomicAdd(&red[OFF_W3 + (tid & 63)], acc_dw3);
+    if (ACTOR) atomicAdd(&red[OFF_W4 + (tid & 63)], acc_dw4);
+    if (tid < TM) {
+        atomicAdd(&red[OFF_B3], acc_db3);
+        if (ACTOR) atomicAdd(&red[OFF_B4], acc_db4);
+        atomicAdd(&red[P + 0], ACTOR ? st0 : st1);
+        atomicAdd(&red[P + 1], st2);
+        atomicAdd(&red[P + 2], st3);
+    }
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * P;
+    for (int k = tid; k < P; k += kThreads) out[k] = red[k];
+    if (tid < 3) stats_partial[blockIdx.x * 4 + tid] = red[P + tid];
+}
+
+// grad[p] = sum over workgroups ; stats = sums * inv_n
+__global__ void reduce_partials(const float* __restrict__ partial, const float* __restrict__ stats_partial, int n_blocks,
+                                int P, float inv_n, float* __restrict__ grad, float* __restrict__ stats, int stats_off) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) {
+        float s = 0.f;
+        for (int b = 0; b < n_blocks; ++b) s += partial[(size_t)b * P + p];
+        grad[p] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3) {
+        float s = 0.f;
+        for (int b = 0; b < n_blocks; ++b) s += stats_partial[b * 4 + threadIdx.x];
+        stats[stats_off + threadIdx.x] = s * inv_n;
+    }
+}
+
+thread_local std::string g_err;
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char* navppo_last_error(void) { return g_err.c_str(); }
+
+size_t navppo_mlp64_workspace_bytes(void) {
+    return (size_t)NAVPPO_MLP64_MAX_BLOCKS * (NAVPPO_MLP64_ACTOR_PARAMS + 4) * sizeof(float);
+}
+
+int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const float* act_dev,
+                           const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples,
+                           float var, float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
+    if (!params_dev || !obs_dev || !act_dev || !logp_old_dev || !rtg_dev || !adv_dev || !grad_dev || !stats_dev ||
+        !workspace_dev || n_samples < 1 || !(var > 0.f)) {
+        g_err = "navppo_mlp64_loss_grad: bad argument";
+        return -1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const long long tiles = (n_samples + TM - 1) / TM;
+    const int blocks = (int)(tiles < NAVPPO_MLP64_MAX_BLOCKS ? tiles : NAVPPO_MLP64_MAX_BLOCKS);
+    float* partial = reinterpret_cast<float*>(workspace_dev);
+    float* stats_partial = partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * NAVPPO_MLP64_ACTOR_PARAMS;
+    const float inv_n = 1.0f / (float)n_samples;
+    hipLaunchKernelGGL((mlp64_pass<true>), dim3(blocks), dim3(kThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
+                       rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial);
+    hipLaunchKernelGGL(reduce_partials, dim3((P_ACTOR + 255) / 256), dim3(256), 0, st, partial, stats_partial, blocks, P_ACTOR,
+                       inv_n, grad_dev, stats_dev, 0);
+    hipLaunchKernelGGL((mlp64_pass<false>), dim3(blocks), dim3(kThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
+                       logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial);
+    hipLaunchKernelGGL(reduce_partials, dim3((P_CRITIC + 255) / 256), dim3(256), 0, st, partial, stats_partial, blocks, P_CRITIC,
+                       inv_n, grad_dev + P_ACTOR, stats_dev, 4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_err = std::string("navppo_mlp64_loss_grad: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

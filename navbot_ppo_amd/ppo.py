@@ -46,6 +46,7 @@ class PPOConfig:
     save_freq: int = 2                     # ppo.py:774
     seed: int = 0
     use_graph: bool = True                 # capture the T-step rollout in one hipGraph
+    fused_update: bool = True              # mlp64x2 on GPU: fused HIP loss+gradient kernel (csrc/ppo_mlp64.hip)
     output_dir: str = ""                   # "" = no checkpoints / logs
     method_name: str = "baseline"
 
@@ -177,6 +178,29 @@ class PPOUpdater:
         fused = self.device.type == "cuda"
         self.opt = torch.optim.Adam([self.fp.proxy], lr=cfg.lr, fused=fused)  # == the two Adam(lr) of ppo.py:116-117
         self.stats = {}
+        # HIP path for the 16-64-64 heads: one fused MFMA kernel per net instead of ~40 PyTorch kernels per epoch
+        self.fused_mlp64 = (self.device.type == "cuda" and cfg.policy == "mlp64x2" and cfg.fused_update
+                            and isinstance(actor, nets.MLP64Actor) and actor.layer1.in_features == 16)
+        if self.fused_mlp64:
+            from ._native import lib
+            assert self.fp.numel == 5378 + 5313
+            self._ws = torch.empty(lib().navppo_mlp64_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
+            self._fstats = torch.zeros(8, dtype=torch.float32, device=self.device)
+
+    def _fused_loss_grad(self, obs, acts, logp_old, rtg, adv, var):
+        """evaluate + losses + backward of ppo.py:307-386 in the HIP kernels of csrc/ppo_mlp64.hip; gradients land
+        in the flat gradient buffer, (actor_loss, approx_kl, clip_frac, -, critic_loss) in self._fstats."""
+        import ctypes as C
+        from ._native import lib
+        L = lib()
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        for t in (obs, acts, logp_old, rtg, adv):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        rc = L.navppo_mlp64_loss_grad(ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+                                      int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad),
+                                      ptr(self._fstats), ptr(self._ws), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"navppo_mlp64_loss_grad failed: {L.navppo_last_error().decode()}")
 
     def update(self, obs, acts, logp_old, rtg, var):
         cfg, ctx = self.cfg, self.ctx
@@ -187,7 +211,21 @@ class PPOUpdater:
         n_ep = cfg.n_updates_per_iteration
         acc = torch.zeros(6, device=obs.device)                # sums over epochs of diagnostics
         self.loss_history = torch.zeros((n_ep, 2), device=obs.device)  # per-epoch (actor, critic) loss, ppo.py:396-397
+        var_f = float(var) if self.fused_mlp64 else None
+        if self.fused_mlp64:
+            obs, acts, logp_old, rtg, adv = (t.contiguous() for t in (obs, acts, logp_old, rtg, adv))
         for ep in range(n_ep):                                 # ppo.py:305
+            if self.fused_mlp64:
+                self._fused_loss_grad(obs, acts, logp_old, rtg, adv, var_f)
+                if world > 1:
+                    ctx.all_reduce_sum(self.fp.grad)
+                    self.fp.grad.div_(world)
+                self.opt.step()
+                f = self._fstats
+                self.loss_history[ep] = torch.stack([f[0], f[4]])
+                acc += torch.stack([f[0], f[4], f[1], f[2], self.fp.grad.norm(), V0.mean()])
+                a_loss, c_loss = f[0].clone(), f[4].clone()
+                continue
             a_loss, c_loss, ratios, logp, _ = ppo_losses(self.actor, self.critic, obs, acts, logp_old, rtg, adv, var, cfg.clip)
             self.fp.grad.zero_()
             (a_loss + c_loss).backward()                       # disjoint nets: same grads as the two backward()s of :349,:386
