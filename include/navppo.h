@@ -45,6 +45,20 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
                            const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples,
                            float var, float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
 
+/*
+ * PPO.get_action() (ppo.py:673-706) for all envs of a shard in one launch: mean = actor(obs) (net_actor forward),
+ * sample MVN(mean, var*I), clamp a0 to [0,1] and a1 to [-1,1] (ppo.py:700-703), log-prob of the CLAMPED action (:704).
+ *   actor_params_dev [5378]   obs_dev [n,16]   act_dev [n,2] out   logp_dev [n] out   mean_dev [n,2] out, nullable
+ *   noise_dev [n,2] standard normal draws, nullable: NULL = Philox4x32-10 keyed by (seed, env_id_base + i, step) +
+ *   Box-Muller inside the kernel (the reference uses torch's global generator, unseeded by default: ppo.py:805-811);
+ *   step = *step_base_dev (nullable = 0) + step_offset.  var_dev and step_base_dev are DEVICE scalars so that a
+ *   captured hipGraph of T launches sees the current variance and a fresh noise stream on every replay.
+ * The exploration-covariance decay of ppo.py:694-695 is the caller's (it changes `var` between launches).
+ */
+int navppo_mlp64_act(const float* actor_params_dev, const float* obs_dev, const float* noise_dev, int64_t n_envs,
+                     const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
+                     uint32_t step_offset, float* act_dev, float* logp_dev, float* mean_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

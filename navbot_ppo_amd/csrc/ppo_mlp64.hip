@@ -72,20 +72,24 @@ __device__ __forceinline__ f32x16 zero16() {
 // C/D element (row, col) of accumulator register r for lane l (32x32 shapes; cdna_hip_programming.md section 3)
 __device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+constexpr int kPassThreads = 512;  // 8 waves = 2 per SIMD: one wave's MFMA overlaps the other's LDS / VALU work
+
 template <bool ACTOR>
-__global__ __launch_bounds__(kThreads) void mlp64_pass(const float* __restrict__ params, const float* __restrict__ obs,
-                                                       const float* __restrict__ act, const float* __restrict__ logp_old,
-                                                       const float* __restrict__ rtg, const float* __restrict__ adv,
-                                                       long long M, float var, float clip, float inv_n,
-                                                       float* __restrict__ partial, float* __restrict__ stats_partial) {
+__global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restrict__ params, const float* __restrict__ obs,
+                                                           const float* __restrict__ act, const float* __restrict__ logp_old,
+                                                           const float* __restrict__ rtg, const float* __restrict__ adv,
+                                                           long long M, float var, float clip, float inv_n,
+                                                           float* __restrict__ partial, float* __restrict__ stats_partial) {
     __shared__ Smem sm;
     constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
+    constexpr int NT = kPassThreads;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
+    const int strip = wave >> 1, ct = wave & 1;  // F1/F2/B2: 32-row strip and 32-column tile owned by this wave
 
     // ---- weights -> LDS (once per workgroup)
-    for (int k = tid; k < H * IN; k += kThreads) sm.W1[(k / IN) * LDX + (k % IN)] = params[OFF_W1 + k];
-    for (int k = tid; k < H * H; k += kThreads) sm.W2[(k / H) * LDH + (k % H)] = params[OFF_W2 + k];
+    for (int k = tid; k < H * IN; k += NT) sm.W1[(k / IN) * LDX + (k % IN)] = params[OFF_W1 + k];
+    for (int k = tid; k < H * H; k += NT) sm.W2[(k / H) * LDH + (k % H)] = params[OFF_W2 + k];
     if (tid < H) {
         sm.b1[tid] = params[OFF_B1 + tid];
         sm.b2[tid] = params[OFF_B2 + tid];
@@ -96,115 +100,113 @@ __global__ __launch_bounds__(kThreads) void mlp64_pass(const float* __restrict__
     const float b4 = ACTOR ? params[OFF_B4] : 0.f;
 
     // ---- accumulators that persist over this workgroup's tiles
-    f32x16 accW2 = zero16();             // quadrant (wave>>1, wave&1) of dW2
-    f32x16 accW1 = zero16();             // half (wave&1) of dW1 over the k-steps of parity (wave>>1)
-    float acc_db1[2] = {0.f, 0.f};       // columns l31 and 32+l31 of dH1 rows owned in B2
-    float acc_db2 = 0.f, acc_dw3 = 0.f, acc_dw4 = 0.f;  // column (tid & 63), rows (tid>>6) + 4 i
-    float acc_db3 = 0.f, acc_db4 = 0.f;  // sample-owner threads
-    float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;  // loss, (kl, clip-frac) sums
+    f32x16 accW2 = zero16();   // quadrant (wave & 3) of dW2 over the samples of half (wave >> 2) of each tile
+    f32x16 accW1 = zero16();   // half (wave & 1) of dW1 over the samples of quarter (wave >> 1) of each tile
+    float acc_db1 = 0.f;       // column 32 ct + l31 of the dH1 rows this lane sees in B2
+    float acc_db2 = 0.f, acc_dw3 = 0.f, acc_dw4 = 0.f;  // column (tid & 63), rows (tid >> 6) + 8 i
+    float acc_db3 = 0.f, acc_db4 = 0.f;                 // sample-owner threads (tid & 3) == 0
+    float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;   // loss, kl, clip-frac sums
 
     const long long n_tiles = (M + TM - 1) / TM;
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long m_base = tile * TM;
         __syncthreads();  // previous tile's LDS readers are done
         // ---- X tile -> LDS (rows beyond M are zero)
-        for (int k = tid; k < TM * IN; k += kThreads) {
+        for (int k = tid; k < TM * IN; k += NT) {
             const int m = k / IN, c = k % IN;
             sm.X[m * LDX + c] = (m_base + m < M) ? obs[(m_base + m) * IN + c] : 0.f;
         }
         __syncthreads();
 
-        // ---- F1: H1 = relu(X W1^T + b1), wave = 32-row strip, two 32-col tiles, K = 16
+        // ---- F1: H1 = relu(X W1^T + b1), K = 16
         {
-            f32x16 c0 = zero16(), c1 = zero16();
-            const float* a_ptr = sm.X + (32 * wave + l31) * LDX + lhi;
-            const float* b0_ptr = sm.W1 + l31 * LDX + lhi;
-            const float* b1_ptr = sm.W1 + (32 + l31) * LDX + lhi;
+            f32x16 c = zero16();
+            const float* a_ptr = sm.X + (32 * strip + l31) * LDX + lhi;
+            const float* b_ptr = sm.W1 + (32 * ct + l31) * LDX + lhi;
 #pragma unroll
-            for (int k0 = 0; k0 < IN; k0 += 2) {
-                const float a = a_ptr[k0];
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0_ptr[k0], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1_ptr[k0], c1, 0, 0, 0);
-            }
-            const float bias0 = sm.b1[l31], bias1 = sm.b1[32 + l31];
+            for (int k0 = 0; k0 < IN; k0 += 2) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[k0], b_ptr[k0], c, 0, 0, 0);
+            const float bias = sm.b1[32 * ct + l31];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * wave + c_row(r, lane);
-                sm.H1[row * LDH + l31] = fmaxf(c0[r] + bias0, 0.f);
-                sm.H1[row * LDH + 32 + l31] = fmaxf(c1[r] + bias1, 0.f);
-            }
+            for (int r = 0; r < 16; ++r)
+                sm.H1[(32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31] = fmaxf(c[r] + bias, 0.f);
         }
         __syncthreads();
 
         // ---- F2: H2 = relu(H1 W2^T + b2), K = 64
         {
-            f32x16 c0 = zero16(), c1 = zero16();
-            const float* a_ptr = sm.H1 + (32 * wave + l31) * LDH + lhi;
-            const float* b0_ptr = sm.W2 + l31 * LDH + lhi;
-            const float* b1_ptr = sm.W2 + (32 + l31) * LDH + lhi;
-#pragma unroll 8
-            for (int k0 = 0; k0 < H; k0 += 2) {
-                const float a = a_ptr[k0];
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0_ptr[k0], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1_ptr[k0], c1, 0, 0, 0);
-            }
-            const float bias0 = sm.b2[l31], bias1 = sm.b2[32 + l31];
+            f32x16 c = zero16();
+            const float* a_ptr = sm.H1 + (32 * strip + l31) * LDH + lhi;
+            const float* b_ptr = sm.W2 + (32 * ct + l31) * LDH + lhi;
+#pragma unroll 16
+            for (int k0 = 0; k0 < H; k0 += 2) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[k0], b_ptr[k0], c, 0, 0, 0);
+            const float bias = sm.b2[32 * ct + l31];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * wave + c_row(r, lane);
-                sm.H2[row * LDH + l31] = fmaxf(c0[r] + bias0, 0.f);
-                sm.H2[row * LDH + 32 + l31] = fmaxf(c1[r] + bias1, 0.f);
-            }
+            for (int r = 0; r < 16; ++r)
+                sm.H2[(32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31] = fmaxf(c[r] + bias, 0.f);
         }
         __syncthreads();
 
-        // ---- output units + loss (thread = sample): g3 = dL/dz3, g4 = dL/dz4
-        if (tid < TM) {
-            const long long m = m_base + tid;
-            float g3 = 0.f, g4 = 0.f;
-            if (m < M) {
-                const float* h2 = sm.H2 + tid * LDH;
-                float z3 = b3, z4 = b4;
-#pragma unroll 8
-                for (int k = 0; k < H; ++k) {
-                    const float h = h2[k];
-                    z3 = fmaf(h, sm.w3[k], z3);
-                    if (ACTOR) z4 = fmaf(h, sm.w4[k], z4);
-                }
-                if (ACTOR) {
-                    const float mu0 = 1.0f / (1.0f + expf(-z3));   // torch.sigmoid, net_actor.py:185
-                    const float mu1 = tanhf(z4);                    // net_actor.py:186
-                    const float a0 = act[2 * m], a1 = act[2 * m + 1];
-                    const float d0 = a0 - mu0, d1 = a1 - mu1;
-                    // MultivariateNormal(mean, var*I).log_prob, ppo.py:734-735
-                    const float lp = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);
-                    const float lr = lp - logp_old[m];
-                    const float ratio = expf(lr);                  // ppo.py:316
-                    const float A = adv[m];
-                    const float s1 = ratio * A;                     // ppo.py:319
-                    const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
-                    const float s2 = rc * A;                        // ppo.py:320
-                    st0 += -fminf(s1, s2);                          // ppo.py:342 (mean taken by inv_n at the end)
-                    st2 += (ratio - 1.0f) - lr;                     // approx KL, ppo.py:326
-                    st3 += (fabsf(ratio - 1.0f) > clip) ? 1.f : 0.f;  // clip fraction, ppo.py:335
-                    // d(-min(s1,s2))/d ratio: -A through s1 when s1 <= s2 inside the clip range (tie: both halves), or
-                    // when s1 < s2 outside it; 0 when the clipped (constant) branch is the minimum
-                    const bool inside = (ratio >= 1.0f - clip) && (ratio <= 1.0f + clip);
-                    const float dL_dratio = (inside || s1 < s2) ? -A : 0.f;
-                    const float dL_dlp = dL_dratio * ratio * inv_n;
-                    g3 = dL_dlp * (d0 / var) * (mu0 * (1.0f - mu0));
-                    g4 = dL_dlp * (d1 / var) * (1.0f - mu1 * mu1);
-                } else {
-                    const float V = z3;                             // critic(obs).squeeze(), ppo.py:724
-                    const float e = V - rtg[m];
-                    st1 += e * e;                                   // MSELoss, ppo.py:343
-                    g3 = 2.0f * e * inv_n;
-                }
+        // ---- output units + loss: 4 threads per sample, 16 hidden units each, then a 4-lane butterfly.
+        //      Thread part p reads units 16 p + ((j + 8 (p >> 1)) & 15): conflict-free over each 32-lane group.
+        {
+            const int ms = tid >> 2, p = tid & 3;
+            const long long m = m_base + ms;
+            const float* h2 = sm.H2 + ms * LDH + 16 * p;
+            const int rot = 8 * (p >> 1);
+            float z3 = 0.f, z4 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = (j + rot) & 15;
+                const float h = h2[k];
+                z3 = fmaf(h, sm.w3[16 * p + k], z3);
+                if (ACTOR) z4 = fmaf(h, sm.w4[16 * p + k], z4);
             }
-            sm.g3[tid] = g3;
-            sm.g4[tid] = g4;
-            acc_db3 += g3;
-            acc_db4 += g4;
+            z3 += __shfl_xor(z3, 1, 64);
+            z3 += __shfl_xor(z3, 2, 64);
+            if (ACTOR) {
+                z4 += __shfl_xor(z4, 1, 64);
+                z4 += __shfl_xor(z4, 2, 64);
+            }
+            if (p == 0) {
+                float g3 = 0.f, g4 = 0.f;
+                if (m < M) {
+                    z3 += b3;
+                    z4 += b4;
+                    if (ACTOR) {
+                        const float mu0 = 1.0f / (1.0f + expf(-z3));   // torch.sigmoid, net_actor.py:185
+                        const float mu1 = tanhf(z4);                    // net_actor.py:186
+                        const float a0 = act[2 * m], a1 = act[2 * m + 1];
+                        const float d0 = a0 - mu0, d1 = a1 - mu1;
+                        // MultivariateNormal(mean, var*I).log_prob, ppo.py:734-735
+                        const float lp = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);
+                        const float lr = lp - logp_old[m];
+                        const float ratio = expf(lr);                  // ppo.py:316
+                        const float A = adv[m];
+                        const float s1 = ratio * A;                     // ppo.py:319
+                        const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+                        const float s2 = rc * A;                        // ppo.py:320
+                        st0 += -fminf(s1, s2);                          // ppo.py:342 (mean taken by inv_n at the end)
+                        st2 += (ratio - 1.0f) - lr;                     // approx KL, ppo.py:326
+                        st3 += (fabsf(ratio - 1.0f) > clip) ? 1.f : 0.f;  // clip fraction, ppo.py:335
+                        // d(-min(s1,s2))/d ratio: -A through s1 when s1 <= s2 inside the clip range (tie: both halves),
+                        // or when s1 < s2 outside it; 0 when the clipped (constant) branch is the minimum
+                        const bool inside = (ratio >= 1.0f - clip) && (ratio <= 1.0f + clip);
+                        const float dL_dratio = (inside || s1 < s2) ? -A : 0.f;
+                        const float dL_dlp = dL_dratio * ratio * inv_n;
+                        g3 = dL_dlp * (d0 / var) * (mu0 * (1.0f - mu0));
+                        g4 = dL_dlp * (d1 / var) * (1.0f - mu1 * mu1);
+                    } else {
+                        const float V = z3;                             // critic(obs).squeeze(), ppo.py:724
+                        const float e = V - rtg[m];
+                        st1 += e * e;                                   // MSELoss, ppo.py:343
+                        g3 = 2.0f * e * inv_n;
+                    }
+                }
+                sm.g3[ms] = g3;
+                sm.g4[ms] = g4;
+                acc_db3 += g3;
+                acc_db4 += g4;
+            }
         }
         __syncthreads();
 
@@ -213,8 +215,8 @@ __global__ __launch_bounds__(kThreads) void mlp64_pass(const float* __restrict__
             const int k = tid & 63;
             const float w3k = sm.w3[k], w4k = sm.w4[k];
 #pragma unroll 4
-            for (int i = 0; i < TM / 4; ++i) {
-                const int m = (tid >> 6) + 4 * i;
+            for (int i = 0; i < TM / 8; ++i) {
+                const int m = (tid >> 6) + 8 * i;
                 const float h = sm.H2[m * LDH + k];
                 const float g3 = sm.g3[m], g4 = sm.g4[m];
                 const float d = (h > 0.f) ? fmaf(g3, w3k, g4 * w4k) : 0.f;
@@ -228,46 +230,40 @@ __global__ __launch_bounds__(kThreads) void mlp64_pass(const float* __restrict__
 
         // ---- B2: dH1 = (dH2 W2) . [H1 > 0] -> stored over H2 ; db1 partial sums
         {
-            f32x16 c0 = zero16(), c1 = zero16();
-            const float* a_ptr = sm.dH2 + (32 * wave + l31) * LDH + lhi;
-            const float* b0_ptr = sm.W2 + lhi * LDH + l31;
-            const float* b1_ptr = sm.W2 + lhi * LDH + 32 + l31;
-#pragma unroll 8
-            for (int n0 = 0; n0 < H; n0 += 2) {
-                const float a = a_ptr[n0];
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0_ptr[n0 * LDH], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1_ptr[n0 * LDH], c1, 0, 0, 0);
-            }
-            // all waves have finished reading H2 (dH2 pass + barrier); dH1 overwrites this wave's own rows only
+            f32x16 c = zero16();
+            const float* a_ptr = sm.dH2 + (32 * strip + l31) * LDH + lhi;
+            const float* b_ptr = sm.W2 + lhi * LDH + 32 * ct + l31;
+#pragma unroll 16
+            for (int n0 = 0; n0 < H; n0 += 2) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[n0], b_ptr[n0 * LDH], c, 0, 0, 0);
+            // every wave finished reading H2 before the barrier above; each wave overwrites only its own tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * wave + c_row(r, lane);
-                const float d0 = (sm.H1[row * LDH + l31] > 0.f) ? c0[r] : 0.f;
-                const float d1 = (sm.H1[row * LDH + 32 + l31] > 0.f) ? c1[r] : 0.f;
-                sm.H2[row * LDH + l31] = d0;
-                sm.H2[row * LDH + 32 + l31] = d1;
-                acc_db1[0] += d0;
-                acc_db1[1] += d1;
+                const int idx = (32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31;
+                const float d = (sm.H1[idx] > 0.f) ? c[r] : 0.f;
+                sm.H2[idx] = d;
+                acc_db1 += d;
             }
         }
         __syncthreads();
 
-        // ---- G2: dW2[n][k] += sum_m dH2[m][n] H1[m][k], quadrant (nt, kt) = (wave>>1, wave&1), K = 128 samples
+        // ---- G2: dW2[n][k] += sum_m dH2[m][n] H1[m][k]; quadrant (nt, kt) from wave & 3, samples 64 (wave>>2) .. +64
         {
-            const float* a_ptr = sm.dH2 + lhi * LDH + 32 * (wave >> 1) + l31;
-            const float* b_ptr = sm.H1 + lhi * LDH + 32 * (wave & 1) + l31;
-#pragma unroll 8
-            for (int m0 = 0; m0 < TM; m0 += 2)
+            const int q = wave & 3, mh = 64 * (wave >> 2);
+            const float* a_ptr = sm.dH2 + (mh + lhi) * LDH + 32 * (q >> 1) + l31;
+            const float* b_ptr = sm.H1 + (mh + lhi) * LDH + 32 * (q & 1) + l31;
+#pragma unroll 16
+            for (int m0 = 0; m0 < 64; m0 += 2)
                 accW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[m0 * LDH], b_ptr[m0 * LDH], accW2, 0, 0, 0);
         }
-        // ---- G1: dW1[n][k] += sum_m dH1[m][n] X[m][k] (k < 16; columns 16..31 of the 32-wide tile are zero padding)
+        // ---- G1: dW1[n][k] += sum_m dH1[m][n] X[m][k] (k < 16; columns 16..31 of the 32-wide tile are zero padding);
+        //      half nt = wave & 1, samples 32 (wave>>1) .. +32
         {
-            const float* a_ptr = sm.H2 + lhi * LDH + 32 * (wave & 1) + l31;
-            const float* b_ptr = sm.X + lhi * LDX + (l31 & 15);
+            const int mq = 32 * (wave >> 1);
+            const float* a_ptr = sm.H2 + (mq + lhi) * LDH + 32 * (wave & 1) + l31;
+            const float* b_ptr = sm.X + (mq + lhi) * LDX + (l31 & 15);
             const bool live = l31 < IN;
-#pragma unroll 8
-            for (int s = 0; s < TM / 4; ++s) {
-                const int m0 = 2 * (2 * s + (wave >> 1));
+#pragma unroll 16
+            for (int m0 = 0; m0 < 32; m0 += 2) {
                 const float b = live ? b_ptr[m0 * LDX] : 0.f;
                 accW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[m0 * LDH], b, accW1, 0, 0, 0);
             }
@@ -277,20 +273,20 @@ __global__ __launch_bounds__(kThreads) void mlp64_pass(const float* __restrict__
     // ---- workgroup reduction of the partial gradient in LDS, then one coalesced row of `partial`
     __syncthreads();
     float* red = sm.H1;  // P <= 5378 floats, H1 holds 8320
-    for (int k = tid; k < P + 4; k += kThreads) red[k] = 0.f;
+    for (int k = tid; k < P + 4; k += NT) red[k] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = c_row(r, lane);
-        atomicAdd(&red[OFF_W2 + (32 * (wave >> 1) + row) * H + 32 * (wave & 1) + l31], accW2[r]);
+        const int q = wave & 3;
+        atomicAdd(&red[OFF_W2 + (32 * (q >> 1) + row) * H + 32 * (q & 1) + l31], accW2[r]);
         if (l31 < IN) atomicAdd(&red[OFF_W1 + (32 * (wave & 1) + row) * IN + l31], accW1[r]);
     }
-    atomicAdd(&red[OFF_B1 + l31], acc_db1[0]);
-    atomicAdd(&red[OFF_B1 + 32 + l31], acc_db1[1]);
+    atomicAdd(&red[OFF_B1 + 32 * ct + l31], acc_db1);
     atomicAdd(&red[OFF_B2 + (tid & 63)], acc_db2);
     atomicAdd(&red[OFF_W3 + (tid & 63)], acc_dw3);
     if (ACTOR) atomicAdd(&red[OFF_W4 + (tid & 63)], acc_dw4);
-    if (tid < TM) {
+    if ((tid & 3) == 0) {
         atomicAdd(&red[OFF_B3], acc_db3);
         if (ACTOR) atomicAdd(&red[OFF_B4], acc_db4);
         atomicAdd(&red[P + 0], ACTOR ? st0 : st1);
@@ -299,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void mlp64_pass(const float* __restrict__
     }
     __syncthreads();
     float* out = partial + (size_t)blockIdx.x * P;
-    for (int k = tid; k < P; k += kThreads) out[k] = red[k];
+    for (int k = tid; k < P; k += NT) out[k] = red[k];
     if (tid < 3) stats_partial[blockIdx.x * 4 + tid] = red[P + tid];
 }
 
@@ -316,6 +312,118 @@ __global__ void reduce_partials(const float* __restrict__ partial, const float* 
         float s = 0.f;
         for (int b = 0; b < n_blocks; ++b) s += stats_partial[b * 4 + threadIdx.x];
         stats[stats_off + threadIdx.x] = s * inv_n;
+    }
+}
+
+// ---------------------------------------------------------------- rollout-time policy step (PPO.get_action, ppo.py:673-706)
+// mean = actor(obs) (same F1/F2 MFMA tiles as above), action = clamp(mean + sqrt(var) * eps), log-prob of the CLAMPED
+// action under N(mean, var I).  eps comes from `noise` ([n,2], e.g. torch.randn) or, when noise == nullptr, from
+// Philox4x32-10 keyed by (seed, global env id, step) + Box-Muller, so a rollout step is one launch.
+__device__ __forceinline__ void philox10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                         uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(kThreads) void mlp64_act(const float* __restrict__ params, const float* __restrict__ obs,
+                                                      const float* __restrict__ noise, long long n,
+                                                      const float* __restrict__ var_ptr, uint64_t seed,
+                                                      uint64_t env_id_base, const uint32_t* __restrict__ step_base,
+                                                      uint32_t step_offset,
+                                                      float* __restrict__ act, float* __restrict__ logp,
+                                                      float* __restrict__ mean_out) {
+    __shared__ float X[TM * LDX], H1[TM * LDH], H2[TM * LDH], W1[H * LDX], W2[H * LDH], b1s[H], b2s[H], w3s[H], w4s[H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const long long m_base = (long long)blockIdx.x * TM;
+    const float var = *var_ptr;
+    const uint32_t step = (step_base ? *step_base : 0u) + step_offset;
+    for (int k = tid; k < H * IN; k += kThreads) W1[(k / IN) * LDX + (k % IN)] = params[OFF_W1 + k];
+    for (int k = tid; k < H * H; k += kThreads) W2[(k / H) * LDH + (k % H)] = params[OFF_W2 + k];
+    if (tid < H) {
+        b1s[tid] = params[OFF_B1 + tid]; b2s[tid] = params[OFF_B2 + tid];
+        w3s[tid] = params[OFF_W3 + tid]; w4s[tid] = params[OFF_W4 + tid];
+    }
+    for (int k = tid; k < TM * IN; k += kThreads) {
+        const int m = k / IN, c = k % IN;
+        X[m * LDX + c] = (m_base + m < n) ? obs[(m_base + m) * IN + c] : 0.f;
+    }
+    __syncthreads();
+    {
+        f32x16 c0 = zero16(), c1 = zero16();
+        const float* a_ptr = X + (32 * wave + l31) * LDX + lhi;
+#pragma unroll
+        for (int k0 = 0; k0 < IN; k0 += 2) {
+            const float a = a_ptr[k0];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, W1[l31 * LDX + lhi + k0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, W1[(32 + l31) * LDX + lhi + k0], c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * wave + c_row(r, lane);
+            H1[row * LDH + l31] = fmaxf(c0[r] + b1s[l31], 0.f);
+            H1[row * LDH + 32 + l31] = fmaxf(c1[r] + b1s[32 + l31], 0.f);
+        }
+    }
+    __syncthreads();
+    {
+        f32x16 c0 = zero16(), c1 = zero16();
+        const float* a_ptr = H1 + (32 * wave + l31) * LDH + lhi;
+#pragma unroll 8
+        for (int k0 = 0; k0 < H; k0 += 2) {
+            const float a = a_ptr[k0];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, W2[l31 * LDH + lhi + k0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, W2[(32 + l31) * LDH + lhi + k0], c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * wave + c_row(r, lane);
+            H2[row * LDH + l31] = fmaxf(c0[r] + b2s[l31], 0.f);
+            H2[row * LDH + 32 + l31] = fmaxf(c1[r] + b2s[32 + l31], 0.f);
+        }
+    }
+    __syncthreads();
+    if (tid < TM && m_base + tid < n) {
+        const long long m = m_base + tid;
+        float z3 = params[OFF_B3], z4 = params[OFF_B4];
+#pragma unroll 8
+        for (int k = 0; k < H; ++k) {
+            const float h = H2[tid * LDH + k];
+            z3 = fmaf(h, w3s[k], z3);
+            z4 = fmaf(h, w4s[k], z4);
+        }
+        const float mu0 = 1.0f / (1.0f + expf(-z3)), mu1 = tanhf(z4);
+        float e0, e1;
+        if (noise) {
+            e0 = noise[2 * m];
+            e1 = noise[2 * m + 1];
+        } else {
+            const uint64_t gid = env_id_base + (uint64_t)m;
+            uint32_t r[4];
+            philox10((uint32_t)gid, (uint32_t)(gid >> 32), step, 0x61637473u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            const float u1 = ((float)(r[0] >> 8) + 1.0f) * 0x1.0p-24f;  // (0, 1]
+            const float u2 = (float)(r[1] >> 8) * 0x1.0p-24f;           // [0, 1)
+            const float rad = sqrtf(-2.0f * logf(u1));
+            e0 = rad * cosf(6.283185307179586f * u2);
+            e1 = rad * sinf(6.283185307179586f * u2);
+        }
+        const float sd = sqrtf(var);
+        const float a0 = fminf(fmaxf(fmaf(sd, e0, mu0), 0.f), 1.f);    // ppo.py:698-703
+        const float a1 = fminf(fmaxf(fmaf(sd, e1, mu1), -1.f), 1.f);
+        const float d0 = a0 - mu0, d1 = a1 - mu1;
+        act[2 * m] = a0;
+        act[2 * m + 1] = a1;
+        logp[m] = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);  // ppo.py:704
+        if (mean_out) {
+            mean_out[2 * m] = mu0;
+            mean_out[2 * m + 1] = mu1;
+        }
     }
 }
 
@@ -346,17 +454,35 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
     float* partial = reinterpret_cast<float*>(workspace_dev);
     float* stats_partial = partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * NAVPPO_MLP64_ACTOR_PARAMS;
     const float inv_n = 1.0f / (float)n_samples;
-    hipLaunchKernelGGL((mlp64_pass<true>), dim3(blocks), dim3(kThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
+    hipLaunchKernelGGL((mlp64_pass<true>), dim3(blocks), dim3(kPassThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
                        rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial);
     hipLaunchKernelGGL(reduce_partials, dim3((P_ACTOR + 255) / 256), dim3(256), 0, st, partial, stats_partial, blocks, P_ACTOR,
                        inv_n, grad_dev, stats_dev, 0);
-    hipLaunchKernelGGL((mlp64_pass<false>), dim3(blocks), dim3(kThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
+    hipLaunchKernelGGL((mlp64_pass<false>), dim3(blocks), dim3(kPassThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
                        logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial);
     hipLaunchKernelGGL(reduce_partials, dim3((P_CRITIC + 255) / 256), dim3(256), 0, st, partial, stats_partial, blocks, P_CRITIC,
                        inv_n, grad_dev + P_ACTOR, stats_dev, 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_loss_grad: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+int navppo_mlp64_act(const float* actor_params_dev, const float* obs_dev, const float* noise_dev, int64_t n_envs,
+                     const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
+                     uint32_t step_offset, float* act_dev, float* logp_dev, float* mean_dev, void* stream) {
+    if (!actor_params_dev || !obs_dev || !act_dev || !logp_dev || n_envs < 1 || !var_dev) {
+        g_err = "navppo_mlp64_act: bad argument";
+        return -1;
+    }
+    const int blocks = (int)((n_envs + TM - 1) / TM);
+    hipLaunchKernelGGL(mlp64_act, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, actor_params_dev, obs_dev, noise_dev,
+                       (long long)n_envs, var_dev, seed, env_id_base, step_base_dev, step_offset, act_dev, logp_dev, mean_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_err = std::string("navppo_mlp64_act: ") + hipGetErrorString(e);
         return -2;
     }
     return 0;

@@ -282,14 +282,34 @@ class PPOTrainer:
         self._lo = torch.tensor([0.0, -1.0], device=dev)
         self._hi = torch.tensor([1.0, 1.0], device=dev)
         self._graph = None
+        self._step_base = torch.zeros((), dtype=torch.int32, device=dev)  # rollout steps taken so far (noise counter)
+        self._act_seed = (cfg.seed * 0x9E3779B97F4A7C15 + 0xAC7) & 0xFFFFFFFFFFFFFFFF
+        self._env_id_base = int(env.sim.cfg.env_id_base)
         self.t_so_far = 0     # completed-episode steps, as the reference counts (ppo.py:258)
         self.env_steps = 0    # all simulated steps
         self.i_so_far = 0
         self.episode_starts = 0
         self.logger = {}
 
+    def _fused_act(self, t, noise=None):
+        """PPO.get_action for all envs in ONE launch (csrc/ppo_mlp64.hip: mlp64_act)."""
+        import ctypes as C
+        from ._native import lib
+        ptr = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        L = lib()
+        rc = L.navppo_mlp64_act(ptr(self.updater.fp.flat), ptr(self.obs_buf[t]), ptr(noise), self.env.N, ptr(self.var),
+                                self._act_seed, self._env_id_base, ptr(self._step_base), t, ptr(self.act_buf[t]),
+                                ptr(self.logp_buf[t]), None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"navppo_mlp64_act failed: {L.navppo_last_error().decode()}")
+
     # ---- ppo.py:673-706 + env.step, for rollout step t (all envs)
     def _rollout_step(self, t):
+        if self.updater.fused_mlp64:
+            self._fused_act(t)
+            self.env.sim.step(self.act_buf[t], self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.arrive_buf[t],
+                              self.ended_buf[t], self.epret_buf[t], self.eplen_buf[t])
+            return
         obs = self.obs_buf[t]
         mean = self.actor(obs)
         std = torch.sqrt(self.var)
@@ -303,6 +323,7 @@ class PPOTrainer:
     def _rollout_body(self):
         for t in range(self.cfg.rollout_len):
             self._rollout_step(t)
+        self._step_base += self.cfg.rollout_len  # inside the captured graph: every replay draws fresh noise
 
     @torch.no_grad()
     def rollout(self):

@@ -130,3 +130,53 @@ def test_trainer_iterations_run_and_learn_signal(policy):
     np.testing.assert_array_equal(tr.rtg_buf.cpu().numpy(),
                                   O.compute_rtgs_tn(tr.rew_buf.cpu().numpy(), tr.ended_buf.cpu().numpy(), cfg.gamma))
     env.close()
+
+
+def test_fused_act_matches_pytorch_policy_step():
+    """mlp64_act with explicit noise == PyTorch: mean = actor(obs), clamp(mean + sqrt(var) eps), log-prob of the clamped
+    action (ppo.py:696-704); and the in-kernel Philox/Box-Muller noise is standard normal and shard-invariant."""
+    import ctypes as C
+    from navbot_ppo_amd._native import lib
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    a, c = nets.make_policy("mlp64x2")
+    a.to(dev), c.to(dev)
+    with torch.no_grad():
+        for p in a.parameters():
+            p.mul_(2.0)
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(policy="mlp64x2"), None, dev)
+    n = 128 * 5 + 77
+    obs = torch.rand((n, 16), device=dev)
+    eps = torch.randn((n, 2), device=dev)
+    var = torch.tensor(0.8, device=dev)
+    act = torch.empty((n, 2), device=dev)
+    lp = torch.empty(n, device=dev)
+    mean = torch.empty((n, 2), device=dev)
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    L = lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.navppo_mlp64_act(ptr(up.fp.flat), ptr(obs), ptr(eps), n, ptr(var), 7, 0, None, 0, ptr(act), ptr(lp), ptr(mean), st) == 0
+    with torch.no_grad():
+        m_ref = a(obs)
+        raw = m_ref + torch.sqrt(var) * eps
+        a_ref = torch.stack([raw[:, 0].clamp(0, 1), raw[:, 1].clamp(-1, 1)], 1)
+        lp_ref = ppo.gaussian_log_prob(m_ref, a_ref, var)
+    np.testing.assert_allclose(mean.cpu().numpy(), m_ref.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(act.cpu().numpy(), a_ref.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+    # in-kernel noise: recover eps = (act - mean)/sqrt(var) where unclamped; moments of N(0,1); depends on (seed, id, step) only
+    N = 1 << 16
+    obs = torch.rand((N, 16), device=dev)
+    act, lp, mean = torch.empty((N, 2), device=dev), torch.empty(N, device=dev), torch.empty((N, 2), device=dev)
+    big = torch.tensor(1e-4, device=dev)  # tiny variance: nothing clamps except at the sigmoid/tanh edges
+    sb = torch.tensor(5, dtype=torch.int32, device=dev)
+    assert L.navppo_mlp64_act(ptr(up.fp.flat), ptr(obs), None, N, ptr(big), 9, 0, ptr(sb), 2, ptr(act), ptr(lp), ptr(mean), st) == 0
+    e = ((act - mean) / 1e-2).cpu().numpy()
+    ok = (np.abs(e) < 6).all(axis=1) & (act[:, 0].cpu().numpy() > 0) & (act[:, 0].cpu().numpy() < 1) & (np.abs(act[:, 1].cpu().numpy()) < 1)
+    e = e[ok]
+    assert ok.mean() > 0.9 and abs(e.mean()) < 0.02 and abs(e.std() - 1) < 0.02 and abs(np.corrcoef(e[:, 0], e[:, 1])[0, 1]) < 0.02
+    act2 = torch.empty((N // 2, 2), device=dev)
+    sb7 = torch.tensor(7, dtype=torch.int32, device=dev)
+    assert L.navppo_mlp64_act(ptr(up.fp.flat), ptr(obs[N // 2:].contiguous()), None, N // 2, ptr(big), 9, N // 2, ptr(sb7), 0,
+                              ptr(act2), ptr(lp), None, st) == 0
+    assert torch.equal(act2, act[N // 2:])  # same (seed, global env id, step) -> same draw on another shard
