@@ -23,7 +23,7 @@ extern "C" {
 
 #define NAVPPO_MLP64_ACTOR_PARAMS 5378  /* 16*64+64 + 64*64+64 + 64+1 + 64+1 */
 #define NAVPPO_MLP64_CRITIC_PARAMS 5313 /* 16*64+64 + 64*64+64 + 64+1 */
-#define NAVPPO_MLP64_MAX_BLOCKS 256     /* persistent workgroups: one per CU */
+#define NAVPPO_MLP64_MAX_BLOCKS 512     /* persistent workgroups: two per CU */
 
 const char* navppo_last_error(void);
 

@@ -51,15 +51,14 @@ constexpr int P_ACTOR = OFF_B4 + 1;   // 5378
 constexpr int P_CRITIC = OFF_B3 + 1;  // 5313
 static_assert(P_ACTOR == NAVPPO_MLP64_ACTOR_PARAMS && P_CRITIC == NAVPPO_MLP64_CRITIC_PARAMS, "layout");
 
-struct Smem {
-    float X[TM * LDX];
-    float H1[TM * LDH];
-    float H2[TM * LDH];   // H2, later dH1
-    float dH2[TM * LDH];
+template <int TM_>
+struct SmemT {
+    float X[TM_ * LDX];
+    float HB[3 * TM_ * LDH];  // H1 | H2 (later dH1) | dH2 ; at the very end: the gradient reduction buffer (5382 floats)
     float W1[H * LDX];
     float W2[H * LDH];
     float b1[H], b2[H], w3[H], w4[H];
-    float g3[TM], g4[TM];
+    float g3[TM_], g4[TM_];
 };
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -72,17 +71,27 @@ __device__ __forceinline__ f32x16 zero16() {
 // C/D element (row, col) of accumulator register r for lane l (32x32 shapes; cdna_hip_programming.md section 3)
 __device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-constexpr int kPassThreads = 512;  // 8 waves = 2 per SIMD: one wave's MFMA overlaps the other's LDS / VALU work
+// PT = samples per tile, 4 threads per sample: PT = 128 -> 8 waves, 132 KB LDS, 1 workgroup per CU;
+// PT = 64 -> 4 waves, 76 KB LDS, 2 independent workgroups per CU (their MFMA / VALU / barrier phases interleave).
+constexpr int kPassTile = 64;
+constexpr int kPassThreads = 4 * kPassTile;
 
-template <bool ACTOR>
-__global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restrict__ params, const float* __restrict__ obs,
+template <bool ACTOR, int PT>
+__global__ __launch_bounds__(4 * PT) void mlp64_pass(const float* __restrict__ params, const float* __restrict__ obs,
                                                            const float* __restrict__ act, const float* __restrict__ logp_old,
                                                            const float* __restrict__ rtg, const float* __restrict__ adv,
                                                            long long M, float var, float clip, float inv_n,
                                                            float* __restrict__ partial, float* __restrict__ stats_partial) {
-    __shared__ Smem sm;
     constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
-    constexpr int NT = kPassThreads;
+    constexpr int NT = 4 * PT;       // threads
+    constexpr int NW = NT / 64;      // waves: PT/32 row strips x 2 column tiles
+    constexpr int TM = PT;           // (shadows the namespace constant inside this kernel)
+    static_assert(PT == 64 || PT == 128, "tile");
+    __shared__ SmemT<PT> sm;
+    static_assert(3 * PT * LDH >= P_ACTOR + 4, "reduction buffer");
+    float* const sH1 = sm.HB;
+    float* const sH2 = sm.HB + PT * LDH;
+    float* const sdH2 = sm.HB + 2 * PT * LDH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int strip = wave >> 1, ct = wave & 1;  // F1/F2/B2: 32-row strip and 32-column tile owned by this wave
@@ -128,21 +137,21 @@ __global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restri
             const float bias = sm.b1[32 * ct + l31];
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                sm.H1[(32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31] = fmaxf(c[r] + bias, 0.f);
+                sH1[(32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31] = fmaxf(c[r] + bias, 0.f);
         }
         __syncthreads();
 
         // ---- F2: H2 = relu(H1 W2^T + b2), K = 64
         {
             f32x16 c = zero16();
-            const float* a_ptr = sm.H1 + (32 * strip + l31) * LDH + lhi;
+            const float* a_ptr = sH1 + (32 * strip + l31) * LDH + lhi;
             const float* b_ptr = sm.W2 + (32 * ct + l31) * LDH + lhi;
 #pragma unroll 16
             for (int k0 = 0; k0 < H; k0 += 2) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[k0], b_ptr[k0], c, 0, 0, 0);
             const float bias = sm.b2[32 * ct + l31];
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                sm.H2[(32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31] = fmaxf(c[r] + bias, 0.f);
+                sH2[(32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31] = fmaxf(c[r] + bias, 0.f);
         }
         __syncthreads();
 
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restri
         {
             const int ms = tid >> 2, p = tid & 3;
             const long long m = m_base + ms;
-            const float* h2 = sm.H2 + ms * LDH + 16 * p;
+            const float* h2 = sH2 + ms * LDH + 16 * p;
             const int rot = 8 * (p >> 1);
             float z3 = 0.f, z4 = 0.f;
 #pragma unroll
@@ -215,12 +224,12 @@ __global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restri
             const int k = tid & 63;
             const float w3k = sm.w3[k], w4k = sm.w4[k];
 #pragma unroll 4
-            for (int i = 0; i < TM / 8; ++i) {
-                const int m = (tid >> 6) + 8 * i;
-                const float h = sm.H2[m * LDH + k];
+            for (int i = 0; i < TM / NW; ++i) {
+                const int m = (tid >> 6) + NW * i;
+                const float h = sH2[m * LDH + k];
                 const float g3 = sm.g3[m], g4 = sm.g4[m];
                 const float d = (h > 0.f) ? fmaf(g3, w3k, g4 * w4k) : 0.f;
-                sm.dH2[m * LDH + k] = d;
+                sdH2[m * LDH + k] = d;
                 acc_db2 += d;
                 acc_dw3 = fmaf(g3, h, acc_dw3);
                 acc_dw4 = fmaf(g4, h, acc_dw4);
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restri
         // ---- B2: dH1 = (dH2 W2) . [H1 > 0] -> stored over H2 ; db1 partial sums
         {
             f32x16 c = zero16();
-            const float* a_ptr = sm.dH2 + (32 * strip + l31) * LDH + lhi;
+            const float* a_ptr = sdH2 + (32 * strip + l31) * LDH + lhi;
             const float* b_ptr = sm.W2 + lhi * LDH + 32 * ct + l31;
 #pragma unroll 16
             for (int n0 = 0; n0 < H; n0 += 2) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[n0], b_ptr[n0 * LDH], c, 0, 0, 0);
@@ -239,8 +248,8 @@ __global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int idx = (32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31;
-                const float d = (sm.H1[idx] > 0.f) ? c[r] : 0.f;
-                sm.H2[idx] = d;
+                const float d = (sH1[idx] > 0.f) ? c[r] : 0.f;
+                sH2[idx] = d;
                 acc_db1 += d;
             }
         }
@@ -248,9 +257,9 @@ __global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restri
 
         // ---- G2: dW2[n][k] += sum_m dH2[m][n] H1[m][k]; quadrant (nt, kt) from wave & 3, samples 64 (wave>>2) .. +64
         {
-            const int q = wave & 3, mh = 64 * (wave >> 2);
-            const float* a_ptr = sm.dH2 + (mh + lhi) * LDH + 32 * (q >> 1) + l31;
-            const float* b_ptr = sm.H1 + (mh + lhi) * LDH + 32 * (q & 1) + l31;
+            const int q = wave & 3, mh = 64 * (wave >> 2);  // NW/4 sample groups of 64
+            const float* a_ptr = sdH2 + (mh + lhi) * LDH + 32 * (q >> 1) + l31;
+            const float* b_ptr = sH1 + (mh + lhi) * LDH + 32 * (q & 1) + l31;
 #pragma unroll 16
             for (int m0 = 0; m0 < 64; m0 += 2)
                 accW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[m0 * LDH], b_ptr[m0 * LDH], accW2, 0, 0, 0);
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restri
         //      half nt = wave & 1, samples 32 (wave>>1) .. +32
         {
             const int mq = 32 * (wave >> 1);
-            const float* a_ptr = sm.H2 + (mq + lhi) * LDH + 32 * (wave & 1) + l31;
+            const float* a_ptr = sH2 + (mq + lhi) * LDH + 32 * (wave & 1) + l31;
             const float* b_ptr = sm.X + (mq + lhi) * LDX + (l31 & 15);
             const bool live = l31 < IN;
 #pragma unroll 16
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restri
 
     // ---- workgroup reduction of the partial gradient in LDS, then one coalesced row of `partial`
     __syncthreads();
-    float* red = sm.H1;  // P <= 5378 floats, H1 holds 8320
+    float* red = sm.HB;
     for (int k = tid; k < P + 4; k += NT) red[k] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -299,15 +308,26 @@ __global__ __launch_bounds__(kPassThreads) void mlp64_pass(const float* __restri
     if (tid < 3) stats_partial[blockIdx.x * 4 + tid] = red[P + tid];
 }
 
-// grad[p] = sum over workgroups ; stats = sums * inv_n
-__global__ void reduce_partials(const float* __restrict__ partial, const float* __restrict__ stats_partial, int n_blocks,
-                                int P, float inv_n, float* __restrict__ grad, float* __restrict__ stats, int stats_off) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+// grad[p] = sum over workgroups ; stats = sums * inv_n.  Block = 64 parameters x 4 row groups; rows are read 256 B per wave.
+__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ partial, const float* __restrict__ stats_partial,
+                                                       int n_blocks, int P, float inv_n, float* __restrict__ grad,
+                                                       float* __restrict__ stats, int stats_off) {
+    __shared__ float part[4][64];
+    const int p = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (p < P) {
-        float s = 0.f;
-        for (int b = 0; b < n_blocks; ++b) s += partial[(size_t)b * P + p];
-        grad[p] = s;
+        int b = g;
+        for (; b + 12 < n_blocks; b += 16) {
+            s0 += partial[(size_t)b * P + p];
+            s1 += partial[(size_t)(b + 4) * P + p];
+            s2 += partial[(size_t)(b + 8) * P + p];
+            s3 += partial[(size_t)(b + 12) * P + p];
+        }
+        for (; b < n_blocks; b += 4) s0 += partial[(size_t)b * P + p];
     }
+    part[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && p < P) grad[p] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
     if (blockIdx.x == 0 && threadIdx.x < 3) {
         float s = 0.f;
         for (int b = 0; b < n_blocks; ++b) s += stats_partial[b * 4 + threadIdx.x];
@@ -449,18 +469,18 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
         return -1;
     }
     hipStream_t st = (hipStream_t)stream;
-    const long long tiles = (n_samples + TM - 1) / TM;
+    const long long tiles = (n_samples + kPassTile - 1) / kPassTile;
     const int blocks = (int)(tiles < NAVPPO_MLP64_MAX_BLOCKS ? tiles : NAVPPO_MLP64_MAX_BLOCKS);
     float* partial = reinterpret_cast<float*>(workspace_dev);
     float* stats_partial = partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * NAVPPO_MLP64_ACTOR_PARAMS;
     const float inv_n = 1.0f / (float)n_samples;
-    hipLaunchKernelGGL((mlp64_pass<true>), dim3(blocks), dim3(kPassThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
+    hipLaunchKernelGGL((mlp64_pass<true, kPassTile>), dim3(blocks), dim3(kPassThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
                        rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial);
-    hipLaunchKernelGGL(reduce_partials, dim3((P_ACTOR + 255) / 256), dim3(256), 0, st, partial, stats_partial, blocks, P_ACTOR,
+    hipLaunchKernelGGL(reduce_partials, dim3((P_ACTOR + 63) / 64), dim3(256), 0, st, partial, stats_partial, blocks, P_ACTOR,
                        inv_n, grad_dev, stats_dev, 0);
-    hipLaunchKernelGGL((mlp64_pass<false>), dim3(blocks), dim3(kPassThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
+    hipLaunchKernelGGL((mlp64_pass<false, kPassTile>), dim3(blocks), dim3(kPassThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
                        logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial);
-    hipLaunchKernelGGL(reduce_partials, dim3((P_CRITIC + 255) / 256), dim3(256), 0, st, partial, stats_partial, blocks, P_CRITIC,
+    hipLaunchKernelGGL(reduce_partials, dim3((P_CRITIC + 63) / 64), dim3(256), 0, st, partial, stats_partial, blocks, P_CRITIC,
                        inv_n, grad_dev + P_ACTOR, stats_dev, 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
