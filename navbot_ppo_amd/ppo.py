@@ -48,6 +48,7 @@ class PPOConfig:
     use_graph: bool = True                 # capture the T-step rollout in one hipGraph
     fused_update: bool = True              # mlp64x2 on GPU: fused HIP loss+gradient kernel (csrc/ppo_mlp64.hip)
     output_dir: str = ""                   # "" = no checkpoints / logs
+    episode_csv_rows: int = 2000           # per-iteration cap on rows appended to <method>_train_episodes.csv (0 = off)
     method_name: str = "baseline"
 
 
@@ -401,9 +402,63 @@ class PPOTrainer:
                            rollout_time=t1 - t0, update_time=t2 - t1, iter_time=t2 - t0,
                            steps_per_sec=T * N * world / (t2 - t0),                      # ppo.py:855
                            rollout_steps_per_sec=T * N * world / (t1 - t0), var=float(self.var))
-        if cfg.output_dir and self.i_so_far % cfg.save_freq == 0 and (self.ctx is None or self.ctx.rank == 0):
-            self.save_checkpoint()
+        if cfg.output_dir and (self.ctx is None or self.ctx.rank == 0):
+            if self.i_so_far % cfg.save_freq == 0:
+                self.save_checkpoint()
+            import json
+            os.makedirs(self.log_dir(), exist_ok=True)
+            with open(os.path.join(self.log_dir(), "scalars.jsonl"), "a") as f:
+                f.write(json.dumps(dict(self.tb_scalars(), iteration=self.i_so_far, t_so_far=self.t_so_far)) + "\n")
+            if cfg.episode_csv_rows:
+                self.write_episode_csv(cfg.episode_csv_rows)
         return self.logger
+
+    # ---- logging surface of the reference: per-episode CSV (ppo.py:159-163,739-746) and the TensorBoard scalar names
+    #      (ppo.py:892-939) written as one JSON object per iteration (tensorboardX is not a dependency here)
+    EPISODE_CSV_HEADER = ["episode", "timestep", "success", "collision", "timeout", "length", "return", "path_length", "time"]
+
+    def log_dir(self):
+        return os.path.join(self.cfg.output_dir, self.cfg.method_name, "logs")
+
+    def write_episode_csv(self, max_rows=None):
+        """Appends the episodes finished in the last rollout, in (step, env) order.  path_length is not tracked by the
+        batched simulator (0.0); time is the iteration's wall time share."""
+        import csv
+        os.makedirs(self.log_dir(), exist_ok=True)
+        path = os.path.join(self.log_dir(), f"{self.cfg.method_name}_train_episodes.csv")
+        new = not os.path.exists(path)
+        ended = self.ended_buf.bool()
+        t_idx, n_idx = torch.nonzero(ended, as_tuple=True)
+        if max_rows is not None:
+            t_idx, n_idx = t_idx[:max_rows], n_idx[:max_rows]
+        d = self.done_buf[t_idx, n_idx].cpu().numpy()
+        a = self.arrive_buf[t_idx, n_idx].cpu().numpy()
+        ln = self.eplen_buf[t_idx, n_idx].cpu().numpy()
+        rt = self.epret_buf[t_idx, n_idx].cpu().numpy()
+        tt = t_idx.cpu().numpy()
+        base = getattr(self, "_episode_count", 0)
+        with open(path, "a", newline="") as f:
+            w = csv.writer(f)
+            if new:
+                w.writerow(self.EPISODE_CSV_HEADER)
+            for k in range(len(tt)):
+                succ = int(a[k]); coll = int(d[k] and not a[k]); tmo = int(not d[k] and not a[k])  # ppo.py:558-560
+                w.writerow([base + k, self.env_steps - (self.cfg.rollout_len - int(tt[k]) - 1) * self.env.N, succ, coll, tmo,
+                            int(ln[k]), float(rt[k]), 0.0, 0.0])
+        self._episode_count = base + len(tt)
+        return path
+
+    def tb_scalars(self):
+        """The reference's scalar names (ppo.py:892-939) for the last iteration."""
+        lg = self.logger
+        ep = max(lg.get("episodes", 0), 1)
+        return {"train/mean_return": lg.get("avg_ep_rews"), "train/mean_length": lg.get("avg_ep_lens"),
+                "train/success_rate": lg.get("success_rate"), "train/collision_rate": lg.get("collisions", 0) / ep,
+                "train/timeout_rate": lg.get("timeouts", 0) / ep, "loss/actor": lg.get("actor_loss"),
+                "loss/critic": lg.get("critic_loss"), "time/rollout_sec": lg.get("rollout_time"),
+                "time/update_sec": lg.get("update_time"), "time/iteration_sec": lg.get("iter_time"),
+                "perf/steps_per_sec": lg.get("steps_per_sec"), "ppo/approx_kl": lg.get("approx_kl"),
+                "ppo/clip_frac": lg.get("clip_frac"), "ppo/grad_norm": lg.get("grad_norm"), "ppo/exploration_var": lg.get("var")}
 
     def learn(self, total_timesteps, log=print):
         while self.t_so_far < total_timesteps:  # ppo.py:245

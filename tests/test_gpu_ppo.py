@@ -180,3 +180,32 @@ def test_fused_act_matches_pytorch_policy_step():
     assert L.navppo_mlp64_act(ptr(up.fp.flat), ptr(obs[N // 2:].contiguous()), None, N // 2, ptr(big), 9, N // 2, ptr(sb7), 0,
                               ptr(act2), ptr(lp), None, st) == 0
     assert torch.equal(act2, act[N // 2:])  # same (seed, global env id, step) -> same draw on another shard
+
+
+def test_train_checkpoint_then_evaluate_like_main(tmp_path):
+    """train -> checkpoint files with the reference's names -> evaluation mode of main.py:135-252 on the newest one."""
+    import csv
+    from navbot_ppo_amd import evaluate as ev
+    from navbot_ppo_amd.env import VecEnv
+    env = VecEnv(128, map="stage_1", max_episode_steps=30, seed=3)
+    cfg = ppo.PPOConfig(rollout_len=32, max_episode_steps=30, n_updates_per_iteration=2, policy="resmlp512", seed=1,
+                        output_dir=str(tmp_path), method_name="m1", save_freq=1)
+    tr = ppo.PPOTrainer(env, cfg)
+    tr.iteration()
+    tr.iteration()
+    env.close()
+    ck = ev.find_latest_checkpoint(str(tmp_path), "m1")
+    assert ck and os.path.basename(ck).startswith("actor_iter0002_step")
+    logs = os.path.join(str(tmp_path), "m1", "logs")
+    head = open(os.path.join(logs, "m1_train_episodes.csv")).readline().strip().split(",")
+    assert head == ["episode", "timestep", "success", "collision", "timeout", "length", "return", "path_length", "time"]
+    import json
+    sc = [json.loads(l) for l in open(os.path.join(logs, "scalars.jsonl"))]
+    assert len(sc) == 2 and {"train/mean_return", "loss/actor", "loss/critic", "perf/steps_per_sec", "ppo/approx_kl"} <= set(sc[0])
+    actor, policy = ev.load_actor(ck, "cuda")
+    assert policy == "resmlp512"
+    s = ev.evaluate(actor, num_episodes=40, max_timesteps_per_episode=25, n_parallel=16, output_dir=str(tmp_path), method_name="m1", log=None)
+    assert s["episodes"] == 40 and abs(s["success_rate"] + s["collision_rate"] + s["timeout_rate"] - 1.0) < 1e-9
+    rows = list(csv.reader(open(s["csv"])))
+    assert rows[0] == ["episode", "success", "collision", "timeout", "length", "return", "path_length", "time"] and len(rows) == 41
+    assert all(int(r[4]) <= 25 for r in rows[1:])
