@@ -90,6 +90,17 @@ int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_
 int navsim_set_goal_rects(navsim_t* h, int32_t which, const double* rects_host, int32_t n_rects);
 
 /*
+ * GoalSpawnSampler  (project_ppo/src/spawn_goal_sampler.py:37-62; parsed as --use_external_sampler at arguments.py:41 but
+ * never wired into the reference's Env): curated start poses [n_starts,3] (x,y,yaw) and goal points [n_goals,2], HOST
+ * pointers, copied.  With n_goals > 0 every reset (and in-step auto-reset) picks a start pose and a goal uniformly from the
+ * tables until min_dist <= |start - goal| <= max_dist (at most 100 attempts, then one unconditional pick) instead of the
+ * fixed spawn pose + uniform goal box; n_goals == 0 keeps the uniform goal rule but resets to starts[0].  Re-casts the
+ * scans of all start poses on `stream`.  Synchronous on `stream`.
+ */
+int navsim_set_spawn_sampler(navsim_t* h, const double* starts_host, int32_t n_starts, const double* goals_host,
+                             int32_t n_goals, double min_dist, double max_dist, void* stream);
+
+/*
  * Env.reset()  (environment_new.py:312-382), masked and batched: for every env i with
  * mask_dev[i] != 0 (all envs if mask_dev is NULL): pose <- spawn, goal <- sampled with the
  * reset rejection rule, past_distance <- distance to goal, episode counters <- 0,

@@ -42,6 +42,7 @@ SYMBOLS = [
     ("navsim_destroy", None, [_vp]),
     ("navsim_set_map", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     ("navsim_set_goal_rects", C.c_int, [_vp, _i32, _vp, _i32]),
+    ("navsim_set_spawn_sampler", C.c_int, [_vp, _vp, _i32, _vp, _i32, _d, _d, _vp]),
     ("navsim_reset", C.c_int, [_vp, _vp, _vp, _vp]),
     ("navsim_step", C.c_int, [_vp] * 11),
     ("navsim_get_state", C.c_int, [_vp] * 8),

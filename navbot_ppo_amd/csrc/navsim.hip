@@ -78,7 +78,11 @@ struct Params {
     int32_t* ep_step;
     uint32_t* rng_ctr;
     const float4* seg;        // [S] or [N][S]
-    const float* spawn_scan;  // [B] or [N][B] raw ranges at the spawn pose
+    const float* spawn_scan;  // [K][B] or [N][K][B] raw ranges at the K start poses (K = 1: the cfg spawn pose)
+    const double* starts;     // [K][3] start poses (x, y, yaw)
+    const double* goals;      // [G][2] goal points; G == 0: uniform goal box + rejection rectangles
+    int K, G;
+    double min_dist, max_dist;
     const double* beam_cs;    // [2][B]: cos(phi_b), sin(phi_b)
     const Rects* rects;
 };
@@ -215,6 +219,32 @@ __device__ __forceinline__ void sample_goal(const Params& P, int i, int which, u
         gx = P.goal_lo + (P.goal_hi - P.goal_lo) * ux;
         gy = P.goal_lo + (P.goal_hi - P.goal_lo) * uy;
         if (!goal_rejected(P.rects, which, gx, gy)) break;
+    }
+}
+
+// Episode start: which start pose k (index into P.starts) and which goal.
+//   G == 0  the reference Env.reset: the single spawn pose and a uniform goal with rectangle rejection.
+//   G  > 0  GoalSpawnSampler.sample_start_and_goal (project_ppo/src/spawn_goal_sampler.py:52-62): uniform picks from the
+//           start-pose and goal tables until min_dist <= |start - goal| <= max_dist, at most 100 attempts, then one
+//           unconditional pick.  One Philox call per attempt.
+__device__ __forceinline__ void sample_episode(const Params& P, int i, uint32_t& ctr, int& k, double& gx, double& gy) {
+    if (P.G == 0) {
+        k = 0;
+        sample_goal(P, i, 0, ctr, gx, gy);
+        return;
+    }
+    const uint64_t gid = P.env_id_base + (uint64_t)i;
+    for (int tries = 0; tries <= 100; ++tries) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), ctr, 0x6e617673u, P.key0, P.key1, r);
+        ctr += 1;
+        k = (int)(((uint64_t)r[0] * (uint64_t)P.K) >> 32);
+        const int g = (int)(((uint64_t)r[1] * (uint64_t)P.G) >> 32);
+        gx = P.goals[2 * g];
+        gy = P.goals[2 * g + 1];
+        const double dx = P.starts[3 * k] - gx, dy = P.starts[3 * k + 1] - gy;
+        const double dist = sqrt(dx * dx + dy * dy);  // np.linalg.norm, spawn_goal_sampler.py:57
+        if (tries == 100 || (P.min_dist <= dist && dist <= P.max_dist)) break;
     }
 }
 
@@ -561,15 +591,16 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         }
         float2 next_pact = act;  // ppo.py:543
         if (end && P.auto_reset) {  // ppo.py:582-593 + Env.reset, environment_new.py:312-382
-            x = P.spawn_x; y = P.spawn_y; th = P.spawn_yaw;
-            sample_goal(P, i, 0, ctr, gx, gy);
+            int k0;
+            sample_episode(P, i, ctr, k0, gx, gy);
+            x = P.starts[3 * k0]; y = P.starts[3 * k0 + 1]; th = P.starts[3 * k0 + 2];
             step = 0;
             ret = 0;
             next_pact = make_float2(0.f, 0.f);
             goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
             dist = hypot(gx - x, gy - y);
             pdist = dist;  // getGoalDistace, :116-120,:359
-            const float* sp = P.spawn_scan + (PER_ENV ? (size_t)i * B : 0);
+            const float* sp = P.spawn_scan + ((PER_ENV ? (size_t)i * P.K : 0) + k0) * B;
             write_obs_row(row, sp, 1, B, 0.f, 0.f, dist, yaw, rel_theta, diff, P.diag);
         }
         P.x[i] = x; P.y[i] = y; P.th[i] = th;
@@ -600,11 +631,12 @@ __global__ void reset_kernel(Params P, const uint8_t* __restrict__ mask, void* _
     const int B = P.B, D = B + 6;
     uint32_t ctr = P.rng_ctr[i];
     double gx, gy, yaw, rel_theta, diff;
-    const double x = P.spawn_x, y = P.spawn_y, th = P.spawn_yaw;
-    sample_goal(P, i, 0, ctr, gx, gy);
+    int k0;
+    sample_episode(P, i, ctr, k0, gx, gy);
+    const double x = P.starts[3 * k0], y = P.starts[3 * k0 + 1], th = P.starts[3 * k0 + 2];
     goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
     const double dist = hypot(gx - x, gy - y);
-    const float* sp = P.spawn_scan + (P.per_env ? (size_t)i * B : 0);
+    const float* sp = P.spawn_scan + ((P.per_env ? (size_t)i * P.K : 0) + k0) * B;
     // row assembled straight in global memory for the f32 case, via registers for f16
     if (P.obs_f16) {
         __half* o = reinterpret_cast<__half*>(obs_out) + (size_t)i * D;
@@ -632,16 +664,19 @@ __global__ void reset_kernel(Params P, const uint8_t* __restrict__ mask, void* _
 }
 
 // ---------------------------------------------------------------- LiDAR only (spawn scans, tests, tooling)
-// thread = env; pose [n,3] f64 (or one shared pose when pose_stride == 0)
-__global__ void raycast_kernel(Params P, const double* __restrict__ pose, int pose_stride, int n,
+// thread = (env, pose): thread t casts pose[(t % n_poses_per_env) or t] against env (t / n_poses_per_env)'s map.
+//   spawn scans:  n_poses_per_env = K, shared_poses = 1 : pose table [K][3] reused by every env
+//   navsim_raycast: n_poses_per_env = 1, shared_poses = 0 : pose[t]
+__global__ void raycast_kernel(Params P, const double* __restrict__ pose, int n_poses_per_env, int shared_poses, int n,
                                float* __restrict__ ranges) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double x = pose[(size_t)i * pose_stride + 0], y = pose[(size_t)i * pose_stride + 1],
-                 th = pose[(size_t)i * pose_stride + 2];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int env = t / n_poses_per_env;
+    const size_t pi = shared_poses ? (size_t)(t % n_poses_per_env) : (size_t)t;
+    const double x = pose[pi * 3 + 0], y = pose[pi * 3 + 1], th = pose[pi * 3 + 2];
     const double cth = cos(th), sth = sin(th);
     const float ox = (float)(x + kLidarX * cth), oy = (float)(y + kLidarX * sth);
-    const float4* __restrict__ sp = P.seg + (P.per_env ? (size_t)i * P.S : 0);
+    const float4* __restrict__ sp = P.seg + (P.per_env ? (size_t)env * P.S : 0);
     for (int b = 0; b < P.B; ++b) {
         const double bc = P.beam_cs[b], bs = P.beam_cs[P.B + b];
         const float c = (float)(cth * bc - sth * bs);
@@ -652,10 +687,10 @@ __global__ void raycast_kernel(Params P, const double* __restrict__ pose, int po
             const float rx = g.x - ox, ry = g.y - oy;
             const float ex = g.z - g.x, ey = g.w - g.y;
             const float k = fmaf(rx, ey, -(ry * ex));
-            const float t = ray_seg(rx, ry, ex, ey, k, c, s);
-            best = t < best ? t : best;
+            const float tt = ray_seg(rx, ry, ex, ey, k, c, s);
+            best = tt < best ? tt : best;
         }
-        ranges[(size_t)i * P.B + b] = scan_value(best);
+        ranges[(size_t)t * P.B + b] = scan_value(best);
     }
 }
 
@@ -687,7 +722,9 @@ struct navsim {
     Rects* rects_dev = nullptr;
     Rects rects_host;
     float* spawn_scan_dev = nullptr;
-    double* spawn_pose_dev = nullptr;
+    double* starts_dev = nullptr;   // [K][3]
+    double* goals_dev = nullptr;    // [G][2]
+    const float* seg_dev = nullptr;
     bool has_map = false;
 };
 
@@ -808,11 +845,15 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
     HIP_TRY(hipMemcpy(h->rects_dev, &h->rects_host, sizeof(Rects), hipMemcpyHostToDevice));
     P.rects = h->rects_dev;
 
-    // pose state starts at the spawn pose (the robot's pose before the first reset)
+    // start-pose table: K = 1, the cfg spawn pose (turtlebot3_stage_1.launch:3-5) until navsim_set_spawn_sampler
     {
         const double sp[3] = {cfg->spawn_x, cfg->spawn_y, cfg->spawn_yaw};
-        HIP_TRY(hipMalloc(&h->spawn_pose_dev, sizeof(sp)));
-        HIP_TRY(hipMemcpy(h->spawn_pose_dev, sp, sizeof(sp), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&h->starts_dev, sizeof(sp)));
+        HIP_TRY(hipMemcpy(h->starts_dev, sp, sizeof(sp), hipMemcpyHostToDevice));
+        P.starts = h->starts_dev;
+        P.K = 1;
+        P.G = 0;
+        P.goals = nullptr;
     }
     *out = h;
     return NAVSIM_OK;
@@ -824,7 +865,8 @@ void navsim_destroy(navsim_t* h) {
     (void)hipFree(h->beam_cs_dev);
     (void)hipFree(h->rects_dev);
     (void)hipFree(h->spawn_scan_dev);
-    (void)hipFree(h->spawn_pose_dev);
+    (void)hipFree(h->starts_dev);
+    (void)hipFree(h->goals_dev);
     delete h;
 }
 
@@ -838,26 +880,57 @@ int navsim_set_goal_rects(navsim_t* h, int32_t which, const double* rects_host, 
     return NAVSIM_OK;
 }
 
-int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_t per_env, void* stream) {
-    if (!h || !seg_dev || n_segments < 1) return fail(NAVSIM_E_ARG, "navsim_set_map: bad argument");
-    hipStream_t st = (hipStream_t)stream;
+static int rebuild_spawn_scans(navsim* h, hipStream_t st) {
     Params& P = h->P;
-    P.seg = reinterpret_cast<const float4*>(seg_dev);
-    P.S = n_segments;
-    P.per_env = per_env ? 1 : 0;
-    const size_t n_scan = (size_t)(per_env ? P.N : 1) * P.B;
+    const size_t n_poses = (size_t)(P.per_env ? P.N : 1) * P.K;
     if (h->spawn_scan_dev) {
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipFree(h->spawn_scan_dev));
         h->spawn_scan_dev = nullptr;
     }
-    HIP_TRY(hipMalloc(&h->spawn_scan_dev, n_scan * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->spawn_scan_dev, n_poses * P.B * sizeof(float)));
     P.spawn_scan = h->spawn_scan_dev;
-    const int n = per_env ? P.N : 1;
-    hipLaunchKernelGGL(raycast_kernel, dim3((n + 63) / 64), dim3(64), 0, st, P, h->spawn_pose_dev, 0, n,
-                       h->spawn_scan_dev);
+    hipLaunchKernelGGL(raycast_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, st, P, h->starts_dev, P.K, 1,
+                       (int)n_poses, h->spawn_scan_dev);
     HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
+}
+
+int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_t per_env, void* stream) {
+    if (!h || !seg_dev || n_segments < 1) return fail(NAVSIM_E_ARG, "navsim_set_map: bad argument");
+    Params& P = h->P;
+    P.seg = reinterpret_cast<const float4*>(seg_dev);
+    P.S = n_segments;
+    P.per_env = per_env ? 1 : 0;
+    const int rc = rebuild_spawn_scans(h, (hipStream_t)stream);
+    if (rc != NAVSIM_OK) return rc;
     h->has_map = true;
+    return NAVSIM_OK;
+}
+
+int navsim_set_spawn_sampler(navsim_t* h, const double* starts_host, int32_t n_starts, const double* goals_host,
+                             int32_t n_goals, double min_dist, double max_dist, void* stream) {
+    if (!h || !starts_host || n_starts < 1 || n_goals < 0 || (n_goals > 0 && !goals_host) || !(max_dist >= min_dist))
+        return fail(NAVSIM_E_ARG, "navsim_set_spawn_sampler: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    Params& P = h->P;
+    (void)hipFree(h->starts_dev);
+    (void)hipFree(h->goals_dev);
+    h->starts_dev = h->goals_dev = nullptr;
+    HIP_TRY(hipMalloc(&h->starts_dev, sizeof(double) * 3 * n_starts));
+    HIP_TRY(hipMemcpy(h->starts_dev, starts_host, sizeof(double) * 3 * n_starts, hipMemcpyHostToDevice));
+    if (n_goals > 0) {
+        HIP_TRY(hipMalloc(&h->goals_dev, sizeof(double) * 2 * n_goals));
+        HIP_TRY(hipMemcpy(h->goals_dev, goals_host, sizeof(double) * 2 * n_goals, hipMemcpyHostToDevice));
+    }
+    P.starts = h->starts_dev;
+    P.goals = h->goals_dev;
+    P.K = n_starts;
+    P.G = n_goals;
+    P.min_dist = min_dist;
+    P.max_dist = max_dist;
+    if (h->has_map) return rebuild_spawn_scans(h, st);
     return NAVSIM_OK;
 }
 
@@ -890,7 +963,7 @@ int navsim_step(navsim_t* h, const float* action_dev, const float* past_action_d
 int navsim_raycast(navsim_t* h, const double* pose_dev, float* ranges_dev, void* stream) {
     if (!h || !pose_dev || !ranges_dev) return fail(NAVSIM_E_ARG, "navsim_raycast: bad argument");
     if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_raycast: call navsim_set_map first");
-    hipLaunchKernelGGL(raycast_kernel, dim3((h->P.N + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, pose_dev, 3,
+    hipLaunchKernelGGL(raycast_kernel, dim3((h->P.N + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, pose_dev, 1, 0,
                        h->P.N, ranges_dev);
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;

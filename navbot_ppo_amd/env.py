@@ -82,6 +82,14 @@ class NavSim:
         r = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
         check(lib().navsim_set_goal_rects(self._h, int(which), _np_ptr(r), r.shape[0]), "navsim_set_goal_rects")
 
+    def set_spawn_sampler(self, starts, goals=None, min_dist=1.5, max_dist=6.0):
+        """GoalSpawnSampler tables (spawn_goal_sampler.py:37-62): start poses [K,3], goal points [G,2] or None."""
+        st = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
+        g = None if goals is None else np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 2)
+        with torch.cuda.device(self.device):
+            check(lib().navsim_set_spawn_sampler(self._h, _np_ptr(st), st.shape[0], _np_ptr(g), 0 if g is None else g.shape[0],
+                                                 float(min_dist), float(max_dist), _stream()), "navsim_set_spawn_sampler")
+
     # -- buffers
     def alloc_io(self):
         dev, N = self.device, self.N
@@ -162,7 +170,7 @@ class VecEnv:
     """
 
     def __init__(self, n_envs, map="stage_1", n_beams=10, max_episode_steps=500, auto_reset=True, is_training=True,
-                 seed=0, env_id_base=0, per_env_map=False, map_seed=0, obs_f16=False, device=None):
+                 seed=0, env_id_base=0, per_env_map=False, map_seed=0, obs_f16=False, device=None, sampler=None):
         thr = 0.2 if is_training else 0.4  # environment_new.py:44-47
         self.sim = NavSim(n_envs, n_beams=n_beams, max_episode_steps=max_episode_steps, auto_reset=auto_reset,
                           respawn_on_arrive=False, seed=seed, env_id_base=env_id_base, threshold_arrive=thr,
@@ -180,6 +188,10 @@ class VecEnv:
         if per_env_map and not (torch.is_tensor(seg) and seg.dim() == 3) and np.ndim(seg) == 2:
             seg = _maps.replicate_per_env(seg, self.N, seed=map_seed)
         self.sim.set_map(seg)
+        if sampler is not None:  # e.g. "stage1" / "small_house" (spawn_goal_sampler.py) or a (starts, goals, min, max) tuple
+            if isinstance(sampler, str):
+                sampler = _maps.spawn_tables(sampler)
+            self.sim.set_spawn_sampler(*sampler)
         self.io = self.sim.alloc_io()
 
     def close(self):

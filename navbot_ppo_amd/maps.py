@@ -136,3 +136,45 @@ def replicate_per_env(seg, n_envs, seed=0, jitter=0.02, shuffle=True):
         s64[:, [1, 3]] += off[i, 1]
         out[i] = s64.astype(np.float32)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Curated start poses (x, y, yaw) and goal points of the reference's GoalSpawnSampler
+# (project_ppo/src/spawn_goal_sampler.py:5-35).  These are scenario DATA of the reference (hand-picked free-space
+# coordinates for its two worlds), reproduced so that `--use_external_sampler` runs are drop-in; the sampling rule
+# itself is re-implemented in the step/reset kernels (navsim_set_spawn_sampler).
+_STAGE1_STARTS = [(0.0, 0.0, 0.0), (0.5, 0.5, 0.785), (-0.5, 0.5, 2.356), (0.5, -0.5, -0.785), (-0.5, -0.5, -2.356),
+                  (1.0, 0.0, 0.0), (0.0, 1.0, 1.57), (-1.0, 0.0, 3.14), (0.0, -1.0, -1.57), (1.0, 1.0, 0.785)]
+_STAGE1_GOALS = [(3.0, 3.0), (3.5, 2.5), (2.5, 3.5), (4.0, 3.0), (-3.0, 3.0), (-3.5, 2.5), (-2.5, 3.5), (-4.0, 3.0),
+                 (3.0, -3.0), (3.5, -2.5), (2.5, -3.5), (4.0, -3.0), (-3.0, -3.0), (-3.5, -2.5), (-2.5, -3.5), (-4.0, -3.0),
+                 (4.0, 0.0), (-4.0, 0.0), (0.0, 4.0), (0.0, -4.0), (3.0, 0.0), (-3.0, 0.0), (0.0, 3.0), (0.0, -3.0),
+                 (2.0, 2.0), (-2.0, 2.0), (2.0, -2.0), (-2.0, -2.0)]
+_HOUSE_STARTS = [(-3.5, 1.0, 0.0), (-3.0, 0.5, 1.57), (-2.5, 1.5, -1.57), (-3.0, 2.0, 0.0), (-1.0, 0.0, 0.0), (-0.5, 0.5, 1.57),
+                 (0.0, 0.0, -1.57), (2.0, 1.5, 3.14), (2.5, 0.5, -1.57), (3.0, 1.0, 0.0), (1.0, -2.0, 1.57), (0.5, -2.5, 0.0),
+                 (1.5, -2.0, -1.57), (-1.5, 2.5, 0.0), (-2.0, 3.0, 1.57), (0.0, 1.0, 0.0), (-1.0, 1.5, 1.57), (1.0, 1.0, -1.57)]
+_HOUSE_GOALS = [(-3.5, 0.5), (-3.0, 1.5), (-2.5, 2.0), (-3.5, 2.5), (-4.0, 1.0), (-2.0, 1.0), (-3.0, 0.0), (-1.0, 0.5),
+                (-0.5, 0.0), (0.0, 0.5), (-1.5, 0.0), (0.5, 0.0), (-1.0, -0.5), (2.0, 0.5), (2.5, 1.0), (3.0, 1.5), (2.0, 2.0),
+                (3.5, 1.0), (2.5, 0.0), (3.0, 0.5), (1.0, -2.5), (0.5, -2.0), (1.5, -2.5), (1.0, -3.0), (0.0, -2.5), (1.5, -1.5),
+                (-1.5, 2.0), (-2.0, 2.5), (-1.0, 3.0), (-2.5, 2.5), (-1.5, 3.5), (0.0, 1.5), (-1.0, 1.0), (1.0, 0.5), (0.5, 1.5),
+                (-0.5, 1.0), (0.0, 2.0), (1.0, 1.5), (-4.0, 3.0), (3.5, 2.0), (2.0, -3.0), (-2.0, -1.0)]
+
+
+def spawn_tables(world_type, min_dist=1.5, max_dist=6.0):
+    """(starts [K,3], goals [G,2], min_dist, max_dist) as GoalSpawnSampler(world_type) holds them
+    (spawn_goal_sampler.py:38-50; defaults min_dist=1.5, max_dist=6.0 at :38)."""
+    if world_type == "stage1":
+        st, g = _STAGE1_STARTS, _STAGE1_GOALS
+    elif world_type == "small_house":
+        st, g = _HOUSE_STARTS, _HOUSE_GOALS
+    else:
+        raise ValueError(f"Unknown world_type: {world_type}")  # same error as spawn_goal_sampler.py:49
+    return np.array(st, dtype=np.float64), np.array(g, dtype=np.float64), float(min_dist), float(max_dist)
+
+
+def validate_open_space(ranges, range_min=0.12, range_max=3.5, open_thresh=0.4):
+    """GoalSpawnSampler.validate_open_space (spawn_goal_sampler.py:64-72) on a raw scan array [..., B]: the smallest
+    range strictly inside (range_min, range_max) must exceed open_thresh; no valid range -> False."""
+    r = np.asarray(ranges, dtype=np.float64)
+    valid = (r > range_min) & (r < range_max)
+    mn = np.where(valid, r, np.inf).min(axis=-1)
+    return valid.any(axis=-1) & (mn > open_thresh)

@@ -286,6 +286,11 @@ typedef struct orc_sim {
     double reset_rects[16][4];
     double respawn_rects[16][4];
     int n_reset_rects, n_respawn_rects;
+    /* GoalSpawnSampler tables (spawn_goal_sampler.py:37-62); K >= 1 start poses, G == 0: uniform goal rule */
+    double* starts; /* [K][3] */
+    double* goals;  /* [G][2] */
+    int K, G;
+    double min_dist, max_dist;
 } orc_sim;
 
 ORC_API orc_sim* orc_sim_create(const orc_cfg* cfg) {
@@ -319,14 +324,30 @@ ORC_API orc_sim* orc_sim_create(const orc_cfg* cfg) {
         s->y[i] = cfg->spawn_y;
         s->th[i] = cfg->spawn_yaw;
     }
+    s->starts = calloc(3, sizeof(double));
+    s->starts[0] = cfg->spawn_x; s->starts[1] = cfg->spawn_y; s->starts[2] = cfg->spawn_yaw;
+    s->K = 1;
+    s->G = 0;
     return s;
+}
+
+ORC_API int orc_sim_set_spawn_sampler(orc_sim* s, const double* starts, int K, const double* goals, int G,
+                                      double min_dist, double max_dist) {
+    if (K < 1 || G < 0) return -1;
+    free(s->starts); free(s->goals);
+    s->starts = malloc(sizeof(double) * 3 * K);
+    memcpy(s->starts, starts, sizeof(double) * 3 * K);
+    s->goals = G ? malloc(sizeof(double) * 2 * G) : NULL;
+    if (G) memcpy(s->goals, goals, sizeof(double) * 2 * G);
+    s->K = K; s->G = G; s->min_dist = min_dist; s->max_dist = max_dist;
+    return 0;
 }
 
 ORC_API void orc_sim_destroy(orc_sim* s) {
     if (!s) return;
     free(s->seg); free(s->x); free(s->y); free(s->th); free(s->gx); free(s->gy);
     free(s->past_dist); free(s->ep_ret); free(s->past_action); free(s->ep_step);
-    free(s->rng_ctr); free(s->beam_cos); free(s->beam_sin);
+    free(s->rng_ctr); free(s->beam_cos); free(s->beam_sin); free(s->starts); free(s->goals);
     free(s);
 }
 
@@ -467,12 +488,38 @@ static void observe(orc_sim* s, int i, const double past_action[2], float* obs_r
     for (int k = 0; k < B + 6; ++k) obs_row[k] = (float)obs[k]; /* ppo.py:616 float64 -> float32 */
 }
 
-static void reset_env(orc_sim* s, int i, float* obs_row) {
+/* spawn_goal_sampler.py:52-62: uniform table picks until min_dist <= |start-goal| <= max_dist, <= 100 attempts, then
+ * one unconditional pick; one Philox call per attempt (r[0] -> start index, r[1] -> goal index). */
+static int sample_tables(orc_sim* s, int i) {
     const orc_cfg* c = &s->cfg;
-    s->x[i] = c->spawn_x; /* /gazebo/reset_world, environment_new.py:323-325 */
-    s->y[i] = c->spawn_y;
-    s->th[i] = c->spawn_yaw;
-    sample_goal(s, i, 0); /* :337-345 */
+    uint64_t gid = c->env_id_base + (uint64_t)i;
+    uint32_t key[2] = {(uint32_t)c->seed, (uint32_t)(c->seed >> 32)};
+    int k = 0;
+    for (int tries = 0; tries <= 100; ++tries) {
+        uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), s->rng_ctr[i], 0x6e617673u};
+        uint32_t r[4];
+        orc_philox4x32_10(ctr, key, r);
+        s->rng_ctr[i] += 1;
+        k = (int)(((uint64_t)r[0] * (uint64_t)s->K) >> 32);
+        int g = (int)(((uint64_t)r[1] * (uint64_t)s->G) >> 32);
+        s->gx[i] = s->goals[2 * g];
+        s->gy[i] = s->goals[2 * g + 1];
+        double dx = s->starts[3 * k] - s->gx[i], dy = s->starts[3 * k + 1] - s->gy[i];
+        double dist = sqrt(dx * dx + dy * dy); /* np.linalg.norm, :57 */
+        if (tries == 100 || (s->min_dist <= dist && dist <= s->max_dist)) break;
+    }
+    return k;
+}
+
+static void reset_env(orc_sim* s, int i, float* obs_row) {
+    int k = 0;
+    if (s->G > 0)
+        k = sample_tables(s, i);
+    else
+        sample_goal(s, i, 0); /* environment_new.py:337-345 */
+    s->x[i] = s->starts[3 * k]; /* /gazebo/reset_world, environment_new.py:323-325 */
+    s->y[i] = s->starts[3 * k + 1];
+    s->th[i] = s->starts[3 * k + 2];
     s->ep_step[i] = 0;
     s->ep_ret[i] = 0;
     s->past_action[2 * i] = 0;

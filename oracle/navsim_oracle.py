@@ -76,6 +76,8 @@ def lib():
         L.orc_sim_set_map.argtypes = [vp, vp, C.c_int, C.c_int]
         L.orc_sim_set_goal_rects.restype = C.c_int
         L.orc_sim_set_goal_rects.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.orc_sim_set_spawn_sampler.restype = C.c_int
+        L.orc_sim_set_spawn_sampler.argtypes = [vp, vp, C.c_int, vp, C.c_int, d, d]
         L.orc_sim_get_state.restype = None
         L.orc_sim_get_state.argtypes = [vp] * 7
         L.orc_sim_set_state.restype = None
@@ -193,6 +195,12 @@ class OracleSim:
     def set_goal_rects(self, which, rects):
         r = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
         assert lib().orc_sim_set_goal_rects(self._h, which, _p(r), r.shape[0]) == 0
+
+    def set_spawn_sampler(self, starts, goals=None, min_dist=1.5, max_dist=6.0):
+        st = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
+        g = None if goals is None else np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 2)
+        assert lib().orc_sim_set_spawn_sampler(self._h, _p(st), st.shape[0], _p(g), 0 if g is None else g.shape[0],
+                                               float(min_dist), float(max_dist)) == 0
 
     def get_state(self):
         N = self.N

@@ -391,3 +391,28 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     js = json.loads(lines[0])
     assert js["n_gpus"] == 2 and js["config"]["n_envs_total"] == 1024 and js["scaling"] == "weak"
     assert js["value"] > 0 and js["metric"] == "env_steps_per_sec"
+
+
+def test_table_sampler_parity_shared_and_per_env():
+    """navsim_set_spawn_sampler (GoalSpawnSampler tables) vs the oracle: resets and in-step auto-resets pick the same start
+    poses / goals (same Philox stream) and observe the scan of the picked pose."""
+    rng = np.random.default_rng(31)
+    st, g, lo, hi = maps.spawn_tables("stage1")
+    gpu, cpu = _mk(384, maps.stage_1(), max_episode_steps=12, auto_reset=True, seed=21)
+    gpu.set_spawn_sampler(st, g, lo, hi)
+    cpu.set_spawn_sampler(st, g, lo, hi)
+    stt = _lockstep(gpu, cpu, _actions(rng, 40, 384), check_state_every=5)
+    assert stt["ended"] >= 384 * 3
+    segp = maps.replicate_per_env(maps.stage_1(), 128, seed=4)
+    gpu, cpu = _mk(128, segp, per_env=True, max_episode_steps=9, auto_reset=True, seed=22)
+    gpu.set_spawn_sampler(st, g, lo, hi)
+    cpu.set_spawn_sampler(st, g, lo, hi)
+    _lockstep(gpu, cpu, _actions(rng, 30, 128), check_state_every=5)
+    # sampler installed before the map is also fine
+    from navbot_ppo_amd.env import NavSim
+    s = NavSim(8, seed=1)
+    s.set_spawn_sampler(st, g, lo, hi)
+    s.set_map(maps.stage_1())
+    io = s.alloc_io()
+    s.reset(io.obs)
+    assert np.all(np.isin(s.get_state()["pose"][:, 0], st[:, 0]))

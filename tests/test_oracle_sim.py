@@ -211,3 +211,55 @@ def test_g9_closed_loop_against_reference():
         n_cmp += int(a.sum())
         past = d["actions"][k].copy()
     assert n_cmp > 1000 and d["ref_flags"][..., 0].sum() >= 2 and d["ref_flags"][..., 1].sum() >= 2
+
+
+def test_table_sampler_rule_and_tables():
+    """GoalSpawnSampler semantics (spawn_goal_sampler.py:37-72) in the oracle: picks come from the tables, respect the
+    distance window, resets start at the picked pose; tables equal the reference's (checked against its module when
+    /root/reference is present)."""
+    st, g, lo, hi = maps.spawn_tables("stage1")
+    assert st.shape == (10, 3) and g.shape == (28, 2) and (lo, hi) == (1.5, 6.0)
+    sh, gh, _, _ = maps.spawn_tables("small_house")
+    assert sh.shape == (18, 3) and gh.shape == (42, 2)
+    with pytest.raises(ValueError):
+        maps.spawn_tables("nope")
+    ref = "/root/reference/project_ppo/src/spawn_goal_sampler.py"
+    if os.path.exists(ref):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_sampler", ref)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        np.testing.assert_array_equal(st, np.array(m.STAGE1_START_POSES))
+        np.testing.assert_array_equal(g, np.array(m.STAGE1_GOAL_POINTS))
+        np.testing.assert_array_equal(sh, np.array(m.SMALL_HOUSE_START_POSES))
+        np.testing.assert_array_equal(gh, np.array(m.SMALL_HOUSE_GOAL_POINTS))
+        smp = m.GoalSpawnSampler("stage1", seed=1)
+        for _ in range(200):
+            s0, g0 = smp.sample_start_and_goal()
+            d = np.hypot(s0[0] - g0[0], s0[1] - g0[1])
+            assert 1.5 <= d <= 6.0
+        scan = type("S", (), dict(ranges=[0.5, 3.5, 0.12, 1.0], range_min=0.12, range_max=3.5))
+        assert smp.validate_open_space(scan) == bool(maps.validate_open_space([0.5, 3.5, 0.12, 1.0]))
+        scan.ranges = [0.3, 2.0]
+        assert smp.validate_open_space(scan) == bool(maps.validate_open_space([0.3, 2.0])) == False
+    N = 3000
+    sim = O.OracleSim(N, seed=5, max_episode_steps=3, auto_reset=True)
+    sim.set_map(maps.stage_1())
+    sim.set_spawn_sampler(st, g, lo, hi)
+    obs = sim.reset()
+    s = sim.get_state()
+    d = np.hypot(s["pose"][:, 0] - s["goal"][:, 0], s["pose"][:, 1] - s["goal"][:, 1])
+    assert np.all((d >= 1.5) & (d <= 6.0))
+    assert all(any(np.array_equal(p, q) for q in st) for p in s["pose"][:50])
+    assert all(any(np.array_equal(p, q) for q in g) for p in s["goal"][:50])
+    assert len({tuple(p) for p in s["pose"]}) == 10 and len({tuple(p) for p in s["goal"]}) >= 25  # all tables used
+    np.testing.assert_allclose(s["past_dist"], d, rtol=1e-15)
+    # yaw of the picked pose shows up in the reset observation: yaw/360 with yaw = round(deg) wrapped
+    yaw_deg = np.round(np.degrees(s["pose"][:, 2])) % 360
+    np.testing.assert_allclose(obs[:, 13], (yaw_deg / 360).astype(np.float32), atol=1e-7)
+    for _ in range(3):
+        out = sim.step(np.zeros((N, 2), np.float32))
+    assert out["ended"].all()  # timeout -> auto-reset through the tables again
+    s2 = sim.get_state()
+    d2 = np.hypot(s2["pose"][:, 0] - s2["goal"][:, 0], s2["pose"][:, 1] - s2["goal"][:, 1])
+    assert np.all((d2 >= 1.5) & (d2 <= 6.0)) and np.any(s2["goal"] != s["goal"])
