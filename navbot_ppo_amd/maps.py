@@ -97,8 +97,72 @@ STAGE4_EXTRA_RECTS = np.array(
     dtype=np.float64)
 
 
+def house_base():
+    """The reference's ``models/turtlebot3_house/model.sdf`` cut at the LiDAR plane: 52 boxes + 4 cylinders (12-gons) = 256
+    segments, produced by ``tools/gen_house_map.py`` with ``sdf_ingest`` (4 mesh collisions have no footprint and are
+    skipped).  15 x 10.7 m."""
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "turtlebot3_house_segments.npy"))
+
+
+def house(n_segments=2048, seed=0, keep_clear=None, clear_radius=0.6):
+    """AUTHORED "small_house ~2k segments" map of BASELINE cfg 5 (``aws_robomaker_small_house_world`` is not vendored in
+    the reference, ``navbot_small_house.launch:11``): ``house_base()`` furnished with seeded clutter -- thin table/chair
+    legs (5 cm boxes) and round stools/plant pots (16-gons) -- until the map has exactly ``n_segments`` segments.  Clutter
+    keeps ``clear_radius`` metres away from every point of ``keep_clear`` (default: the small_house start/goal tables)."""
+    base = house_base()
+    if keep_clear is None:
+        keep_clear = np.concatenate([np.array(_HOUSE_STARTS)[:, :2], np.array(_HOUSE_GOALS)])
+    rng = np.random.default_rng(seed)
+    segs = [base.astype(np.float64)]
+    n = base.shape[0]
+    xmin, xmax, ymin, ymax = -7.3, 7.3, -5.1, 5.1
+    placed = []
+    while n < n_segments:
+        left = n_segments - n
+        x, y = rng.uniform(xmin, xmax), rng.uniform(ymin, ymax)
+        if np.min(np.hypot(keep_clear[:, 0] - x, keep_clear[:, 1] - y)) < clear_radius:
+            continue
+        if placed and np.min(np.hypot(np.array(placed)[:, 0] - x, np.array(placed)[:, 1] - y)) < 0.25:
+            continue
+        if left >= 16 and rng.random() < 0.35:
+            segs.append(np.array(cylinder_to_segments(rng.uniform(0.1, 0.2), x, y, sides=16, phase=rng.uniform(0, 1))))
+            n += 16
+        elif left >= 4:
+            segs.append(np.array(box_to_segments(0.05, 0.05, x, y, rng.uniform(0, math.pi / 2))))
+            n += 4
+        else:  # 1..3 segments left: a short free-standing panel per segment
+            a = rng.uniform(0, math.pi)
+            segs.append(np.array([[x, y, x + 0.3 * math.cos(a), y + 0.3 * math.sin(a)]]))
+            n += 1
+        placed.append((x, y))
+    return _as_map(np.concatenate(segs))
+
+
+def open_tables(seg, starts, goals, n_beams=10, open_thresh=0.4):
+    """Keeps the start poses / goal points whose surroundings are open in map ``seg`` (validate_open_space rule,
+    spawn_goal_sampler.py:64-72) using a float64 numpy ray-caster (host-side tooling, not the simulation path)."""
+    seg = np.asarray(seg, dtype=np.float64)
+
+    def min_range(x, y):
+        ang = np.linspace(-math.pi, math.pi, 72, endpoint=False)
+        dx, dy = np.cos(ang)[:, None], np.sin(ang)[:, None]
+        ax, ay, bx, by = seg.T
+        ex, ey = bx - ax, by - ay
+        den = dx * ey - dy * ex
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = ((ax - x) * ey - (ay - y) * ex) / den
+            u = ((ax - x) * dy - (ay - y) * dx) / den
+        t = np.where((den != 0) & (t >= 0) & (u >= 0) & (u <= 1), t, np.inf)
+        return t.min()
+
+    ks = [k for k, p in enumerate(starts) if min_range(p[0], p[1]) > open_thresh]
+    kg = [k for k, p in enumerate(goals) if min_range(p[0], p[1]) > open_thresh]
+    return np.asarray(starts)[ks], np.asarray(goals)[kg]
+
+
 def by_name(name):
-    table = {"stage_1": stage_1, "stage_2": stage_2, "stage_4": stage_4}
+    table = {"stage_1": stage_1, "stage_2": stage_2, "stage_4": stage_4, "house": house, "house_base": house_base}
     if name not in table:
         raise KeyError(f"unknown map {name!r}; have {sorted(table)}")
     return table[name]()
@@ -114,6 +178,8 @@ def goal_rects(name):
     if name == "stage_4":
         return (np.concatenate([RESET_RECTS_STAGE1, STAGE4_EXTRA_RECTS]),
                 np.concatenate([RESPAWN_RECTS_STAGE1, STAGE4_EXTRA_RECTS]))
+    if name in ("house", "house_base"):  # goals come from the curated tables (sampler), not from the uniform box
+        return np.zeros((0, 4)), np.zeros((0, 4))
     raise KeyError(name)
 
 

@@ -416,3 +416,39 @@ def test_table_sampler_parity_shared_and_per_env():
     io = s.alloc_io()
     s.reset(io.obs)
     assert np.all(np.isin(s.get_state()["pose"][:, 0], st[:, 0]))
+
+
+def test_cfg5_house_map_f16_sampler_parity():
+    """BASELINE configs[4] in small: the 2048-segment house map (shared), curated start/goal tables filtered to open space,
+    half-precision observation buffers; GPU vs oracle (obs compared after the oracle's rows are rounded to half)."""
+    rng = np.random.default_rng(41)
+    N = 192
+    seg = maps.house()
+    st, g, lo, hi = maps.spawn_tables("small_house")
+    st, g = maps.open_tables(seg, st, g)
+    from navbot_ppo_amd.env import NavSim
+    gpu = NavSim(N, max_episode_steps=25, auto_reset=True, seed=8, obs_f16=True)
+    cpu = O.OracleSim(N, max_episode_steps=25, auto_reset=True, seed=8)
+    for s in (gpu, cpu):
+        s.set_map(seg)
+        s.set_spawn_sampler(st, g, lo, hi)
+    io = gpu.alloc_io()
+    og = gpu.reset(io.obs)
+    oc = cpu.reset()
+    assert og.dtype == torch.float16
+    assert torch.equal(og.cpu(), torch.from_numpy(oc).half())
+    acts = _actions(rng, 60, N)
+    n_end = 0
+    for k in range(60):
+        gpu.step(torch.from_numpy(acts[k]).cuda(), io.obs, io.reward, io.done, io.arrive, io.ended, io.ep_return, io.ep_length)
+        out = cpu.step(acts[k])
+        diff = (io.obs.float().cpu() - torch.from_numpy(out["obs"]).half().float()).abs().max().item()
+        assert diff <= 1e-3  # one half ulp at 1.0 is 4.9e-4; rows are equal except where f32 differs in its last bit
+        for name in ("done", "arrive", "ended"):
+            np.testing.assert_array_equal(getattr(io, name).cpu().numpy(), out[name])
+        np.testing.assert_allclose(io.reward.cpu().numpy(), out["reward"], rtol=REW_RTOL, atol=1e-5)
+        n_end += int(out["ended"].sum())
+    assert n_end > N
+    sg, sc = gpu.get_state(), cpu.get_state()
+    np.testing.assert_array_equal(sg["goal"], sc["goal"])
+    np.testing.assert_allclose(sg["pose"], sc["pose"], atol=1e-11)
