@@ -31,9 +31,10 @@ def test_sdf_ingest_composes_poses_and_filters_the_scan_plane():
     # cylinder at model-frame (0,1) -> world (0, 2), radius 0.5
     c = seg[4:12]
     assert np.allclose(np.hypot(c[:, 0] - 0.0, c[:, 1] - 2.0), 0.5, atol=1e-6)
-    # nested model: yaw +90 - 90 = 0, box centre model-frame (3,0) rotated by +90 -> world (1, 5)
+    # nested model: origin (1,2), yaw +90 - 90 = 0 -> its box at nested-frame (3,0) sits at world (4, 2), axis-aligned
     n = seg[12:]
-    assert np.allclose([n[:, [0, 2]].mean(), n[:, [1, 3]].mean()], [1.0, 5.0], atol=1e-6)
+    assert np.allclose([n[:, [0, 2]].mean(), n[:, [1, 3]].mean()], [4.0, 2.0], atol=1e-6)
+    assert np.allclose([n[:, [0, 2]].min(), n[:, [0, 2]].max()], [3.5, 4.5], atol=1e-6)
 
 
 def test_house_maps():
