@@ -116,15 +116,46 @@ __global__ __launch_bounds__(4 * PT) void mlp64_pass(const float* __restrict__ p
     float acc_db3 = 0.f, acc_db4 = 0.f;                 // sample-owner threads (tid & 3) == 0
     float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;   // loss, kl, clip-frac sums
 
+    // Software prefetch: the next tile's observations (PT*16/NT = 4 floats per thread) and per-sample scalars are
+    // loaded into registers while the current tile is being processed, so no phase waits on HBM latency.
+    constexpr int XPT = TM * IN / NT;
+    float xpre[XPT];
+    float pre_a0 = 0.f, pre_a1 = 0.f, pre_lp = 0.f, pre_t = 0.f;  // act, logp_old, (adv | rtg) of sample tid >> 2
+    auto prefetch_tile = [&](long long tile) {
+        const long long mb = tile * TM;
+#pragma unroll
+        for (int j = 0; j < XPT; ++j) {
+            const int k = tid + j * NT;
+            const long long m = mb + k / IN;
+            xpre[j] = (m < M) ? obs[m * IN + (k % IN)] : 0.f;
+        }
+        if ((tid & 3) == 0) {
+            const long long m = mb + (tid >> 2);
+            if (m < M) {
+                if (ACTOR) {
+                    pre_a0 = act[2 * m];
+                    pre_a1 = act[2 * m + 1];
+                    pre_lp = logp_old[m];
+                    pre_t = adv[m];
+                } else {
+                    pre_t = rtg[m];
+                }
+            }
+        }
+    };
     const long long n_tiles = (M + TM - 1) / TM;
+    if (blockIdx.x < n_tiles) prefetch_tile(blockIdx.x);
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long m_base = tile * TM;
         __syncthreads();  // previous tile's LDS readers are done
-        // ---- X tile -> LDS (rows beyond M are zero)
-        for (int k = tid; k < TM * IN; k += NT) {
-            const int m = k / IN, c = k % IN;
-            sm.X[m * LDX + c] = (m_base + m < M) ? obs[(m_base + m) * IN + c] : 0.f;
+        // ---- X tile: registers -> LDS; then start loading the next tile
+#pragma unroll
+        for (int j = 0; j < XPT; ++j) {
+            const int k = tid + j * NT;
+            sm.X[(k / IN) * LDX + (k % IN)] = xpre[j];
         }
+        const float cur_a0 = pre_a0, cur_a1 = pre_a1, cur_lp = pre_lp, cur_t = pre_t;
+        if (tile + gridDim.x < n_tiles) prefetch_tile(tile + gridDim.x);
         __syncthreads();
 
         // ---- F1: H1 = relu(X W1^T + b1), K = 16
@@ -184,13 +215,13 @@ __global__ __launch_bounds__(4 * PT) void mlp64_pass(const float* __restrict__ p
                     if (ACTOR) {
                         const float mu0 = 1.0f / (1.0f + expf(-z3));   // torch.sigmoid, net_actor.py:185
                         const float mu1 = tanhf(z4);                    // net_actor.py:186
-                        const float a0 = act[2 * m], a1 = act[2 * m + 1];
+                        const float a0 = cur_a0, a1 = cur_a1;
                         const float d0 = a0 - mu0, d1 = a1 - mu1;
                         // MultivariateNormal(mean, var*I).log_prob, ppo.py:734-735
                         const float lp = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);
-                        const float lr = lp - logp_old[m];
+                        const float lr = lp - cur_lp;
                         const float ratio = expf(lr);                  // ppo.py:316
-                        const float A = adv[m];
+                        const float A = cur_t;
                         const float s1 = ratio * A;                     // ppo.py:319
                         const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
                         const float s2 = rc * A;                        // ppo.py:320
@@ -206,7 +237,7 @@ __global__ __launch_bounds__(4 * PT) void mlp64_pass(const float* __restrict__ p
                         g4 = dL_dlp * (d1 / var) * (1.0f - mu1 * mu1);
                     } else {
                         const float V = z3;                             // critic(obs).squeeze(), ppo.py:724
-                        const float e = V - rtg[m];
+                        const float e = V - cur_t;
                         st1 += e * e;                                   // MSELoss, ppo.py:343
                         g3 = 2.0f * e * inv_n;
                     }
