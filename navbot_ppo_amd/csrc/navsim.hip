@@ -114,11 +114,19 @@ __device__ __forceinline__ double py_round(double x, double s) {
 }
 
 // Env.getOdometry, environment_new.py:138-181, for the yaw-only quaternion Gazebo publishes.
+__device__ __forceinline__ void goal_angles_q(double x, double y, double qz, double qw, double gx, double gy,
+                                              double& yaw, double& rel_theta, double& diff);
+
 __device__ __forceinline__ void goal_angles(double x, double y, double th, double gx, double gy,
                                             double& yaw, double& rel_theta, double& diff) {
+    goal_angles_q(x, y, sin(th / 2), cos(th / 2), gx, gy, yaw, rel_theta, diff);
+}
+
+// (qz, qw) = (sin(theta/2), cos(theta/2)): the odom orientation quaternion of a planar robot
+__device__ __forceinline__ void goal_angles_q(double x, double y, double qz, double qw, double gx, double gy,
+                                              double& yaw, double& rel_theta, double& diff) {
     const double kPi = 3.14159265358979323846;
     const double rad2deg = 180.0 / kPi;
-    const double qz = sin(th / 2), qw = cos(th / 2);
     const double qx = 0.0, qy = 0.0;
     yaw = rint(atan2(2 * (qx * qy + qw * qz), 1 - 2 * (qy * qy + qz * qz)) * rad2deg);  // :142
     if (!(yaw >= 0)) yaw = yaw + 360;                                                    // :144-147
@@ -278,6 +286,7 @@ struct StepSmem {
     float2 dir[NB * EPB];        // [beam][env] unit direction
     unsigned rng[NB * EPB];      // [beam][env] nearest hit as float bits (non-negative floats order like uints)
     float obs[EPB * (NB + 7)];   // [env][B+6 (+1 pad: odd row stride, conflict-free)] the block's output tile
+    double sc[EPB][8][2];  // pose phase: (cos, sin) of the 6 substep angles, of theta and of theta/2, one per lane
     // pose-wave values parked here while wave 0 ray-casts (keeps the kernel under 128 VGPRs = 4 blocks per CU)
     double sv_d[11][EPB];
     float2 sv_act[EPB], sv_pact[EPB];
@@ -371,13 +380,20 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     const int nloc = min(EPB, P.N - base);  // envs in this block
     const unsigned kInfBits = 0x7f800000u;
 
-    // pose-wave registers that live across the phases
+    // Pose lanes: 8 lanes per env (lane r of the group evaluates ONE of the 8 sincos the step needs: the six substep
+    // headings, the final heading, and half of it), so the pose phase costs one sincos latency instead of eight.
+    // Lane r == 0 of each group owns the env's float64 state across the phases.  EPB envs -> EPB/8 waves (0, 1).
+    constexpr int PW = (EPB + 7) / 8;          // pose waves
+    static_assert(PW <= 2, "pose lanes live in waves 0 and 1");
     double x = 0, y = 0, th = 0, gx = 0, gy = 0, pdist = 0, dist = 0, yaw = 0, rel_theta = 0, diff = 0, ret0 = 0;
     float2 act = make_float2(0.f, 0.f), pact = make_float2(0.f, 0.f);
     uint32_t ctr = 0;
     int step0 = 0;
-    const int i = base + lane;
-    const bool own = (wave == 0) && (lane < nloc);
+    const int el_pose = 8 * wave + (lane >> 3);  // env (local) this pose lane works for
+    const int rr = lane & 7;
+    const bool pose_lane = (wave < PW) && (el_pose < EPB);
+    const bool own = pose_lane && (rr == 0) && (el_pose < nloc);
+    const int i = base + el_pose;
 
     float4 pre[PF];  // prefetched segments of the current work item (per-env maps)
     auto prefetch = [&](int el, float4 (&dst)[PF]) {
@@ -389,17 +405,21 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         }
     };
 
-    if (wave == 0) {
-        // ---------------- pose wave, part 1: motion + sensor frame
-        if (lane < EPB) {
-            if (own) {
-                x = P.x[i]; y = P.y[i]; th = P.th[i];
-                gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
+    if (wave < PW) {
+        // ---------------- pose lanes, part 1: motion + sensor frame
+        if (pose_lane) {
+            double delta_s = 0, delta_theta = 0, arg = 0;
+            if (el_pose < nloc) {
+                th = P.th[i];
                 act = action[i];
-                pact = past_override ? past_override[i] : P.past_action[i];
-                ctr = P.rng_ctr[i];
-                step0 = P.ep_step[i];
-                ret0 = P.ep_ret[i];
+                if (rr == 0) {
+                    x = P.x[i]; y = P.y[i];
+                    gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
+                    pact = past_override ? past_override[i] : P.past_action[i];
+                    ctr = P.rng_ctr[i];
+                    step0 = P.ep_step[i];
+                    ret0 = P.ep_ret[i];
+                }
                 // environment_new.py:273-278
                 const double v = (double)act.x / 4;
                 const double w = (double)act.y;
@@ -409,47 +429,64 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
                 const double dt = 1.0 / 30.0;
                 const double wl = vl / kWheelRadius, wr = vr / kWheelRadius;
                 const double wheel_l = wl * dt, wheel_r = wr * dt;
-                const double delta_s = kWheelRadius * (wheel_r + wheel_l) / 2.0;
-                const double delta_theta = kWheelRadius * (wheel_r - wheel_l) / kWheelSep;
-                for (int k = 0; k < kSubsteps; ++k) {  // :158-160
-                    const double a = th + (delta_theta / 2.0);
-                    x += delta_s * cos(a);
-                    y += delta_s * sin(a);
-                    th += delta_theta;
+                delta_s = kWheelRadius * (wheel_r + wheel_l) / 2.0;
+                delta_theta = kWheelRadius * (wheel_r - wheel_l) / kWheelSep;
+                // heading before substep k is th0 + k additions of delta_theta (same roundings as the serial loop)
+                for (int k = 0; k < kSubsteps; ++k) {
+                    if (k == rr) arg = th + (delta_theta / 2.0);  // :158-159 argument of substep rr
+                    th += delta_theta;                             // :160
+                }
+                if (rr == 6) arg = th;
+                if (rr == 7) arg = th / 2;
+            }
+            sm.sc[el_pose][rr][0] = cos(arg);
+            sm.sc[el_pose][rr][1] = sin(arg);
+            // same wave wrote what this lane reads next: LDS ops of a wave complete in order, no barrier needed
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (rr == 0) {
+                for (int k = 0; k < kSubsteps; ++k) {  // :158-159
+                    x += delta_s * sm.sc[el_pose][k][0];
+                    y += delta_s * sm.sc[el_pose][k][1];
+                }
+                const double cth = sm.sc[el_pose][6][0], sth = sm.sc[el_pose][6][1];
+                const double ox = x + kLidarX * cth;
+                const double oy = y + kLidarX * sth;
+                sm.org[el_pose] = make_float2((float)ox, (float)oy);
+            }
+            {
+                const double cth = sm.sc[el_pose][6][0], sth = sm.sc[el_pose][6][1];
+                for (int b = rr; b < B; b += 8) {
+                    const double bc = P.beam_cs[b], bs = P.beam_cs[B + b];
+                    const double c = cth * bc - sth * bs;
+                    const double s = sth * bc + cth * bs;
+                    sm.dir[b * EPB + el_pose] = make_float2((float)c, (float)s);
                 }
             }
-            const double cth = cos(th), sth = sin(th);
-            const double ox = x + kLidarX * cth;
-            const double oy = y + kLidarX * sth;
-            sm.org[lane] = make_float2((float)ox, (float)oy);
-            for (int b = 0; b < B; ++b) {
-                const double bc = P.beam_cs[b], bs = P.beam_cs[B + b];
-                const double c = cth * bc - sth * bs;
-                const double s = sth * bc + cth * bs;
-                sm.dir[b * EPB + lane] = make_float2((float)c, (float)s);
-            }
         }
-        if (lane == 0) next_env = 3;  // envs 0,1,2 are pre-assigned to waves 1,2,3
-    } else {
-        // ---------------- waves 1-3, part 1: nothing here depends on the pose
-        for (int k = tid - 64; k < NB * EPB; k += kThreads - 64) sm.rng[k] = kInfBits;
+        if (tid == 0) next_env = 4 - PW;  // the first envs are pre-assigned to the non-pose waves
+    }
+    if (wave >= PW) {
+        // ---------------- other waves, part 1: nothing here depends on the pose
+        for (int k = tid - 64 * PW; k < NB * EPB; k += kThreads - 64 * PW) sm.rng[k] = kInfBits;
         if constexpr (PER_ENV) {
-            if (wave - 1 < nloc) prefetch(wave - 1, pre);
+            if (wave - PW < nloc) prefetch(wave - PW, pre);
         } else {
             const int ns = min(kSegTile, P.S);
-            for (int j = tid - 64; j < ns; j += kThreads - 64) seg_tile[j] = P.seg[j];
+            for (int j = tid - 64 * PW; j < ns; j += kThreads - 64 * PW) seg_tile[j] = P.seg[j];
         }
     }
     __syncthreads();  // barrier A: origins / directions / first segment tile visible
 
-    if (wave == 0 && own) {
-        // ---------------- pose wave, part 2 (the other waves are already ray-casting): goal geometry
-        goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
+    if (own) {
+        // ---------------- pose lanes, part 2 (the other waves are already ray-casting): goal geometry
+        goal_angles_q(x, y, sm.sc[el_pose][7][1], sm.sc[el_pose][7][0], gx, gy, yaw, rel_theta, diff);
         dist = hypot(gx - x, gy - y);  // environment_new.py:203
-        sm.sv_d[0][lane] = x; sm.sv_d[1][lane] = y; sm.sv_d[2][lane] = th; sm.sv_d[3][lane] = gx; sm.sv_d[4][lane] = gy;
-        sm.sv_d[5][lane] = pdist; sm.sv_d[6][lane] = dist; sm.sv_d[7][lane] = yaw; sm.sv_d[8][lane] = rel_theta;
-        sm.sv_d[9][lane] = diff; sm.sv_d[10][lane] = ret0;
-        sm.sv_act[lane] = act; sm.sv_pact[lane] = pact; sm.sv_ctr[lane] = ctr; sm.sv_step[lane] = step0;
+        const int e = el_pose;
+        sm.sv_d[0][e] = x; sm.sv_d[1][e] = y; sm.sv_d[2][e] = th; sm.sv_d[3][e] = gx; sm.sv_d[4][e] = gy;
+        sm.sv_d[5][e] = pdist; sm.sv_d[6][e] = dist; sm.sv_d[7][e] = yaw; sm.sv_d[8][e] = rel_theta;
+        sm.sv_d[9][e] = diff; sm.sv_d[10][e] = ret0;
+        sm.sv_act[e] = act; sm.sv_pact[e] = pact; sm.sv_ctr[e] = ctr; sm.sv_step[e] = step0;
     }
     if constexpr (PER_ENV) {
         auto grab = [&]() {
@@ -457,8 +494,8 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             if (lane == 0) v = atomicAdd(&next_env, 1);
             return __builtin_amdgcn_readfirstlane(v);
         };
-        int cur = (wave == 0) ? grab() : wave - 1;
-        if (wave == 0 && cur < nloc) prefetch(cur, pre);
+        int cur = (wave < PW) ? grab() : wave - PW;
+        if (wave < PW && cur < nloc) prefetch(cur, pre);
         while (cur < nloc) {  // wave-uniform
             const int nxt = grab();
             float4 pre_nxt[PF];
@@ -548,14 +585,15 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
 
     // ---------------- pose wave, part 3: rules of getState / step / setReward + episode logic
     if (own) {
-        x = sm.sv_d[0][lane]; y = sm.sv_d[1][lane]; th = sm.sv_d[2][lane]; gx = sm.sv_d[3][lane]; gy = sm.sv_d[4][lane];
-        pdist = sm.sv_d[5][lane]; dist = sm.sv_d[6][lane]; yaw = sm.sv_d[7][lane]; rel_theta = sm.sv_d[8][lane];
-        diff = sm.sv_d[9][lane]; ret0 = sm.sv_d[10][lane];
-        act = sm.sv_act[lane]; pact = sm.sv_pact[lane]; ctr = sm.sv_ctr[lane]; step0 = sm.sv_step[lane];
-        float* row = sm.obs + lane * DP;
+        const int e = el_pose;
+        x = sm.sv_d[0][e]; y = sm.sv_d[1][e]; th = sm.sv_d[2][e]; gx = sm.sv_d[3][e]; gy = sm.sv_d[4][e];
+        pdist = sm.sv_d[5][e]; dist = sm.sv_d[6][e]; yaw = sm.sv_d[7][e]; rel_theta = sm.sv_d[8][e];
+        diff = sm.sv_d[9][e]; ret0 = sm.sv_d[10][e];
+        act = sm.sv_act[e]; pact = sm.sv_pact[e]; ctr = sm.sv_ctr[e]; step0 = sm.sv_step[e];
+        float* row = sm.obs + e * DP;
         float mn = INFINITY;
         for (int b = 0; b < B; ++b) {
-            float r = scan_value(__uint_as_float(sm.rng[b * EPB + lane]));
+            float r = scan_value(__uint_as_float(sm.rng[b * EPB + e]));
             if (r == INFINITY) r = 3.5f;  // environment_new.py:193-194
             mn = r < mn ? r : mn;
             row[b] = r / 3.5f;            // :289 (see write_obs_row on the float32 divide)
@@ -728,7 +766,7 @@ struct navsim {
     bool has_map = false;
 };
 
-int g_epb = 16;  // envs per workgroup (NAVSIM_EPB = 16 | 32 | 64 overrides; tuning knob)
+int g_epb = 16;  // envs per workgroup (NAVSIM_EPB = 8 | 16; tuning knob)
 
 template <int NB, int EPB>
 static void launch_step_epb(const navsim* h, const float* action, const float* past, void* obs, float* reward,
@@ -748,8 +786,6 @@ static void launch_step(const navsim* h, const float* action, const float* past,
                         uint8_t* done, uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len,
                         hipStream_t st) {
     switch (g_epb) {
-        case 64: launch_step_epb<NB, 64>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
-        case 32: launch_step_epb<NB, 32>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
         case 8: launch_step_epb<NB, 8>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
         default: launch_step_epb<NB, 16>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
     }
@@ -790,7 +826,7 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
 
     if (const char* e = std::getenv("NAVSIM_EPB")) {
         const int v = std::atoi(e);
-        if (v == 8 || v == 16 || v == 32 || v == 64) g_epb = v;
+        if (v == 8 || v == 16) g_epb = v;
     }
     navsim* h = new navsim();
     h->cfg = *cfg;
