@@ -44,7 +44,7 @@ def _event_time_ms(fn, iters, warm=20, per_graph=64):
         fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         for _ in range(per_graph):
             fn()
     g.replay()

@@ -343,7 +343,9 @@ class PPOTrainer:
                 torch.cuda.synchronize()
                 self.env.sim.reset(self.obs_buf[0])
                 self._graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph):
+                # thread_local: other threads (the RCCL watchdog of torch.distributed) may touch the HIP runtime while
+                # this thread captures; the default global mode would turn that into a capture error on multi-GPU runs
+                with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                     self._rollout_body()
             self._graph.replay()
         else:

@@ -32,5 +32,6 @@ os.makedirs(os.path.join(R, "build"), exist_ok=True)
 open("/tmp/navsim_timing.hip", "w").write(t)
 out = os.path.join(R, "build", "libnavsim_timing.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                       "-fvisibility=hidden", "-I", os.path.join(R, "include"), "/tmp/navsim_timing.hip", "-o", out])
+                       "-fvisibility=hidden", "-I", os.path.join(R, "include"), "/tmp/navsim_timing.hip",
+                       os.path.join(R, "navbot_ppo_amd/csrc/ppo_mlp64.hip"), "-o", out])
 print(out)
