@@ -187,8 +187,9 @@ class PPOUpdater:
             assert self.fp.numel == 5378 + 5313
             self._ws = torch.empty(lib().navppo_mlp64_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
             self._fstats = torch.zeros(8, dtype=torch.float32, device=self.device)
+            self._fhist = torch.zeros((max(cfg.n_updates_per_iteration, 1), 8), dtype=torch.float32, device=self.device)
 
-    def _fused_loss_grad(self, obs, acts, logp_old, rtg, adv, var):
+    def _fused_loss_grad(self, obs, acts, logp_old, rtg, adv, var, stats=None):
         """evaluate + losses + backward of ppo.py:307-386 in the HIP kernels of csrc/ppo_mlp64.hip; gradients land
         in the flat gradient buffer, (actor_loss, approx_kl, clip_frac, -, critic_loss) in self._fstats."""
         import ctypes as C
@@ -199,7 +200,8 @@ class PPOUpdater:
             assert t.is_contiguous() and t.dtype == torch.float32
         rc = L.navppo_mlp64_loss_grad(ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
                                       int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad),
-                                      ptr(self._fstats), ptr(self._ws), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                      ptr(self._fstats if stats is None else stats), ptr(self._ws),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise RuntimeError(f"navppo_mlp64_loss_grad failed: {L.navppo_last_error().decode()}")
 
@@ -215,17 +217,22 @@ class PPOUpdater:
         var_f = float(var) if self.fused_mlp64 else None
         if self.fused_mlp64:
             obs, acts, logp_old, rtg, adv = (t.contiguous() for t in (obs, acts, logp_old, rtg, adv))
+            if self._fhist.shape[0] < n_ep:
+                self._fhist = torch.zeros((n_ep, 8), dtype=torch.float32, device=self.device)
         for ep in range(n_ep):                                 # ppo.py:305
             if self.fused_mlp64:
-                self._fused_loss_grad(obs, acts, logp_old, rtg, adv, var_f)
+                # per-epoch diagnostics land in row ep of a device buffer: no extra launches inside the epoch loop
+                self._fused_loss_grad(obs, acts, logp_old, rtg, adv, var_f, stats=self._fhist[ep])
                 if world > 1:
                     ctx.all_reduce_sum(self.fp.grad)
                     self.fp.grad.div_(world)
                 self.opt.step()
-                f = self._fstats
-                self.loss_history[ep] = torch.stack([f[0], f[4]])
-                acc += torch.stack([f[0], f[4], f[1], f[2], self.fp.grad.norm(), V0.mean()])
-                a_loss, c_loss = f[0].clone(), f[4].clone()
+                if ep == n_ep - 1:
+                    h = self._fhist[:n_ep]
+                    self.loss_history = h[:, [0, 4]].clone()
+                    acc = torch.stack([h[:, 0].sum(), h[:, 4].sum(), h[:, 1].sum(), h[:, 2].sum(),
+                                       self.fp.grad.norm() * n_ep, V0.mean() * n_ep])
+                    a_loss, c_loss = h[-1, 0].clone(), h[-1, 4].clone()
                 continue
             a_loss, c_loss, ratios, logp, _ = ppo_losses(self.actor, self.critic, obs, acts, logp_old, rtg, adv, var, cfg.clip)
             self.fp.grad.zero_()
