@@ -452,3 +452,48 @@ def test_cfg5_house_map_f16_sampler_parity():
     sg, sc = gpu.get_state(), cpu.get_state()
     np.testing.assert_array_equal(sg["goal"], sc["goal"])
     np.testing.assert_allclose(sg["pose"], sc["pose"], atol=1e-11)
+
+
+def test_cfg1_single_env_scripted_tape():
+    """BASELINE configs[0] / SURVEY 8d cfg 1: ONE env on stage_1, a 1000-step scripted action tape from
+    np.random.default_rng(0), goals drawn from default_rng(1) through the reset-rejection rule and injected; the GPU
+    path (N=1 is a single lane of a single workgroup) against the CPU oracle step by step, flags bit-exact."""
+    from navbot_ppo_amd.env import NavSim
+    tape = np.random.default_rng(0)
+    goals = np.random.default_rng(1)
+
+    def next_goal():
+        while True:
+            g = goals.uniform(-3.6, 3.6, 2)
+            if not O.goal_rejected(0, g[0], g[1]):
+                return g
+
+    gpu = NavSim(1, max_episode_steps=500, auto_reset=False, seed=0)
+    cpu = O.OracleSim(1, max_episode_steps=500, auto_reset=False, seed=0)
+    for s in (gpu, cpu):
+        s.set_map(maps.stage_1())
+    io = gpu.alloc_io()
+
+    def reset_both():
+        gpu.reset(io.obs)
+        cpu.reset()
+        g = next_goal()[None, :]
+        pd = np.hypot(g[:, 0], g[:, 1])
+        gpu.set_state(goal=g, past_dist=pd)
+        cpu.set_state(goal=g, past_dist=pd)
+
+    reset_both()
+    n_eps = n_exact = 0
+    for k in range(1000):
+        a = np.array([[tape.uniform(0, 1), tape.uniform(-1, 1)]], dtype=np.float32)
+        gpu.step(torch.from_numpy(a).cuda(), io.obs, io.reward, io.done, io.arrive, io.ended)
+        out = cpu.step(a)
+        og = io.obs.cpu().numpy()
+        np.testing.assert_allclose(og, out["obs"], rtol=0, atol=OBS_ATOL)
+        assert abs(io.reward.item() - out["reward"][0]) <= 1e-5 * max(1.0, abs(out["reward"][0]))
+        assert (io.done.item(), io.arrive.item(), io.ended.item()) == (out["done"][0], out["arrive"][0], out["ended"][0])
+        n_exact += int(np.array_equal(og, out["obs"]))
+        if out["ended"][0]:
+            n_eps += 1
+            reset_both()
+    assert n_eps >= 3 and n_exact >= 990
