@@ -81,7 +81,8 @@ __global__ __launch_bounds__(4 * PT) void mlp64_pass(const float* __restrict__ p
                                                            const float* __restrict__ act, const float* __restrict__ logp_old,
                                                            const float* __restrict__ rtg, const float* __restrict__ adv,
                                                            long long M, float var, float clip, float inv_n,
-                                                           float* __restrict__ partial, float* __restrict__ stats_partial) {
+                                                           float* __restrict__ partial, float* __restrict__ stats_partial,
+                                                           float* __restrict__ grad_zero, float* __restrict__ stats_zero) {
     constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
     constexpr int NT = 4 * PT;       // threads
     constexpr int NW = NT / 64;      // waves: PT/32 row strips x 2 column tiles
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(4 * PT) void mlp64_pass(const float* __restrict__ p
     const int l31 = lane & 31, lhi = lane >> 5;
     const int strip = wave >> 1, ct = wave & 1;  // F1/F2/B2: 32-row strip and 32-column tile owned by this wave
 
+    if (blockIdx.x == 0) {  // the reduction that follows this launch accumulates with atomics: clear its targets here
+        for (int k = tid; k < P; k += NT) grad_zero[k] = 0.f;
+        if (tid < 3) stats_zero[tid] = 0.f;
+    }
     // ---- weights -> LDS (once per workgroup)
     for (int k = tid; k < H * IN; k += NT) sm.W1[(k / IN) * LDX + (k % IN)] = params[OFF_W1 + k];
     for (int k = tid; k < H * H; k += NT) sm.W2[(k / H) * LDH + (k % H)] = params[OFF_W2 + k];
@@ -339,30 +344,35 @@ __global__ __launch_bounds__(4 * PT) void mlp64_pass(const float* __restrict__ p
     if (tid < 3) stats_partial[blockIdx.x * 4 + tid] = red[P + tid];
 }
 
-// grad[p] = sum over workgroups ; stats = sums * inv_n.  Block = 64 parameters x 4 row groups; rows are read 256 B per wave.
+// grad[p] += sum over a slice of the workgroups' partial rows ; stats += slice sums * inv_n.  grid = (P/64, kRedSlices):
+// block = 64 parameters x 4 row groups of one slice; rows are read 256 B per wave; one atomicAdd per parameter per slice
+// (grad / stats were zeroed by workgroup 0 of the pass kernel that produced the partials).
+constexpr int kRedSlices = 8;
+
 __global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ partial, const float* __restrict__ stats_partial,
                                                        int n_blocks, int P, float inv_n, float* __restrict__ grad,
-                                                       float* __restrict__ stats, int stats_off) {
+                                                       float* __restrict__ stats) {
     __shared__ float part[4][64];
     const int p = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int per = (n_blocks + kRedSlices - 1) / kRedSlices;
+    const int b_lo = blockIdx.y * per, b_hi = min(n_blocks, b_lo + per);
+    float s0 = 0.f, s1 = 0.f;
     if (p < P) {
-        int b = g;
-        for (; b + 12 < n_blocks; b += 16) {
+        int b = b_lo + g;
+        for (; b + 4 < b_hi; b += 8) {
             s0 += partial[(size_t)b * P + p];
             s1 += partial[(size_t)(b + 4) * P + p];
-            s2 += partial[(size_t)(b + 8) * P + p];
-            s3 += partial[(size_t)(b + 12) * P + p];
         }
-        for (; b < n_blocks; b += 4) s0 += partial[(size_t)b * P + p];
+        if (b < b_hi) s0 += partial[(size_t)b * P + p];
     }
-    part[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    part[g][threadIdx.x & 63] = s0 + s1;
     __syncthreads();
-    if (g == 0 && p < P) grad[p] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (g == 0 && p < P)
+        atomicAdd(&grad[p], (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
     if (blockIdx.x == 0 && threadIdx.x < 3) {
         float s = 0.f;
-        for (int b = 0; b < n_blocks; ++b) s += stats_partial[b * 4 + threadIdx.x];
-        stats[stats_off + threadIdx.x] = s * inv_n;
+        for (int b = b_lo; b < b_hi; ++b) s += stats_partial[b * 4 + threadIdx.x];
+        atomicAdd(&stats[threadIdx.x], s * inv_n);
     }
 }
 
@@ -506,13 +516,14 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
     float* stats_partial = partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * NAVPPO_MLP64_ACTOR_PARAMS;
     const float inv_n = 1.0f / (float)n_samples;
     hipLaunchKernelGGL((mlp64_pass<true, kPassTile>), dim3(blocks), dim3(kPassThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
-                       rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial);
-    hipLaunchKernelGGL(reduce_partials, dim3((P_ACTOR + 63) / 64), dim3(256), 0, st, partial, stats_partial, blocks, P_ACTOR,
-                       inv_n, grad_dev, stats_dev, 0);
+                       rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, grad_dev, stats_dev);
+    hipLaunchKernelGGL(reduce_partials, dim3((P_ACTOR + 63) / 64, kRedSlices), dim3(256), 0, st, partial, stats_partial, blocks,
+                       P_ACTOR, inv_n, grad_dev, stats_dev);
     hipLaunchKernelGGL((mlp64_pass<false, kPassTile>), dim3(blocks), dim3(kPassThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
-                       logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial);
-    hipLaunchKernelGGL(reduce_partials, dim3((P_CRITIC + 63) / 64), dim3(256), 0, st, partial, stats_partial, blocks, P_CRITIC,
-                       inv_n, grad_dev + P_ACTOR, stats_dev, 4);
+                       logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial,
+                       grad_dev + P_ACTOR, stats_dev + 4);
+    hipLaunchKernelGGL(reduce_partials, dim3((P_CRITIC + 63) / 64, kRedSlices), dim3(256), 0, st, partial, stats_partial, blocks,
+                       P_CRITIC, inv_n, grad_dev + P_ACTOR, stats_dev + 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_loss_grad: ") + hipGetErrorString(e);
