@@ -11,7 +11,9 @@ INC = os.path.join(REPO, "include")
 LIB = os.path.join(HERE, "libnavsim.so")
 
 # -ffp-contract=off: the arithmetic contract writes every fused multiply-add explicitly
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+# -fno-slp-vectorize: packed f32 ops (v_pk_fma_f32 ...) issue at half rate on gfx950, so SLP-packing the ray tests buys
+# nothing and costs register-pairing moves (measured: step kernel 28.8 -> 27.1 us)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
                "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
