@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NAVSIM_ABI_VERSION 1
+#define NAVSIM_ABI_VERSION 2
 
 #define NAVSIM_OK 0
 #define NAVSIM_E_ARG (-1)   /* bad argument / unsupported configuration */
@@ -54,6 +54,12 @@ typedef struct navsim_cfg {
     int32_t auto_reset;        /* 1: envs that end are reset inside step (ppo.py:582-593) and obs is the post-reset obs */
     int32_t respawn_on_arrive; /* 1: on arrival draw a new goal + re-base past_distance (environment_new.py:245-267) */
     int32_t obs_f16;           /* 1: obs buffers are IEEE half instead of float */
+    int32_t lidar_below_min;   /* readings under range_min 0.12 m: 0 = clamp to 0.12 (default), 1 = -inf as Gazebo's ray sensor
+                                  reports them; the reference passes -inf through unsanitised, which also suppresses the
+                                  collision flag (environment_new.py:192-201) */
+    float lidar_noise_sigma;   /* Gaussian range noise of the sensor (turtlebot3_burger.gazebo.xacro:122-126: 0.01); 0 = off
+                                  (default, needed for bit-parity runs).  Applied to in-range readings, then clamped to
+                                  [0.12, 3.5]; Philox keyed by (seed, env id, goal draws, episode step, beam) + Box-Muller */
     uint64_t seed;             /* Philox key */
     uint64_t env_id_base;      /* global id of env 0: RNG streams are keyed by (seed, env_id_base + i) */
     double threshold_arrive;

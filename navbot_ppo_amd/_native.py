@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnavsim.so")
 
-NAVSIM_ABI_VERSION = 1
+NAVSIM_ABI_VERSION = 2
 
 
 class NavsimError(RuntimeError):
@@ -21,6 +21,8 @@ class NavsimCfg(C.Structure):
         ("auto_reset", C.c_int32),
         ("respawn_on_arrive", C.c_int32),
         ("obs_f16", C.c_int32),
+        ("lidar_below_min", C.c_int32),
+        ("lidar_noise_sigma", C.c_float),
         ("seed", C.c_uint64),
         ("env_id_base", C.c_uint64),
         ("threshold_arrive", C.c_double),

@@ -69,7 +69,8 @@ struct Rects {
 };
 
 struct Params {
-    int N, B, S, per_env, max_ep_steps, auto_reset, respawn, obs_f16;
+    int N, B, S, per_env, max_ep_steps, auto_reset, respawn, obs_f16, below_min_mode;
+    float sigma;  // LiDAR range noise (0 = off)
     uint32_t key0, key1;
     uint64_t env_id_base;
     double thr, spawn_x, spawn_y, spawn_yaw, goal_lo, goal_hi, diag;
@@ -78,7 +79,7 @@ struct Params {
     int32_t* ep_step;
     uint32_t* rng_ctr;
     const float4* seg;        // [S] or [N][S]
-    const float* spawn_scan;  // [K][B] or [N][K][B] raw ranges at the K start poses (K = 1: the cfg spawn pose)
+    const float* spawn_scan;  // [K][B] or [N][K][B] nearest hits (+inf = none) at the K start poses (K = 1: the cfg spawn pose)
     const double* starts;     // [K][3] start poses (x, y, yaw)
     const double* goals;      // [G][2] goal points; G == 0: uniform goal box + rejection rectangles
     int K, G;
@@ -171,11 +172,16 @@ __device__ __forceinline__ float ray_seg(float rx, float ry, float ex, float ey,
     return (pos || neg) ? (k / den) : INFINITY;
 }
 
-// raw LaserScan value from the nearest hit: >= max -> +inf, < min -> min (gazebo.xacro:117-120)
-__device__ __forceinline__ float scan_value(float best) {
+// LaserScan value from the nearest hit `best` (+inf if none), gazebo.xacro:117-126:
+//   >= range_max -> +inf ; < range_min -> range_min (mode 0) or -inf (mode 1, Gazebo's ray sensor) ;
+//   otherwise best + sigma * n clamped to [range_min, range_max]  (n = 0 when the noise is off)
+__device__ __forceinline__ float sensor_value(float best, float sigma, float n, int below_min_mode) {
     if (!(best < kRangeMax)) return INFINITY;
-    return best < kRangeMin ? kRangeMin : best;
+    if (best < kRangeMin) return below_min_mode ? -INFINITY : kRangeMin;
+    const float r = fmaf(sigma, n, best);
+    return fminf(fmaxf(r, kRangeMin), kRangeMax);
 }
+__device__ __forceinline__ float scan_value(float best) { return sensor_value(best, 0.f, 0.f, 0); }
 
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
@@ -201,6 +207,20 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         k1 += 0xBB67AE85u;
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Standard-normal draw for LiDAR beam b of env `gid` at (goal draws so far, episode step): Philox4x32-10, one call per
+// four beams, Box-Muller in float32.
+__device__ __forceinline__ float lidar_noise(uint32_t k0, uint32_t k1, uint64_t gid, uint32_t ctr, uint32_t ep_step, int b) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), ctr, 0x4C000000u | ((ep_step & 0xFFFFu) << 8) | (uint32_t)(b >> 2),
+                  k0, k1, r);
+    const int pr = (b >> 1) & 1;
+    const float u1 = ((float)(r[2 * pr] >> 8) + 1.0f) * 0x1.0p-24f;  // (0, 1]
+    const float u2 = (float)(r[2 * pr + 1] >> 8) * 0x1.0p-24f;       // [0, 1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    const float ang = 6.283185307179586f * u2;
+    return (b & 1) ? rad * sinf(ang) : rad * cosf(ang);
 }
 
 __device__ __forceinline__ bool goal_rejected(const Rects* R, int which, double gx, double gy) {
@@ -256,16 +276,16 @@ __device__ __forceinline__ void sample_episode(const Params& P, int i, uint32_t&
     }
 }
 
-// Observation row (environment_new.py:289-301) into an LDS row of stride-1 floats.
-// `ranges` holds raw scan values for this env with element stride `rstride`.
-// Returns min(sanitised scan) for the collision rule (:200).
-__device__ __forceinline__ float write_obs_row(float* row, const float* ranges, int rstride, int B,
-                                               float pa0, float pa1, double dist, double yaw,
-                                               double rel_theta, double diff, double diag) {
+// Observation row (environment_new.py:289-301) into a row of stride-1 floats.
+// `best` holds this env's NEAREST HITS (raw, +inf if none) with element stride `bstride`; `noise` (nullable) the
+// per-beam standard-normal draws with stride `nstride`.  Returns min(sanitised scan) for the collision rule (:200).
+__device__ __forceinline__ float write_obs_row(float* row, const float* best, int bstride, const float* noise, int nstride,
+                                               float sigma, int below_min_mode, int B, float pa0, float pa1, double dist,
+                                               double yaw, double rel_theta, double diff, double diag) {
     float mn = INFINITY;
     for (int b = 0; b < B; ++b) {
-        float r = ranges[b * rstride];
-        if (r == INFINITY) r = 3.5f;  // :193-194 (NaN / -inf cannot occur: scan_value())
+        float r = sensor_value(best[b * bstride], sigma, noise ? noise[b * nstride] : 0.f, below_min_mode);
+        if (r == INFINITY) r = 3.5f;  // :193-194 (+inf only: -inf passes through like in the reference; NaN cannot occur)
         mn = r < mn ? r : mn;
         // (float)((double)r / 3.5) == r / 3.5f : double rounding is innocuous for a quotient of
         // two float32 values (53 >= 2*24+2), so the float32 divide gives the reference's bits.
@@ -286,6 +306,7 @@ struct StepSmem {
     float2 dir[NB * EPB];        // [beam][env] unit direction
     unsigned rng[NB * EPB];      // [beam][env] nearest hit as float bits (non-negative floats order like uints)
     float obs[EPB * (NB + 7)];   // [env][B+6 (+1 pad: odd row stride, conflict-free)] the block's output tile
+    float noise[NB * EPB];     // [beam][env] standard-normal draws for the range noise (only written when sigma > 0)
     double sc[EPB][8][2];  // pose phase: (cos, sin) of the 6 substep angles, of theta and of theta/2, one per lane
     // pose-wave values parked here while wave 0 ray-casts (keeps the kernel under 128 VGPRs = 4 blocks per CU)
     double sv_d[11][EPB];
@@ -412,12 +433,12 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             if (el_pose < nloc) {
                 th = P.th[i];
                 act = action[i];
+                ctr = P.rng_ctr[i];
+                step0 = P.ep_step[i];
                 if (rr == 0) {
                     x = P.x[i]; y = P.y[i];
                     gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
                     pact = past_override ? past_override[i] : P.past_action[i];
-                    ctr = P.rng_ctr[i];
-                    step0 = P.ep_step[i];
                     ret0 = P.ep_ret[i];
                 }
                 // environment_new.py:273-278
@@ -478,6 +499,11 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     }
     __syncthreads();  // barrier A: origins / directions / first segment tile visible
 
+    if (P.sigma > 0.f && pose_lane && el_pose < nloc) {
+        // range noise for this step: lane rr draws beams rr, rr + 8, ... (off the critical path: the others ray-cast)
+        for (int b = rr; b < B; b += 8)
+            sm.noise[b * EPB + el_pose] = lidar_noise(P.key0, P.key1, P.env_id_base + (uint64_t)i, ctr, (uint32_t)step0, b);
+    }
     if (own) {
         // ---------------- pose lanes, part 2 (the other waves are already ray-casting): goal geometry
         goal_angles_q(x, y, sm.sc[el_pose][7][1], sm.sc[el_pose][7][0], gx, gy, yaw, rel_theta, diff);
@@ -591,19 +617,10 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         diff = sm.sv_d[9][e]; ret0 = sm.sv_d[10][e];
         act = sm.sv_act[e]; pact = sm.sv_pact[e]; ctr = sm.sv_ctr[e]; step0 = sm.sv_step[e];
         float* row = sm.obs + e * DP;
-        float mn = INFINITY;
-        for (int b = 0; b < B; ++b) {
-            float r = scan_value(__uint_as_float(sm.rng[b * EPB + e]));
-            if (r == INFINITY) r = 3.5f;  // environment_new.py:193-194
-            mn = r < mn ? r : mn;
-            row[b] = r / 3.5f;            // :289 (see write_obs_row on the float32 divide)
-        }
-        row[B + 0] = pact.x;              // :299-300
-        row[B + 1] = pact.y;
-        row[B + 2] = (float)(dist / P.diag);  // :301
-        row[B + 3] = (float)(yaw / 360);
-        row[B + 4] = (float)(rel_theta / 360);
-        row[B + 5] = (float)(diff / 180);
+        const float* noise = (P.sigma > 0.f) ? sm.noise + e : nullptr;
+        // nearest hits are held as uint bit patterns of non-negative floats (inf = no hit)
+        const float mn = write_obs_row(row, reinterpret_cast<const float*>(sm.rng) + e, EPB, noise, EPB, P.sigma, P.below_min_mode, B,
+                                       pact.x, pact.y, dist, yaw, rel_theta, diff, P.diag);
         const bool d = (0.2 > (double)mn) && ((double)mn > 0);  // environment_new.py:200
         const bool a = dist <= P.thr;                             // :204
         // setReward, :209-222
@@ -639,7 +656,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             dist = hypot(gx - x, gy - y);
             pdist = dist;  // getGoalDistace, :116-120,:359
             const float* sp = P.spawn_scan + ((PER_ENV ? (size_t)i * P.K : 0) + k0) * B;
-            write_obs_row(row, sp, 1, B, 0.f, 0.f, dist, yaw, rel_theta, diff, P.diag);
+            write_obs_row(row, sp, 1, noise, EPB, P.sigma, P.below_min_mode, B, 0.f, 0.f, dist, yaw, rel_theta, diff, P.diag);
         }
         P.x[i] = x; P.y[i] = y; P.th[i] = th;
         P.gx[i] = gx; P.gy[i] = gy; P.past_dist[i] = pdist;
@@ -674,24 +691,23 @@ __global__ void reset_kernel(Params P, const uint8_t* __restrict__ mask, void* _
     const double x = P.starts[3 * k0], y = P.starts[3 * k0 + 1], th = P.starts[3 * k0 + 2];
     goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
     const double dist = hypot(gx - x, gy - y);
-    const float* sp = P.spawn_scan + ((P.per_env ? (size_t)i * P.K : 0) + k0) * B;
-    // row assembled straight in global memory for the f32 case, via registers for f16
+    const float* sp = P.spawn_scan + ((P.per_env ? (size_t)i * P.K : 0) + k0) * B;  // nearest hits at the start pose
+    const uint64_t gid = P.env_id_base + (uint64_t)i;
+    auto lidar = [&](int b) {
+        const float n = (P.sigma > 0.f) ? lidar_noise(P.key0, P.key1, gid, ctr, 0xFFFFu, b) : 0.f;
+        float r = sensor_value(sp[b], P.sigma, n, P.below_min_mode);
+        if (r == INFINITY) r = 3.5f;  // environment_new.py:193-194
+        return r / 3.5f;              // :362
+    };
+    const float tail[6] = {0.f, 0.f, (float)(dist / P.diag), (float)(yaw / 360), (float)(rel_theta / 360), (float)(diff / 180)};
     if (P.obs_f16) {
         __half* o = reinterpret_cast<__half*>(obs_out) + (size_t)i * D;
-        for (int b = 0; b < B; ++b) {
-            float r = sp[b];
-            if (r == INFINITY) r = 3.5f;
-            o[b] = __float2half_rn(r / 3.5f);
-        }
-        o[B] = __float2half_rn(0.f);
-        o[B + 1] = __float2half_rn(0.f);
-        o[B + 2] = __float2half_rn((float)(dist / P.diag));
-        o[B + 3] = __float2half_rn((float)(yaw / 360));
-        o[B + 4] = __float2half_rn((float)(rel_theta / 360));
-        o[B + 5] = __float2half_rn((float)(diff / 180));
+        for (int b = 0; b < B; ++b) o[b] = __float2half_rn(lidar(b));
+        for (int k = 0; k < 6; ++k) o[B + k] = __float2half_rn(tail[k]);
     } else {
         float* o = reinterpret_cast<float*>(obs_out) + (size_t)i * D;
-        write_obs_row(o, sp, 1, B, 0.f, 0.f, dist, yaw, rel_theta, diff, P.diag);
+        for (int b = 0; b < B; ++b) o[b] = lidar(b);
+        for (int k = 0; k < 6; ++k) o[B + k] = tail[k];
     }
     P.x[i] = x; P.y[i] = y; P.th[i] = th;
     P.gx[i] = gx; P.gy[i] = gy; P.past_dist[i] = dist;
@@ -706,7 +722,7 @@ __global__ void reset_kernel(Params P, const uint8_t* __restrict__ mask, void* _
 //   spawn scans:  n_poses_per_env = K, shared_poses = 1 : pose table [K][3] reused by every env
 //   navsim_raycast: n_poses_per_env = 1, shared_poses = 0 : pose[t]
 __global__ void raycast_kernel(Params P, const double* __restrict__ pose, int n_poses_per_env, int shared_poses, int n,
-                               float* __restrict__ ranges) {
+                               int raw, float* __restrict__ ranges) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int env = t / n_poses_per_env;
@@ -728,7 +744,8 @@ __global__ void raycast_kernel(Params P, const double* __restrict__ pose, int n_
             const float tt = ray_seg(rx, ry, ex, ey, k, c, s);
             best = tt < best ? tt : best;
         }
-        ranges[(size_t)t * P.B + b] = scan_value(best);
+        // raw: the nearest hit itself (spawn-scan table, noise is applied when it is used); else the noise-free scan value
+        ranges[(size_t)t * P.B + b] = raw ? best : sensor_value(best, 0.f, 0.f, P.below_min_mode);
     }
 }
 
@@ -820,6 +837,7 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
     if (cfg->n_beams != 10 && cfg->n_beams != 36)
         return fail(NAVSIM_E_ARG, "navsim_create: n_beams must be 10 or 36");
     if (!(cfg->goal_hi > cfg->goal_lo)) return fail(NAVSIM_E_ARG, "navsim_create: empty goal box");
+    if (!(cfg->lidar_noise_sigma >= 0.f)) return fail(NAVSIM_E_ARG, "navsim_create: negative lidar_noise_sigma");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(NAVSIM_E_HIP, "navsim_create: no HIP device (there is no CPU path)");
@@ -854,6 +872,8 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
     P.auto_reset = cfg->auto_reset;
     P.respawn = cfg->respawn_on_arrive;
     P.obs_f16 = cfg->obs_f16;
+    P.below_min_mode = cfg->lidar_below_min ? 1 : 0;
+    P.sigma = cfg->lidar_noise_sigma;
     P.key0 = (uint32_t)cfg->seed;
     P.key1 = (uint32_t)(cfg->seed >> 32);
     P.env_id_base = cfg->env_id_base;
@@ -927,7 +947,7 @@ static int rebuild_spawn_scans(navsim* h, hipStream_t st) {
     HIP_TRY(hipMalloc(&h->spawn_scan_dev, n_poses * P.B * sizeof(float)));
     P.spawn_scan = h->spawn_scan_dev;
     hipLaunchKernelGGL(raycast_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, st, P, h->starts_dev, P.K, 1,
-                       (int)n_poses, h->spawn_scan_dev);
+                       (int)n_poses, 1, h->spawn_scan_dev);
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;
 }
@@ -1000,7 +1020,7 @@ int navsim_raycast(navsim_t* h, const double* pose_dev, float* ranges_dev, void*
     if (!h || !pose_dev || !ranges_dev) return fail(NAVSIM_E_ARG, "navsim_raycast: bad argument");
     if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_raycast: call navsim_set_map first");
     hipLaunchKernelGGL(raycast_kernel, dim3((h->P.N + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->P, pose_dev, 1, 0,
-                       h->P.N, ranges_dev);
+                       h->P.N, 0, ranges_dev);
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;
 }

@@ -39,14 +39,15 @@ class NavSim:
 
     def __init__(self, n_envs, n_beams=10, max_episode_steps=0, auto_reset=False, respawn_on_arrive=False,
                  seed=0, env_id_base=0, threshold_arrive=0.2, spawn=(0.0, 0.0, 0.0), goal_box=(-3.6, 3.6),
-                 obs_f16=False, device=None):
+                 obs_f16=False, device=None, lidar_below_min="clamp", lidar_noise_sigma=0.0):
         if not torch.cuda.is_available():
             raise NavsimError("navbot_ppo_amd needs a HIP device (MI355X); there is no CPU path")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.N, self.B, self.D = int(n_envs), int(n_beams), int(n_beams) + 6
         self.obs_dtype = torch.float16 if obs_f16 else torch.float32
         self.cfg = NavsimCfg(self.N, self.B, int(max_episode_steps), int(bool(auto_reset)), int(bool(respawn_on_arrive)),
-                             int(bool(obs_f16)), int(seed), int(env_id_base), float(threshold_arrive),
+                             int(bool(obs_f16)), {"clamp": 0, "gazebo": 1}[lidar_below_min], float(lidar_noise_sigma),
+                             int(seed), int(env_id_base), float(threshold_arrive),
                              float(spawn[0]), float(spawn[1]), float(spawn[2]), float(goal_box[0]), float(goal_box[1]))
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -170,11 +171,13 @@ class VecEnv:
     """
 
     def __init__(self, n_envs, map="stage_1", n_beams=10, max_episode_steps=500, auto_reset=True, is_training=True,
-                 seed=0, env_id_base=0, per_env_map=False, map_seed=0, obs_f16=False, device=None, sampler=None):
+                 seed=0, env_id_base=0, per_env_map=False, map_seed=0, obs_f16=False, device=None, sampler=None,
+                 lidar_below_min="clamp", lidar_noise_sigma=0.0):
         thr = 0.2 if is_training else 0.4  # environment_new.py:44-47
         self.sim = NavSim(n_envs, n_beams=n_beams, max_episode_steps=max_episode_steps, auto_reset=auto_reset,
                           respawn_on_arrive=False, seed=seed, env_id_base=env_id_base, threshold_arrive=thr,
-                          obs_f16=obs_f16, device=device)
+                          obs_f16=obs_f16, device=device, lidar_below_min=lidar_below_min,
+                          lidar_noise_sigma=lidar_noise_sigma)
         self.N, self.B, self.D, self.device = self.sim.N, self.sim.B, self.sim.D, self.sim.device
         self.threshold_arrive = thr
         self.use_vision = False

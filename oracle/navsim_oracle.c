@@ -264,7 +264,9 @@ typedef struct orc_cfg {
     int32_t max_episode_steps; /* 0 = no timeout (ppo.py:552) */
     int32_t auto_reset;        /* masked in-step reset, ppo.py:591-593 */
     int32_t respawn_on_arrive; /* environment_new.py:245-267 */
-    int32_t reserved;
+    int32_t obs_f16;           /* unused by the oracle (obs are float32); keeps the layout of navsim_cfg */
+    int32_t lidar_below_min;   /* 0 clamp to range_min, 1 -inf (Gazebo) */
+    float lidar_noise_sigma;   /* 0 = off */
     uint64_t seed;
     uint64_t env_id_base; /* global id of env 0 (multi-GPU shards) */
     double threshold_arrive; /* environment_new.py:44-47 */
@@ -424,8 +426,8 @@ static void sample_goal(orc_sim* s, int i, int which) {
  * f64 pose -> f32 origin and directions, then f32 tests (explicit fmaf), t = k/den
  * correctly rounded, range = min over hits.  Out-of-range handling per
  * gazebo.xacro:117-120: >= max -> +inf ; < min -> clamped to min ("clamp" mode). */
-ORC_API void orc_raycast(const float* seg, int S, double x, double y, double th,
-                         const double* beam_cos, const double* beam_sin, int B, float* ranges) {
+static void raycast_best(const float* seg, int S, double x, double y, double th, const double* beam_cos,
+                         const double* beam_sin, int B, float* best_out) {
     double cth = cos(th), sth = sin(th);
     double ox = x + LIDAR_X * cth;
     double oy = y + LIDAR_X * sth;
@@ -454,15 +456,39 @@ ORC_API void orc_raycast(const float* seg, int S, double x, double y, double th,
                 if (t < best) best = t;
             }
         }
-        float r;
-        if (!(best < RANGE_MAX))
-            r = INFINITY;
-        else if (best < RANGE_MIN)
-            r = RANGE_MIN;
-        else
-            r = best;
-        ranges[b] = r;
+        best_out[b] = best;
     }
+}
+
+/* gazebo.xacro:117-126: >= max -> +inf ; < min -> min (mode 0) or -inf (mode 1) ; else best + sigma*n clamped to [min,max] */
+static float sensor_value(float best, float sigma, float n, int below_min_mode) {
+    if (!(best < RANGE_MAX)) return INFINITY;
+    if (best < RANGE_MIN) return below_min_mode ? -INFINITY : RANGE_MIN;
+    float r = fmaf(sigma, n, best);
+    return fminf(fmaxf(r, RANGE_MIN), RANGE_MAX);
+}
+
+/* standard normal for beam b: Philox per four beams + Box-Muller in float32 (same counter layout as the kernel) */
+static float lidar_noise(const orc_cfg* c, uint64_t gid, uint32_t ctr, uint32_t ep_step, int b) {
+    uint32_t key[2] = {(uint32_t)c->seed, (uint32_t)(c->seed >> 32)};
+    uint32_t cw[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), ctr, 0x4C000000u | ((ep_step & 0xFFFFu) << 8) | (uint32_t)(b >> 2)};
+    uint32_t r[4];
+    orc_philox4x32_10(cw, key, r);
+    int pr = (b >> 1) & 1;
+    float u1 = ((float)(r[2 * pr] >> 8) + 1.0f) * 0x1.0p-24f;
+    float u2 = (float)(r[2 * pr + 1] >> 8) * 0x1.0p-24f;
+    float rad = sqrtf(-2.0f * logf(u1));
+    float ang = 6.283185307179586f * u2;
+    return (b & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
+
+/* LiDAR: B rays from the sensor origin, nearest hit against the segment list.
+ * f64 pose -> f32 origin and directions, then f32 tests (explicit fmaf), t = k/den
+ * correctly rounded, range = min over hits.  Noise-free, clamp mode (the default sensor). */
+ORC_API void orc_raycast(const float* seg, int S, double x, double y, double th,
+                         const double* beam_cos, const double* beam_sin, int B, float* ranges) {
+    raycast_best(seg, S, x, y, th, beam_cos, beam_sin, B, ranges);
+    for (int b = 0; b < B; ++b) ranges[b] = sensor_value(ranges[b], 0.f, 0.f, 0);
 }
 
 static const float* env_seg(const orc_sim* s, int i) {
@@ -470,12 +496,17 @@ static const float* env_seg(const orc_sim* s, int i) {
 }
 
 /* observation for env i at its current pose; returns flags through pointers */
-static void observe(orc_sim* s, int i, const double past_action[2], float* obs_row, double* dist,
-                    int32_t* done, int32_t* arrive) {
+static void observe(orc_sim* s, int i, const double past_action[2], uint32_t noise_ctr, uint32_t noise_step,
+                    float* obs_row, double* dist, int32_t* done, int32_t* arrive) {
     int B = s->cfg.n_beams;
+    const orc_cfg* c = &s->cfg;
     float rf[256];
     double rd[256], scan[256], obs[256 + 6];
-    orc_raycast(env_seg(s, i), s->S, s->x[i], s->y[i], s->th[i], s->beam_cos, s->beam_sin, B, rf);
+    raycast_best(env_seg(s, i), s->S, s->x[i], s->y[i], s->th[i], s->beam_cos, s->beam_sin, B, rf);
+    for (int b = 0; b < B; ++b) {
+        float n = (c->lidar_noise_sigma > 0.f) ? lidar_noise(c, c->env_id_base + (uint64_t)i, noise_ctr, noise_step, b) : 0.f;
+        rf[b] = sensor_value(rf[b], c->lidar_noise_sigma, n, c->lidar_below_min);
+    }
     for (int b = 0; b < B; ++b) rd[b] = (double)rf[b];
     /* odom message as Gazebo would publish it: yaw-only quaternion */
     double qz = sin(s->th[i] / 2), qw = cos(s->th[i] / 2);
@@ -511,7 +542,9 @@ static int sample_tables(orc_sim* s, int i) {
     return k;
 }
 
-static void reset_env(orc_sim* s, int i, float* obs_row) {
+/* use_key: the in-step auto-reset re-uses the step's noise draws (noise_ctr, noise_step); an explicit reset keys its
+ * noise by (goal draws after sampling, 0xFFFF) */
+static void reset_env(orc_sim* s, int i, float* obs_row, int use_key, uint32_t noise_ctr, uint32_t noise_step) {
     int k = 0;
     if (s->G > 0)
         k = sample_tables(s, i);
@@ -527,7 +560,8 @@ static void reset_env(orc_sim* s, int i, float* obs_row) {
     double zero[2] = {0, 0};
     double dist;
     int32_t d, a;
-    observe(s, i, zero, obs_row, &dist, &d, &a);
+    if (!use_key) { noise_ctr = s->rng_ctr[i]; noise_step = 0xFFFFu; }
+    observe(s, i, zero, noise_ctr, noise_step, obs_row, &dist, &d, &a);
     s->past_dist[i] = dist; /* getGoalDistace :116-120, :359 */
 }
 
@@ -535,7 +569,7 @@ static void reset_env(orc_sim* s, int i, float* obs_row) {
 ORC_API void orc_sim_reset(orc_sim* s, const uint8_t* mask, float* obs) {
     int N = s->cfg.n_envs, D = s->cfg.n_beams + 6;
     for (int i = 0; i < N; ++i)
-        if (!mask || mask[i]) reset_env(s, i, obs + (size_t)i * D);
+        if (!mask || mask[i]) reset_env(s, i, obs + (size_t)i * D, 0, 0, 0);
 }
 
 /* one env step for all envs.  past_action_override: nullable [N][2] (Env.step(action, past_action)).
@@ -575,7 +609,8 @@ ORC_API void orc_sim_step(orc_sim* s, const float* action, const float* past_act
         }
         double dist;
         int32_t d, a;
-        observe(s, i, pa, obs + (size_t)i * D, &dist, &d, &a);
+        const uint32_t nz_ctr = s->rng_ctr[i], nz_step = (uint32_t)s->ep_step[i];
+        observe(s, i, pa, nz_ctr, nz_step, obs + (size_t)i * D, &dist, &d, &a);
         double r = orc_set_reward(&s->past_dist[i], dist, d, a);
         if (a && c->respawn_on_arrive) { /* environment_new.py:245-267 */
             sample_goal(s, i, 1);
@@ -595,6 +630,6 @@ ORC_API void orc_sim_step(orc_sim* s, const float* action, const float* past_act
         }
         s->past_action[2 * i] = action[2 * i]; /* ppo.py:543 */
         s->past_action[2 * i + 1] = action[2 * i + 1];
-        if (end && c->auto_reset) reset_env(s, i, obs + (size_t)i * D); /* ppo.py:582-593 */
+        if (end && c->auto_reset) reset_env(s, i, obs + (size_t)i * D, 1, nz_ctr, nz_step); /* ppo.py:582-593 */
     }
 }

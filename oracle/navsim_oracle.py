@@ -27,7 +27,9 @@ class OrcCfg(C.Structure):
         ("max_episode_steps", C.c_int32),
         ("auto_reset", C.c_int32),
         ("respawn_on_arrive", C.c_int32),
-        ("reserved", C.c_int32),
+        ("obs_f16", C.c_int32),
+        ("lidar_below_min", C.c_int32),
+        ("lidar_noise_sigma", C.c_float),
         ("seed", C.c_uint64),
         ("env_id_base", C.c_uint64),
         ("threshold_arrive", C.c_double),
@@ -175,9 +177,10 @@ class OracleSim:
     """Batched CPU simulator with the same call surface as the C-ABI (navsim.h)."""
 
     def __init__(self, n_envs, n_beams=10, max_episode_steps=0, auto_reset=False, respawn_on_arrive=False,
-                 seed=0, env_id_base=0, threshold_arrive=0.2, spawn=(0.0, 0.0, 0.0), goal_box=(-3.6, 3.6)):
+                 seed=0, env_id_base=0, threshold_arrive=0.2, spawn=(0.0, 0.0, 0.0), goal_box=(-3.6, 3.6),
+                 lidar_below_min="clamp", lidar_noise_sigma=0.0):
         self.cfg = OrcCfg(n_envs, n_beams, max_episode_steps, int(auto_reset), int(respawn_on_arrive), 0,
-                          seed, env_id_base, threshold_arrive, spawn[0], spawn[1], spawn[2], goal_box[0], goal_box[1])
+                          {"clamp": 0, "gazebo": 1}[lidar_below_min], float(lidar_noise_sigma), seed, env_id_base, threshold_arrive, spawn[0], spawn[1], spawn[2], goal_box[0], goal_box[1])
         self.N, self.B, self.D = n_envs, n_beams, n_beams + 6
         self._h = lib().orc_sim_create(C.byref(self.cfg))
 

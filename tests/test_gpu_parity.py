@@ -497,3 +497,34 @@ def test_cfg1_single_env_scripted_tape():
             n_eps += 1
             reset_both()
     assert n_eps >= 3 and n_exact >= 990
+
+
+def test_sensor_options_parity_noise_and_gazebo_below_min():
+    """lidar_noise_sigma / lidar_below_min on the GPU vs the oracle.  The noise goes through float32 logf/sinf/cosf whose
+    device and glibc versions may differ in the last ulp, so observations are compared at 1e-6; flags stay exact."""
+    rng = np.random.default_rng(51)
+    gpu, cpu = _mk(256, maps.stage_1(), max_episode_steps=30, auto_reset=True, seed=31, lidar_noise_sigma=0.01)
+    st = _lockstep(gpu, cpu, _actions(rng, 80, 256))
+    assert st["ended"] > 256
+    segp = maps.replicate_per_env(maps.stage_2(), 64, seed=6)
+    gpu, cpu = _mk(64, segp, per_env=True, max_episode_steps=20, auto_reset=True, seed=32, lidar_noise_sigma=0.02,
+                   lidar_below_min="gazebo")
+    _lockstep(gpu, cpu, _actions(rng, 50, 64))
+    # -inf readings: drive envs nose-first into the inner box; both sides must report -inf lidar and done == 0
+    gpu, cpu = _mk(8, maps.stage_1(), lidar_below_min="gazebo", seed=3)
+    io = gpu.alloc_io()
+    gpu.reset(io.obs)
+    cpu.reset()
+    pose = np.tile(np.array([[1.9 - 0.06 + 0.032, 0.0, 0.0]]), (8, 1))
+    pose[:, 1] = np.linspace(-0.5, 0.5, 8)
+    for s in (gpu, cpu):
+        s.set_state(pose=pose, goal=np.full((8, 2), 3.0), past_dist=np.full(8, 3.0))
+    a = np.zeros((8, 2), np.float32)
+    gpu.step(torch.from_numpy(a).cuda(), io.obs, io.reward, io.done, io.arrive, io.ended)
+    out = cpu.step(a)
+    og = io.obs.cpu().numpy()
+    assert np.isneginf(og[:, :10]).any() and not io.done.any()
+    np.testing.assert_array_equal(np.isneginf(og), np.isneginf(out["obs"]))
+    fin = np.isfinite(out["obs"])
+    np.testing.assert_allclose(og[fin], out["obs"][fin], atol=OBS_ATOL)
+    np.testing.assert_array_equal(io.done.cpu().numpy(), out["done"])

@@ -263,3 +263,45 @@ def test_table_sampler_rule_and_tables():
     s2 = sim.get_state()
     d2 = np.hypot(s2["pose"][:, 0] - s2["goal"][:, 0], s2["pose"][:, 1] - s2["goal"][:, 1])
     assert np.all((d2 >= 1.5) & (d2 <= 6.0)) and np.any(s2["goal"] != s["goal"])
+
+
+def test_sensor_options_noise_and_below_min():
+    """Optional sensor fidelity (gazebo.xacro:117-126): Gaussian range noise sigma=0.01 on in-range readings, and Gazebo's
+    -inf for readings under range_min, which the reference passes through unsanitised and which suppresses `done`
+    (environment_new.py:192-201)."""
+    seg = maps.stage_1()
+    N = 4000
+    clean = O.OracleSim(N, seed=3)
+    noisy = O.OracleSim(N, seed=3, lidar_noise_sigma=0.01)
+    for s in (clean, noisy):
+        s.set_map(seg)
+    o0, o1 = clean.reset(), noisy.reset()
+    d = (o1[:, :10] - o0[:, :10]) * 3.5
+    fin = o0[:, :10] < 1.0  # in-range beams only get noise
+    assert np.all(d[~fin] == 0) and abs(d[fin].mean()) < 5e-4 and abs(d[fin].std() - 0.01) < 5e-4
+    assert np.array_equal(o0[:, 10:], o1[:, 10:])  # goal geometry untouched, same goal stream
+    a = np.tile(np.array([[0.6, 0.1]], np.float32), (N, 1))
+    s0, s1 = clean.step(a), noisy.step(a)
+    d = (s1["obs"][:, :10] - s0["obs"][:, :10]) * 3.5
+    fin = s0["obs"][:, :10] < 1.0
+    assert abs(d[fin].std() - 0.01) < 5e-4 and np.abs(d).max() < 0.06
+    # successive steps draw fresh noise; two sims with the same seed agree exactly
+    s1b = noisy.step(a)
+    again = O.OracleSim(N, seed=3, lidar_noise_sigma=0.01)
+    again.set_map(seg)
+    again.reset()
+    np.testing.assert_array_equal(again.step(a)["obs"], s1["obs"])
+    assert not np.array_equal(s1b["obs"][:, :10], s1["obs"][:, :10])
+    # below range_min: clamp mode -> 0.12 and a collision; gazebo mode -> -inf and NO collision (reference quirk)
+    pose = np.array([[1.9 - 0.08 + 0.032, 0.0, 0.0]])
+    for mode, want_done in (("clamp", 1), ("gazebo", 0)):
+        s = O.OracleSim(1, seed=1, lidar_below_min=mode)
+        s.set_map(seg)
+        s.reset()
+        s.set_state(pose=pose, goal=np.array([[3.0, 3.0]]), past_dist=np.array([3.0]))
+        out = s.step(np.zeros((1, 2), np.float32))
+        assert out["done"][0] == want_done
+        if mode == "gazebo":
+            assert np.isneginf(out["obs"][0, :10]).any()
+        else:
+            assert np.isclose(out["obs"][0, :10].min(), 0.12 / 3.5, atol=1e-7)
