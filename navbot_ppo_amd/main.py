@@ -1,0 +1,121 @@
+"""Command-line entry with the reference's flags (project_ppo/src/arguments.py:22-46, main.py:423-499).
+
+    python -m navbot_ppo_amd.main --method_name baseline --steps_per_iteration 5000 --max_timesteps 100000
+    python -m navbot_ppo_amd.main --eval --eval_episodes 100 --method_name baseline
+    torchrun --nproc-per-node 8 -m navbot_ppo_amd.main --n_envs 32768 ...          # env shards + RCCL
+
+Same flag names and defaults; what they mean on the batched simulator:
+  --steps_per_iteration   timesteps per PPO batch = n_envs * rollout_len (rounded up to a whole rollout step of all envs)
+  --timesteps_per_episode episode cap (the rollout's timeout, ppo.py:552)
+  --max_timesteps         training budget, counted like the reference over COMPLETED episodes (ppo.py:258)
+  --tiny_debug_run        20-step episodes / 40-step batches / 400 total steps (arguments.py:58-65)
+  --use_external_sampler  start/goal from the curated GoalSpawnSampler tables (parsed but never wired in the reference)
+Additions (not in the reference): --n_envs, --policy, --map, --seed.  Vision flags are accepted and refused (the camera
+modality is outside the LiDAR hot path); --mode test maps to --eval (the reference's test path is broken).
+"""
+import argparse
+import os
+import sys
+
+
+def get_args(argv=None):
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--mode", type=str, default="train")
+    p.add_argument("--actor_model", type=str, default="")
+    p.add_argument("--critic_model", type=str, default="")
+    p.add_argument("--method_name", type=str, default="baseline")
+    p.add_argument("--eval", action="store_true", default=False)
+    p.add_argument("--eval_episodes", type=int, default=100)
+    p.add_argument("--output_dir", type=str, default=None)
+    p.add_argument("--timesteps_per_episode", type=int, default=500)
+    p.add_argument("--max_timesteps", type=int, default=5000)
+    p.add_argument("--steps_per_iteration", type=int, default=5000)
+    p.add_argument("--save_every_iterations", type=int, default=2)
+    p.add_argument("--resume", action="store_true", default=False)
+    p.add_argument("--dry_run_vision", action="store_true", default=False)
+    p.add_argument("--vision_backbone", type=str, default="mobilenet_v2")
+    p.add_argument("--vision_proj_dim", type=int, default=64)
+    p.add_argument("--use_external_sampler", action="store_true", default=False)
+    p.add_argument("--tiny_debug_run", action="store_true", default=False)
+    # batched-simulator additions
+    p.add_argument("--n_envs", type=int, default=None, help="parallel envs over all ranks (default: min(steps_per_iteration, 4096))")
+    p.add_argument("--policy", type=str, default="resmlp512", choices=["resmlp512", "mlp64x2"])
+    p.add_argument("--map", type=str, default="stage_1")
+    p.add_argument("--seed", type=int, default=0)
+    args = p.parse_args(argv)
+    if args.output_dir is None:
+        args.output_dir = os.path.join(os.getcwd(), "runs")
+    if args.tiny_debug_run:  # arguments.py:58-65
+        args.timesteps_per_episode, args.steps_per_iteration, args.max_timesteps = 20, 40, 400
+    if args.dry_run_vision or "vision" in args.method_name.lower():
+        p.error("the camera / vision modality is not part of this package (LiDAR hot path only)")
+    return args
+
+
+def schedule(args, world=1):
+    """(n_envs_total, rollout_len): steps_per_iteration timesteps per batch spread over the envs.  Every rollout starts from a
+    reset (ppo.py:486), so a rollout shorter than the episode cap could never finish a timed-out episode: by default the
+    env count is chosen so that rollout_len >= timesteps_per_episode (5000/500 -> 10 envs x 500 steps; 2 M/500 -> 4096 x 512)."""
+    if args.n_envs:
+        n_envs = args.n_envs
+    else:
+        n_envs = max(1, min(args.steps_per_iteration // max(args.timesteps_per_episode, 1), 4096 * world))
+        n_envs = max(world, n_envs // world * world)
+    rollout = max(1, -(-args.steps_per_iteration // n_envs))
+    return n_envs, rollout
+
+
+def main(argv=None):
+    args = get_args(argv)
+    import torch
+    from . import evaluate as ev
+    from . import maps, ppo
+    from .env import VecEnv
+
+    if args.eval or args.mode == "test":
+        path = args.actor_model or ev.find_latest_checkpoint(args.output_dir, args.method_name)
+        if not path:
+            print("No checkpoint found for evaluation. Exiting.", flush=True)  # main.py:161-163
+            return 0
+        print(f"Loading actor: {path}", flush=True)
+        actor, _ = ev.load_actor(path, "cuda")
+        s = ev.evaluate(actor, num_episodes=args.eval_episodes, max_timesteps_per_episode=args.timesteps_per_episode, map=args.map,
+                        seed=args.seed, output_dir=args.output_dir, method_name=args.method_name)
+        return 0 if s["episodes"] == args.eval_episodes else 1
+
+    ctx = ppo.DistCtx()
+    n_envs, rollout = schedule(args, ctx.world)
+    lo, hi = ctx.shard(n_envs)
+    sampler = None
+    if args.use_external_sampler:
+        world_type = "stage1" if args.map.startswith("stage") else "small_house"
+        st, g, dmin, dmax = maps.spawn_tables(world_type)
+        if world_type == "small_house":
+            st, g = maps.open_tables(maps.by_name(args.map), st, g)
+        sampler = (st, g, dmin, dmax)
+    env = VecEnv(hi - lo, map=args.map, max_episode_steps=args.timesteps_per_episode, auto_reset=True, is_training=True,
+                 seed=args.seed, env_id_base=lo, device=ctx.device, sampler=sampler)
+    cfg = ppo.PPOConfig(rollout_len=rollout, max_episode_steps=args.timesteps_per_episode, policy=args.policy, seed=args.seed,
+                        save_freq=args.save_every_iterations, output_dir=args.output_dir, method_name=args.method_name)
+    trainer = ppo.PPOTrainer(env, cfg, ctx)
+    if args.resume or args.actor_model:  # main.py:52-89
+        pa = args.actor_model or ev.find_latest_checkpoint(args.output_dir, args.method_name, "actor")
+        pc = args.critic_model or ev.find_latest_checkpoint(args.output_dir, args.method_name, "critic")
+        if pa and pc:
+            trainer.load_checkpoint(pa, pc)
+            if ctx.rank == 0:
+                print(f"Resumed from {pa}", flush=True)
+    if ctx.rank == 0:
+        print(f"Learning... {n_envs} envs x {rollout} steps = {n_envs * rollout} timesteps per batch, episode cap "
+              f"{args.timesteps_per_episode}, total budget {args.max_timesteps} timesteps, policy {args.policy}", flush=True)
+    trainer.learn(args.max_timesteps)
+    if cfg.output_dir and ctx.rank == 0:
+        trainer.save_checkpoint()
+    ctx.barrier()
+    if ctx.enabled:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

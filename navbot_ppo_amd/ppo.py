@@ -470,7 +470,13 @@ class PPOTrainer:
                 "ppo/clip_frac": lg.get("clip_frac"), "ppo/grad_norm": lg.get("grad_norm"), "ppo/exploration_var": lg.get("var")}
 
     def learn(self, total_timesteps, log=print):
-        while self.t_so_far < total_timesteps:  # ppo.py:245
+        # The reference counts only COMPLETED episodes toward the budget (ppo.py:258); if a configuration never completes
+        # one (rollout shorter than the episode cap) its loop would spin forever -- bound the iterations by the budget in
+        # simulated steps instead of hanging.
+        world = self.ctx.world if self.ctx is not None else 1
+        per_iter = self.cfg.rollout_len * self.env.N * world
+        max_iters = 4 * (-(-int(total_timesteps) // per_iter)) + 4
+        while self.t_so_far < total_timesteps and self.i_so_far < max_iters:  # ppo.py:245
             lg = self.iteration()
             if log and (self.ctx is None or self.ctx.rank == 0):
                 log(f"[iter {lg['iteration']:4d}] t={lg['t_so_far']:>10d} mean_ep_rew={lg['avg_ep_rews']:8.2f} "

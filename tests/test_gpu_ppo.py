@@ -209,3 +209,16 @@ def test_train_checkpoint_then_evaluate_like_main(tmp_path):
     rows = list(csv.reader(open(s["csv"])))
     assert rows[0] == ["episode", "success", "collision", "timeout", "length", "return", "path_length", "time"] and len(rows) == 41
     assert all(int(r[4]) <= 25 for r in rows[1:])
+
+
+def test_cli_train_resume_eval(tmp_path):
+    """The command-line surface: tiny debug run -> checkpoints -> --resume -> --eval, as `python3 main.py ...` of the reference."""
+    from navbot_ppo_amd import main as M
+    out = str(tmp_path)
+    assert M.main(["--tiny_debug_run", "--method_name", "dbg", "--output_dir", out, "--policy", "mlp64x2", "--save_every_iterations", "1"]) == 0
+    ck = sorted(os.listdir(os.path.join(out, "dbg", "checkpoints")))
+    assert any(f.startswith("actor_iter") for f in ck) and any(f.startswith("critic_iter") for f in ck)
+    assert M.main(["--tiny_debug_run", "--resume", "--method_name", "dbg", "--output_dir", out, "--policy", "mlp64x2",
+                   "--use_external_sampler"]) == 0
+    assert M.main(["--eval", "--eval_episodes", "12", "--timesteps_per_episode", "15", "--method_name", "dbg", "--output_dir", out]) == 0
+    assert os.path.exists(os.path.join(out, "dbg", "logs", "dbg_eval_episodes.csv"))

@@ -227,3 +227,18 @@ def test_split_k_linear_same_gradients_and_keys():
         nets.Linear.SPLIT_ROWS = 1 << 16
     for u, v in zip(g1, g0):
         np.testing.assert_allclose(u.numpy(), v.numpy(), rtol=1e-4, atol=1e-4 * float(v.abs().max()))
+
+
+def test_cli_flags_match_reference_arguments():
+    """navbot_ppo_amd.main accepts the reference's flags with its defaults (project_ppo/src/arguments.py:22-46,58-65)."""
+    from navbot_ppo_amd import main as M
+    a = M.get_args([])
+    assert (a.mode, a.method_name, a.eval, a.eval_episodes, a.timesteps_per_episode, a.max_timesteps, a.steps_per_iteration,
+            a.save_every_iterations, a.resume, a.use_external_sampler) == ("train", "baseline", False, 100, 500, 5000, 5000, 2, False, False)
+    t = M.get_args(["--tiny_debug_run", "--method_name", "x"])
+    assert (t.timesteps_per_episode, t.steps_per_iteration, t.max_timesteps) == (20, 40, 400)
+    assert M.schedule(M.get_args([]))[0] * M.schedule(M.get_args([]))[1] >= 5000
+    assert M.schedule(M.get_args(["--steps_per_iteration", "2097152", "--n_envs", "4096"])) == (4096, 512)
+    assert M.schedule(t) == (2, 20) and M.schedule(M.get_args([])) == (10, 500)
+    with pytest.raises(SystemExit):
+        M.get_args(["--method_name", "vision_mobilenet"])
