@@ -40,5 +40,9 @@ for w in which:
         us = run(4096, maps.stage_1(), False); print(f"cfg2 4096 envs shared S=32  : {us:8.2f} us")
     elif w == "--cfg4":
         us = run(4096, maps.stage_4(), False, B=36); print(f"cfg4 4096 envs shared S=64 B=36: {us:8.2f} us")
+    elif w.startswith("--s="):
+        S = int(w[4:]); sides = (S - 32) // 4
+        seg = maps.replicate_per_env(maps.stage_2(sides=sides), 16384, seed=0); us = run(16384, seg, True)
+        print(f"16384 envs per-env S={seg.shape[1]}: {us:8.2f} us  -> {16384*(134+16*seg.shape[1])/us/1e3:8.1f} GB/s")
     elif w == "--big":
         us = run(65536, maps.stage_1(), False); print(f"65536 envs shared S=32: {us:8.2f} us")
