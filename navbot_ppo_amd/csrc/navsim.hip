@@ -378,7 +378,7 @@ constexpr int kThreads = 256;   // 4 waves.  (A workgroup reserves ceil(waves/4)
 //          beam = per-lane min over its segments, then one LDS atomic-min per lane that saw a hit.
 //   shared map: lane = ray (env, beam); segments staged in LDS tiles, read two at a time as wave-wide broadcasts.
 //   all:   the EPB x (B+6) observation tile leaves LDS as one contiguous, fully coalesced store.
-template <int NB, bool PER_ENV, int EPB>
+template <int NB, bool PER_ENV, int EPB, bool SENS>
 __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* __restrict__ action,
                                                         const float2* __restrict__ past_override,
                                                         void* __restrict__ obs_out, float* __restrict__ reward,
@@ -400,6 +400,10 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     constexpr int PF = 2;       // segment tiles (64 segments each) of one env held in registers
     const int nloc = min(EPB, P.N - base);  // envs in this block
     const unsigned kInfBits = 0x7f800000u;
+    // sensor-fidelity options (range noise, -inf below range_min) are compiled out of the default instantiation:
+    // carrying them as run-time branches cost 1.2 us per launch (28.2 -> 27.0 us, configs[2])
+    const float sigma = SENS ? P.sigma : 0.f;
+    const int below_min = SENS ? P.below_min_mode : 0;
 
     // Pose lanes: 8 lanes per env (lane r of the group evaluates ONE of the 8 sincos the step needs: the six substep
     // headings, the final heading, and half of it), so the pose phase costs one sincos latency instead of eight.
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     }
     __syncthreads();  // barrier A: origins / directions / first segment tile visible
 
-    if (P.sigma > 0.f && pose_lane && el_pose < nloc) {
+    if (sigma > 0.f && pose_lane && el_pose < nloc) {
         // range noise for this step: lane rr draws beams rr, rr + 8, ... (off the critical path: the others ray-cast)
         for (int b = rr; b < B; b += 8)
             sm.noise[b * EPB + el_pose] = lidar_noise(P.key0, P.key1, P.env_id_base + (uint64_t)i, ctr, (uint32_t)step0, b);
@@ -617,9 +621,9 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         diff = sm.sv_d[9][e]; ret0 = sm.sv_d[10][e];
         act = sm.sv_act[e]; pact = sm.sv_pact[e]; ctr = sm.sv_ctr[e]; step0 = sm.sv_step[e];
         float* row = sm.obs + e * DP;
-        const float* noise = (P.sigma > 0.f) ? sm.noise + e : nullptr;
+        const float* noise = (sigma > 0.f) ? sm.noise + e : nullptr;
         // nearest hits are held as uint bit patterns of non-negative floats (inf = no hit)
-        const float mn = write_obs_row(row, reinterpret_cast<const float*>(sm.rng) + e, EPB, noise, EPB, P.sigma, P.below_min_mode, B,
+        const float mn = write_obs_row(row, reinterpret_cast<const float*>(sm.rng) + e, EPB, noise, EPB, sigma, below_min, B,
                                        pact.x, pact.y, dist, yaw, rel_theta, diff, P.diag);
         const bool d = (0.2 > (double)mn) && ((double)mn > 0);  // environment_new.py:200
         const bool a = dist <= P.thr;                             // :204
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             dist = hypot(gx - x, gy - y);
             pdist = dist;  // getGoalDistace, :116-120,:359
             const float* sp = P.spawn_scan + ((PER_ENV ? (size_t)i * P.K : 0) + k0) * B;
-            write_obs_row(row, sp, 1, noise, EPB, P.sigma, P.below_min_mode, B, 0.f, 0.f, dist, yaw, rel_theta, diff, P.diag);
+            write_obs_row(row, sp, 1, noise, EPB, sigma, below_min, B, 0.f, 0.f, dist, yaw, rel_theta, diff, P.diag);
         }
         P.x[i] = x; P.y[i] = y; P.th[i] = th;
         P.gx[i] = gx; P.gy[i] = gy; P.past_dist[i] = pdist;
@@ -790,12 +794,16 @@ static void launch_step_epb(const navsim* h, const float* action, const float* p
                             uint8_t* done, uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len,
                             hipStream_t st) {
     const dim3 grid((h->P.N + EPB - 1) / EPB), block(kThreads);
-    if (h->P.per_env)
-        hipLaunchKernelGGL((step_kernel<NB, true, EPB>), grid, block, 0, st, h->P, (const float2*)action,
-                           (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len);
-    else
-        hipLaunchKernelGGL((step_kernel<NB, false, EPB>), grid, block, 0, st, h->P, (const float2*)action,
-                           (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len);
+    const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, st, h->P, (const float2*)action, (const float2*)past, obs, reward, done,
+                           arrive, ended, ep_ret, ep_len);
+    };
+    if (h->P.per_env) {
+        if (sens) go(step_kernel<NB, true, EPB, true>); else go(step_kernel<NB, true, EPB, false>);
+    } else {
+        if (sens) go(step_kernel<NB, false, EPB, true>); else go(step_kernel<NB, false, EPB, false>);
+    }
 }
 
 template <int NB>

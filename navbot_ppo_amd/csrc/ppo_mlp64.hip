@@ -8,22 +8,23 @@
 // project_ppo/src/net_actor.py:147-189, graph_code/ppo_for_beginners/network.py:11-50).
 //
 // Why a kernel: in PyTorch every layer's activations ([2.1 M, 64] f32 = 537 MB) make a round trip through HBM per op
-// (profiles/r01_bench_v4_kernel_stats.csv: 3.8 ms per epoch, relu-backward alone 1 ms).  Here a workgroup
-// keeps a 128-sample tile and the net's weights in LDS (132 KB of the CU's 160 KB): per epoch the batch is read
-// once per net (84 B/sample) and nothing but 10,691 gradient floats per workgroup is written.
+// (profiles/r01_bench_v4_kernel_stats.csv: 3.8 ms per epoch, relu-backward alone 1 ms).  Here activations never leave
+// the CU: per epoch the batch is read once per net (84 B/sample) and nothing but one partial-gradient row per
+// workgroup is written.
 //
-// Arithmetic: float32 throughout.  GEMMs use v_mfma_f32_32x32x2_f32, which is an exact k-ordered f32 fma chain
-// (no reduced-precision inputs); sums over samples are taken in tile order, so results agree with PyTorch
-// autograd to fp32 round-off, not bit for bit.
+// Arithmetic: float32 throughout.  GEMMs use v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32, which are exact
+// k-ordered f32 fma chains (no reduced-precision inputs); sums over samples are taken in tile order, so results agree
+// with PyTorch autograd to fp32 round-off, not bit for bit.
 //
-// One launch per net (template ACTOR): grid = persistent workgroups (1 per CU), each loops over tiles.
-//   F1  H1 = relu(X W1^T + b1)      [128x16]x[16x64]    wave w owns rows 32w..32w+31
-//   F2  H2 = relu(H1 W2^T + b2)     [128x64]x[64x64]
-//   heads + PPO loss / MSE (VALU, thread = sample) -> g3, g4 (dL/dz of the output units)
-//   dH2 = (g3 w3 + g4 w4) . [H2 > 0]                    (VALU, elementwise) ; db2, dW3, dW4, db3, db4 partial sums
-//   B2  dH1 = (dH2 W2) . [H1 > 0]   [128x64]x[64x64]    ; db1 partial sums
-//   G2  dW2 += dH2^T H1             [64x128]x[128x64]   wave w owns one 32x32 quadrant, accumulators persist over tiles
-//   G1  dW1 += dH1^T X              [64x128]x[128x16]
+// One launch per net (template ACTOR), one persistent 8-wave workgroup per CU; a WAVE owns a 32-sample tile end to end
+// (mlp64_pass_w below):
+//   F1  H1 = relu(X W1^T + b1)      [32x16]x[16x64]
+//   F2  H2 = relu(H1 W2^T + b2)     [32x64]x[64x64]
+//   heads + PPO loss / MSE (VALU)   -> g3, g4 (dL/dz of the output units) ; dW3, dW4, db3, db4
+//   dH2 = (g3 w3 + g4 w4) . [H2 > 0]                    (VALU, elementwise) ; db2
+//   B2  dH1 = (dH2 W2) . [H1 > 0]   [32x64]x[64x64]     ; db1
+//   G2  dW2 += dH2^T H1             [64x32]x[32x64]     accumulators persist over the wave's tiles
+//   G1  dW1 += dH1^T X              [64x32]x[32x16]
 // At the end every workgroup writes its partial gradient (one row of `partial`), and `reduce_partials` sums rows.
 #include <hip/hip_runtime.h>
 
@@ -36,7 +37,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 128;    // samples per tile
+constexpr int TM = 128;    // samples per workgroup of mlp64_act
 constexpr int H = 64;      // hidden width
 constexpr int IN = 16;     // observation width
 constexpr int LDH = H + 1; // padded LDS row strides (odd: conflict-free for row-per-lane and column-per-lane reads)
@@ -51,16 +52,6 @@ constexpr int P_ACTOR = OFF_B4 + 1;   // 5378
 constexpr int P_CRITIC = OFF_B3 + 1;  // 5313
 static_assert(P_ACTOR == NAVPPO_MLP64_ACTOR_PARAMS && P_CRITIC == NAVPPO_MLP64_CRITIC_PARAMS, "layout");
 
-template <int TM_>
-struct SmemT {
-    float X[TM_ * LDX];
-    float HB[3 * TM_ * LDH];  // H1 | H2 (later dH1) | dH2 ; at the very end: the gradient reduction buffer (5382 floats)
-    float W1[H * LDX];
-    float W2[H * LDH];
-    float b1[H], b2[H], w3[H], w4[H];
-    float g3[TM_], g4[TM_];
-};
-
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -71,39 +62,73 @@ __device__ __forceinline__ f32x16 zero16() {
 // C/D element (row, col) of accumulator register r for lane l (32x32 shapes; cdna_hip_programming.md section 3)
 __device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// PT = samples per tile, 4 threads per sample: PT = 128 -> 8 waves, 132 KB LDS, 1 workgroup per CU;
-// PT = 64 -> 4 waves, 76 KB LDS, 2 independent workgroups per CU (their MFMA / VALU / barrier phases interleave).
-constexpr int kPassTile = 64;
-constexpr int kPassThreads = 4 * kPassTile;
+// ---------------------------------------------------------------- the pass kernel
+// A WAVE owns a 32-sample tile end to end and never meets a workgroup barrier inside the tile loop (round-1 history:
+// 4-wave workgroups that shared 64-sample tiles through LDS needed 7 barriers and ~370 ds_read_b32 per tile and ran
+// 1.43 ms per epoch; this layout 1.13 ms).  Measured on gfx950 (tools/ubench/mfma_valu_overlap.hip): f32 MFMA and
+// VALU / LDS work of two waves on one SIMD do NOT overlap -- the times add -- so the kernel is organised to minimise
+// the number of non-MFMA instructions, not to hide them.  Everything is computed transposed (sample = lane):
+//   F1  H1^T[n][m] = relu(b1 + W1 X^T)         A = W1 rows from LDS, B = the lane's own 8 observation floats (registers)
+//   F2  H2^T       = relu(b2 + W2 H1^T)        B = the F1 accumulators themselves: accumulator register r of lane
+//   B2  dH1^T      = (W2^T dH2^T) . [H1 > 0]       (m, hi) holds row (r&3) + 8 (r>>2) + 4 hi, which is exactly a legal
+//                                                  k-pairing for the next MFMA when A is read k-permuted (ds_read_b128)
+//   G2 / G1 (contraction over samples = lanes) are the only products that need a transpose: H1^T, dH2^T, dH1^T and X
+//   pass through three 32x32 wave-private LDS tiles and come back as k-contiguous ds_read_b128 operands; the same
+//   operand registers give db2 / db1, and one more tile round trip of H2^T gives dW3 / dW4.
+// LDS: W1 5 KB + W2 and W2^T 17 KB each + vectors 1 KB + 8 x 13.75 KB wave tiles = 150 KB -> one workgroup per CU.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int LW1 = 20;                   // row strides (floats): 16-byte aligned rows, conflict-free ds_read_b128
+constexpr int LW2 = 68;
+constexpr int LT = 36;
+constexpr int TILE_F = 32 * LT;
+constexpr int WAVE_F = 3 * TILE_F + 64;   // T0 | T1 | TD | g3[32] g4[32]
+constexpr int kWWaves = 8;
+constexpr int kWThreads = 64 * kWWaves;
+constexpr int kWMaxBlocks = 256;          // one persistent workgroup per CU
 
-template <bool ACTOR, int PT>
-__global__ __launch_bounds__(4 * PT) void mlp64_pass(const float* __restrict__ params, const float* __restrict__ obs,
-                                                           const float* __restrict__ act, const float* __restrict__ logp_old,
-                                                           const float* __restrict__ rtg, const float* __restrict__ adv,
-                                                           long long M, float var, float clip, float inv_n,
-                                                           float* __restrict__ partial, float* __restrict__ stats_partial,
-                                                           float* __restrict__ grad_zero, float* __restrict__ stats_zero) {
+struct SmemW {
+    float W1s[H * LW1];
+    float W2s[H * LW2];
+    float W2Ts[H * LW2];
+    float b1[H], b2[H], w3[H], w4[H];
+    float wv[kWWaves * WAVE_F];
+};
+static_assert(sizeof(SmemW) <= 160 * 1024, "LDS");
+static_assert(kWWaves * WAVE_F >= P_ACTOR + 4, "reduction buffer");
+
+__device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// relu as an integer max on the bit pattern: negative floats (sign bit set, incl. -0) -> +0, positive unchanged.
+// One v_max_i32 instead of the canonicalise + v_max_f32 pair the compiler emits for fmaxf(x, 0).
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wave are performed in issue order: this only stops the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool ACTOR>
+__global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restrict__ params, const float* __restrict__ obs,
+                                                          const float* __restrict__ act, const float* __restrict__ logp_old,
+                                                          const float* __restrict__ rtg, const float* __restrict__ adv,
+                                                          long long M, float var, float clip, float inv_n,
+                                                          float* __restrict__ partial, float* __restrict__ stats_partial,
+                                                          float* __restrict__ grad_zero, float* __restrict__ stats_zero) {
     constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
-    constexpr int NT = 4 * PT;       // threads
-    constexpr int NW = NT / 64;      // waves: PT/32 row strips x 2 column tiles
-    constexpr int TM = PT;           // (shadows the namespace constant inside this kernel)
-    static_assert(PT == 64 || PT == 128, "tile");
-    __shared__ SmemT<PT> sm;
-    static_assert(3 * PT * LDH >= P_ACTOR + 4, "reduction buffer");
-    float* const sH1 = sm.HB;
-    float* const sH2 = sm.HB + PT * LDH;
-    float* const sdH2 = sm.HB + 2 * PT * LDH;
+    constexpr int NT = kWThreads;
+    __shared__ __attribute__((aligned(16))) SmemW sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int strip = wave >> 1, ct = wave & 1;  // F1/F2/B2: 32-row strip and 32-column tile owned by this wave
+    const int l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15, kk = lane >> 4;
 
     if (blockIdx.x == 0) {  // the reduction that follows this launch accumulates with atomics: clear its targets here
         for (int k = tid; k < P; k += NT) grad_zero[k] = 0.f;
         if (tid < 3) stats_zero[tid] = 0.f;
     }
-    // ---- weights -> LDS (once per workgroup)
-    for (int k = tid; k < H * IN; k += NT) sm.W1[(k / IN) * LDX + (k % IN)] = params[OFF_W1 + k];
-    for (int k = tid; k < H * H; k += NT) sm.W2[(k / H) * LDH + (k % H)] = params[OFF_W2 + k];
+    for (int k = tid; k < H * IN; k += NT) sm.W1s[(k / IN) * LW1 + (k % IN)] = params[OFF_W1 + k];
+    for (int k = tid; k < H * H; k += NT) {
+        const float w = params[OFF_W2 + k];
+        sm.W2s[(k / H) * LW2 + (k % H)] = w;
+        sm.W2Ts[(k % H) * LW2 + (k / H)] = w;
+    }
     if (tid < H) {
         sm.b1[tid] = params[OFF_B1 + tid];
         sm.b2[tid] = params[OFF_B2 + tid];
@@ -112,228 +137,327 @@ __global__ __launch_bounds__(4 * PT) void mlp64_pass(const float* __restrict__ p
     }
     const float b3 = params[OFF_B3];
     const float b4 = ACTOR ? params[OFF_B4] : 0.f;
+    __syncthreads();
 
-    // ---- accumulators that persist over this workgroup's tiles
-    f32x16 accW2 = zero16();   // quadrant (wave & 3) of dW2 over the samples of half (wave >> 2) of each tile
-    f32x16 accW1 = zero16();   // half (wave & 1) of dW1 over the samples of quarter (wave >> 1) of each tile
-    float acc_db1 = 0.f;       // column 32 ct + l31 of the dH1 rows this lane sees in B2
-    float acc_db2 = 0.f, acc_dw3 = 0.f, acc_dw4 = 0.f;  // column (tid & 63), rows (tid >> 6) + 8 i
-    float acc_db3 = 0.f, acc_db4 = 0.f;                 // sample-owner threads (tid & 3) == 0
-    float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;   // loss, kl, clip-frac sums
+    float* const T0 = sm.wv + wave * WAVE_F;   // H1^T rows 0..31  (later: X as [k][m])
+    float* const T1 = T0 + TILE_F;             // H1^T rows 32..63
+    float* const TD = T0 + 2 * TILE_F;         // H2^T / dH2^T / dH1^T, one 32-row tile at a time
+    float* const gs = T0 + 3 * TILE_F;         // g3[m] | g4[m]
+    // accumulator register r = 4 g + j of lane (m = l31, lhi) is row j + 8 g + 4 lhi of its 32x32 tile
+    const int wr_base = 4 * lhi * LT + l31;    // tile[row][m] write: + (8 g + j) * LT
+    const int rd32 = l31 * LT + 16 * lhi;      // row l31, samples 16 lhi .. + 15 (32x32x2 operands: k = sample)
+    const int rd16 = l15 * LT + 8 * kk;        // row l15, samples 8 kk .. + 7   (16x16x4 operands)
+    const int vec_off = 4 * lhi;               // b1 / b2 / w3 / w4 [32 t + 8 g + 4 lhi + j]
+    const float* const w1row = sm.W1s + l31 * LW1 + 8 * lhi;
+    const float* const w2row = sm.W2s + l31 * LW2 + 4 * lhi;
+    const float* const w2trow = sm.W2Ts + l31 * LW2 + 4 * lhi;
 
-    // Software prefetch: the next tile's observations (PT*16/NT = 4 floats per thread) and per-sample scalars are
-    // loaded into registers while the current tile is being processed, so no phase waits on HBM latency.
-    constexpr int XPT = TM * IN / NT;
-    float xpre[XPT];
-    float pre_a0 = 0.f, pre_a1 = 0.f, pre_lp = 0.f, pre_t = 0.f;  // act, logp_old, (adv | rtg) of sample tid >> 2
-    auto prefetch_tile = [&](long long tile) {
-        const long long mb = tile * TM;
+    // accumulators that persist over this wave's tiles
+    f32x16 aW2[2][2];   // dW2 quadrant [n2 tile][n tile]
+    f32x4 aW1[4];       // dW1 rows 16 u .. + 15
 #pragma unroll
-        for (int j = 0; j < XPT; ++j) {
-            const int k = tid + j * NT;
-            const long long m = mb + k / IN;
-            xpre[j] = (m < M) ? obs[m * IN + (k % IN)] : 0.f;
-        }
-        if ((tid & 3) == 0) {
-            const long long m = mb + (tid >> 2);
-            if (m < M) {
-                if (ACTOR) {
-                    pre_a0 = act[2 * m];
-                    pre_a1 = act[2 * m + 1];
-                    pre_lp = logp_old[m];
-                    pre_t = adv[m];
-                } else {
-                    pre_t = rtg[m];
-                }
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) aW2[a][b] = zero16();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) aW1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float adb2[2] = {0.f, 0.f}, adw3[2] = {0.f, 0.f}, adw4[2] = {0.f, 0.f}, adb1[4] = {0.f, 0.f, 0.f, 0.f};
+    float adb3 = 0.f, adb4 = 0.f, st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
+
+    const long long n_tiles = (M + 31) / 32;
+    const long long gw = (long long)blockIdx.x * kWWaves + wave, stride = (long long)gridDim.x * kWWaves;
+    float4 xp0 = make_float4(0.f, 0.f, 0.f, 0.f), xp1 = xp0;
+    float pre_a0 = 0.f, pre_a1 = 0.f, pre_lp = 0.f, pre_t = 0.f;
+    auto prefetch_tile = [&](long long tile) {   // next tile's rows stream in while the current one is computed
+        const long long m = tile * 32 + l31;
+        xp0 = xp1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M) {
+            const float4* xp = reinterpret_cast<const float4*>(obs + m * IN + 8 * lhi);
+            xp0 = xp[0];
+            xp1 = xp[1];
+            if (ACTOR) {
+                const float2 a = reinterpret_cast<const float2*>(act)[m];
+                pre_a0 = a.x;
+                pre_a1 = a.y;
+                pre_lp = logp_old[m];
+                pre_t = adv[m];
+            } else {
+                pre_t = rtg[m];
             }
         }
     };
-    const long long n_tiles = (M + TM - 1) / TM;
-    if (blockIdx.x < n_tiles) prefetch_tile(blockIdx.x);
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const long long m_base = tile * TM;
-        __syncthreads();  // previous tile's LDS readers are done
-        // ---- X tile: registers -> LDS; then start loading the next tile
-#pragma unroll
-        for (int j = 0; j < XPT; ++j) {
-            const int k = tid + j * NT;
-            sm.X[(k / IN) * LDX + (k % IN)] = xpre[j];
-        }
+    if (gw < n_tiles) prefetch_tile(gw);
+    for (long long tile = gw; tile < n_tiles; tile += stride) {
+        const bool valid = tile * 32 + l31 < M;
+        const float xr[8] = {xp0.x, xp0.y, xp0.z, xp0.w, xp1.x, xp1.y, xp1.z, xp1.w};  // X[m][8 lhi + s]
         const float cur_a0 = pre_a0, cur_a1 = pre_a1, cur_lp = pre_lp, cur_t = pre_t;
-        if (tile + gridDim.x < n_tiles) prefetch_tile(tile + gridDim.x);
-        __syncthreads();
+        if (tile + stride < n_tiles) prefetch_tile(tile + stride);
 
-        // ---- F1: H1 = relu(X W1^T + b1), K = 16
+        // ---- F1: both 32-row tiles of H1^T interleaved (independent accumulators)
+        f32x16 c1[2];
         {
-            f32x16 c = zero16();
-            const float* a_ptr = sm.X + (32 * strip + l31) * LDX + lhi;
-            const float* b_ptr = sm.W1 + (32 * ct + l31) * LDX + lhi;
+            float wa[2][8];
 #pragma unroll
-            for (int k0 = 0; k0 < IN; k0 += 2) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[k0], b_ptr[k0], c, 0, 0, 0);
-            const float bias = sm.b1[32 * ct + l31];
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sH1[(32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31] = fmaxf(c[r] + bias, 0.f);
-        }
-        __syncthreads();
-
-        // ---- F2: H2 = relu(H1 W2^T + b2), K = 64
-        {
-            f32x16 c = zero16();
-            const float* a_ptr = sH1 + (32 * strip + l31) * LDH + lhi;
-            const float* b_ptr = sm.W2 + (32 * ct + l31) * LDH + lhi;
-#pragma unroll 16
-            for (int k0 = 0; k0 < H; k0 += 2) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[k0], b_ptr[k0], c, 0, 0, 0);
-            const float bias = sm.b2[32 * ct + l31];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sH2[(32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31] = fmaxf(c[r] + bias, 0.f);
-        }
-        __syncthreads();
-
-        // ---- output units + loss: 4 threads per sample, 16 hidden units each, then a 4-lane butterfly.
-        //      Thread part p reads units 16 p + ((j + 8 (p >> 1)) & 15): conflict-free over each 32-lane group.
-        {
-            const int ms = tid >> 2, p = tid & 3;
-            const long long m = m_base + ms;
-            const float* h2 = sH2 + ms * LDH + 16 * p;
-            const int rot = 8 * (p >> 1);
-            float z3 = 0.f, z4 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int k = (j + rot) & 15;
-                const float h = h2[k];
-                z3 = fmaf(h, sm.w3[16 * p + k], z3);
-                if (ACTOR) z4 = fmaf(h, sm.w4[16 * p + k], z4);
-            }
-            z3 += __shfl_xor(z3, 1, 64);
-            z3 += __shfl_xor(z3, 2, 64);
-            if (ACTOR) {
-                z4 += __shfl_xor(z4, 1, 64);
-                z4 += __shfl_xor(z4, 2, 64);
-            }
-            if (p == 0) {
-                float g3 = 0.f, g4 = 0.f;
-                if (m < M) {
-                    z3 += b3;
-                    z4 += b4;
-                    if (ACTOR) {
-                        const float mu0 = 1.0f / (1.0f + expf(-z3));   // torch.sigmoid, net_actor.py:185
-                        const float mu1 = tanhf(z4);                    // net_actor.py:186
-                        const float a0 = cur_a0, a1 = cur_a1;
-                        const float d0 = a0 - mu0, d1 = a1 - mu1;
-                        // MultivariateNormal(mean, var*I).log_prob, ppo.py:734-735
-                        const float lp = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);
-                        const float lr = lp - cur_lp;
-                        const float ratio = expf(lr);                  // ppo.py:316
-                        const float A = cur_t;
-                        const float s1 = ratio * A;                     // ppo.py:319
-                        const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
-                        const float s2 = rc * A;                        // ppo.py:320
-                        st0 += -fminf(s1, s2);                          // ppo.py:342 (mean taken by inv_n at the end)
-                        st2 += (ratio - 1.0f) - lr;                     // approx KL, ppo.py:326
-                        st3 += (fabsf(ratio - 1.0f) > clip) ? 1.f : 0.f;  // clip fraction, ppo.py:335
-                        // d(-min(s1,s2))/d ratio: -A through s1 when s1 <= s2 inside the clip range (tie: both halves),
-                        // or when s1 < s2 outside it; 0 when the clipped (constant) branch is the minimum
-                        const bool inside = (ratio >= 1.0f - clip) && (ratio <= 1.0f + clip);
-                        const float dL_dratio = (inside || s1 < s2) ? -A : 0.f;
-                        const float dL_dlp = dL_dratio * ratio * inv_n;
-                        g3 = dL_dlp * (d0 / var) * (mu0 * (1.0f - mu0));
-                        g4 = dL_dlp * (d1 / var) * (1.0f - mu1 * mu1);
-                    } else {
-                        const float V = z3;                             // critic(obs).squeeze(), ppo.py:724
-                        const float e = V - cur_t;
-                        st1 += e * e;                                   // MSELoss, ppo.py:343
-                        g3 = 2.0f * e * inv_n;
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b = lds4(sm.b1 + 32 * t + 8 * g + vec_off);
+                    c1[t][4 * g] = b.x; c1[t][4 * g + 1] = b.y; c1[t][4 * g + 2] = b.z; c1[t][4 * g + 3] = b.w;
                 }
-                sm.g3[ms] = g3;
-                sm.g4[ms] = g4;
-                acc_db3 += g3;
-                acc_db4 += g4;
+                const float4 w0 = lds4(w1row + 32 * t * LW1), w1 = lds4(w1row + 32 * t * LW1 + 4);
+                wa[t][0] = w0.x; wa[t][1] = w0.y; wa[t][2] = w0.z; wa[t][3] = w0.w;
+                wa[t][4] = w1.x; wa[t][5] = w1.y; wa[t][6] = w1.z; wa[t][7] = w1.w;
             }
-        }
-        __syncthreads();
-
-        // ---- dH2 = (g3 w3 + g4 w4) . [H2 > 0] ; column sums for db2, dW3, dW4
-        {
-            const int k = tid & 63;
-            const float w3k = sm.w3[k], w4k = sm.w4[k];
-#pragma unroll 4
-            for (int i = 0; i < TM / NW; ++i) {
-                const int m = (tid >> 6) + NW * i;
-                const float h = sH2[m * LDH + k];
-                const float g3 = sm.g3[m], g4 = sm.g4[m];
-                const float d = (h > 0.f) ? fmaf(g3, w3k, g4 * w4k) : 0.f;
-                sdH2[m * LDH + k] = d;
-                acc_db2 += d;
-                acc_dw3 = fmaf(g3, h, acc_dw3);
-                acc_dw4 = fmaf(g4, h, acc_dw4);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                c1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], xr[s], c1[0], 0, 0, 0);
+                c1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], xr[s], c1[1], 0, 0, 0);
             }
-        }
-        __syncthreads();
-
-        // ---- B2: dH1 = (dH2 W2) . [H1 > 0] -> stored over H2 ; db1 partial sums
-        {
-            f32x16 c = zero16();
-            const float* a_ptr = sdH2 + (32 * strip + l31) * LDH + lhi;
-            const float* b_ptr = sm.W2 + lhi * LDH + 32 * ct + l31;
-#pragma unroll 16
-            for (int n0 = 0; n0 < H; n0 += 2) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[n0], b_ptr[n0 * LDH], c, 0, 0, 0);
-            // every wave finished reading H2 before the barrier above; each wave overwrites only its own tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int idx = (32 * strip + c_row(r, lane)) * LDH + 32 * ct + l31;
-                const float d = (sH1[idx] > 0.f) ? c[r] : 0.f;
-                sH2[idx] = d;
-                acc_db1 += d;
+                c1[0][r] = relu_bits(c1[0][r]);
+                c1[1][r] = relu_bits(c1[1][r]);
+                const int o = wr_base + (8 * (r >> 2) + (r & 3)) * LT;
+                T0[o] = c1[0][r];
+                T1[o] = c1[1][r];
             }
         }
-        __syncthreads();
 
-        // ---- G2: dW2[n][k] += sum_m dH2[m][n] H1[m][k]; quadrant (nt, kt) from wave & 3, samples 64 (wave>>2) .. +64
-        {
-            const int q = wave & 3, mh = 64 * (wave >> 2);  // NW/4 sample groups of 64
-            const float* a_ptr = sdH2 + (mh + lhi) * LDH + 32 * (q >> 1) + l31;
-            const float* b_ptr = sH1 + (mh + lhi) * LDH + 32 * (q & 1) + l31;
-#pragma unroll 16
-            for (int m0 = 0; m0 < 64; m0 += 2)
-                accW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[m0 * LDH], b_ptr[m0 * LDH], accW2, 0, 0, 0);
-        }
-        // ---- G1: dW1[n][k] += sum_m dH1[m][n] X[m][k] (k < 16; columns 16..31 of the 32-wide tile are zero padding);
-        //      half nt = wave & 1, samples 32 (wave>>1) .. +32
-        {
-            const int mq = 32 * (wave >> 1);
-            const float* a_ptr = sH2 + (mq + lhi) * LDH + 32 * (wave & 1) + l31;
-            const float* b_ptr = sm.X + (mq + lhi) * LDX + (l31 & 15);
-            const bool live = l31 < IN;
-#pragma unroll 16
-            for (int m0 = 0; m0 < 32; m0 += 2) {
-                const float b = live ? b_ptr[m0 * LDX] : 0.f;
-                accW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[m0 * LDH], b, accW1, 0, 0, 0);
+        // ---- F2: H2^T, B operands are the H1^T accumulators
+        f32x16 c2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = lds4(sm.b2 + 32 * t + 8 * g + vec_off);
+                c2[t][4 * g] = b.x; c2[t][4 * g + 1] = b.y; c2[t][4 * g + 2] = b.z; c2[t][4 * g + 3] = b.w;
             }
+        {   // operands of group i + 1 are requested before the MFMAs of group i are issued
+            float4 w0n = lds4(w2row), w1n = lds4(w2row + 32 * LW2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t1 = i >> 2, g = i & 3;
+                const float4 w0 = w0n, w1 = w1n;
+                if (i + 1 < 8) {
+                    w0n = lds4(w2row + 8 * (i + 1));
+                    w1n = lds4(w2row + 32 * LW2 + 8 * (i + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the requests above the MFMAs they overlap with
+                const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], c1[t1][4 * g + j], c2[0], 0, 0, 0);
+                    c2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], c1[t1][4 * g + j], c2[1], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            c2[0][r] = relu_bits(c2[0][r]);
+            c2[1][r] = relu_bits(c2[1][r]);
+        }
+
+        // ---- output units + loss (every lane: the two halves of a sample hold 32 hidden units each)
+        float g3 = 0.f, g4 = 0.f;
+        {
+            float z3 = 0.f, z4 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 w = lds4(sm.w3 + 32 * t + 8 * g + vec_off);
+                    z3 = fmaf(c2[t][4 * g], w.x, z3); z3 = fmaf(c2[t][4 * g + 1], w.y, z3);
+                    z3 = fmaf(c2[t][4 * g + 2], w.z, z3); z3 = fmaf(c2[t][4 * g + 3], w.w, z3);
+                    if (ACTOR) {
+                        const float4 v = lds4(sm.w4 + 32 * t + 8 * g + vec_off);
+                        z4 = fmaf(c2[t][4 * g], v.x, z4); z4 = fmaf(c2[t][4 * g + 1], v.y, z4);
+                        z4 = fmaf(c2[t][4 * g + 2], v.z, z4); z4 = fmaf(c2[t][4 * g + 3], v.w, z4);
+                    }
+                }
+            z3 += __shfl_xor(z3, 32, 64);
+            if (ACTOR) z4 += __shfl_xor(z4, 32, 64);
+            const float own = (lhi == 0) ? 1.f : 0.f;   // statistics are counted once per sample
+            if (valid) {
+                z3 += b3;
+                z4 += b4;
+                if (ACTOR) {
+                    const float mu0 = 1.0f / (1.0f + expf(-z3));   // torch.sigmoid, net_actor.py:185
+                    const float mu1 = tanhf(z4);                    // net_actor.py:186
+                    const float d0 = cur_a0 - mu0, d1 = cur_a1 - mu1;
+                    // MultivariateNormal(mean, var*I).log_prob, ppo.py:734-735
+                    const float lp = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);
+                    const float lr = lp - cur_lp;
+                    const float ratio = expf(lr);                  // ppo.py:316
+                    const float A = cur_t;
+                    const float s1 = ratio * A;                     // ppo.py:319
+                    const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+                    const float s2 = rc * A;                        // ppo.py:320
+                    st0 += own * -fminf(s1, s2);                    // ppo.py:342 (mean taken by inv_n at the end)
+                    st2 += own * ((ratio - 1.0f) - lr);             // approx KL, ppo.py:326
+                    st3 += (fabsf(ratio - 1.0f) > clip) ? own : 0.f;  // clip fraction, ppo.py:335
+                    // d(-min(s1,s2))/d ratio: -A through s1 when s1 <= s2 inside the clip range (tie: both halves),
+                    // or when s1 < s2 outside it; 0 when the clipped (constant) branch is the minimum
+                    const bool inside = (ratio >= 1.0f - clip) && (ratio <= 1.0f + clip);
+                    const float dL_dratio = (inside || s1 < s2) ? -A : 0.f;
+                    const float dL_dlp = dL_dratio * ratio * inv_n;
+                    g3 = dL_dlp * (d0 / var) * (mu0 * (1.0f - mu0));
+                    g4 = dL_dlp * (d1 / var) * (1.0f - mu1 * mu1);
+                } else {
+                    const float e = z3 - cur_t;                     // critic(obs).squeeze(), ppo.py:724
+                    st1 += own * (e * e);                           // MSELoss, ppo.py:343
+                    g3 = 2.0f * e * inv_n;
+                }
+            }
+            adb3 += own * g3;
+            adb4 += own * g4;
+            if (lhi == 0) {
+                gs[l31] = g3;
+                if (ACTOR) gs[32 + l31] = g4;
+            }
+        }
+
+        // ---- per 32-row tile of the second layer: dW3/dW4 from H2^T, dH2^T in place, then its two dW2 quadrants
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) TD[wr_base + (8 * (r >> 2) + (r & 3)) * LT] = c2[t2][r];
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // lane (n2 = 32 t2 + l31, half lhi): sum over its 16 samples
+                const float4 h = lds4(TD + rd32 + 4 * q);
+                const float4 a = lds4(gs + 16 * lhi + 4 * q);
+                adw3[t2] = fmaf(h.x, a.x, adw3[t2]); adw3[t2] = fmaf(h.y, a.y, adw3[t2]);
+                adw3[t2] = fmaf(h.z, a.z, adw3[t2]); adw3[t2] = fmaf(h.w, a.w, adw3[t2]);
+                if (ACTOR) {
+                    const float4 b = lds4(gs + 32 + 16 * lhi + 4 * q);
+                    adw4[t2] = fmaf(h.x, b.x, adw4[t2]); adw4[t2] = fmaf(h.y, b.y, adw4[t2]);
+                    adw4[t2] = fmaf(h.z, b.z, adw4[t2]); adw4[t2] = fmaf(h.w, b.w, adw4[t2]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 w = lds4(sm.w3 + 32 * t2 + 8 * g + vec_off);
+                const float wv3[4] = {w.x, w.y, w.z, w.w};
+                float wv4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (ACTOR) {
+                    const float4 v = lds4(sm.w4 + 32 * t2 + 8 * g + vec_off);
+                    wv4[0] = v.x; wv4[1] = v.y; wv4[2] = v.z; wv4[3] = v.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = ACTOR ? fmaf(g3, wv3[j], g4 * wv4[j]) : g3 * wv3[j];
+                    c2[t2][4 * g + j] = (c2[t2][4 * g + j] > 0.f) ? d : 0.f;
+                }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) TD[wr_base + (8 * (r >> 2) + (r & 3)) * LT] = c2[t2][r];
+            wave_lds_fence();
+            {
+                float4 an = lds4(TD + rd32), h0n = lds4(T0 + rd32), h1n = lds4(T1 + rd32);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = an, h0 = h0n, h1 = h1n;
+                    if (q + 1 < 4) {
+                        an = lds4(TD + rd32 + 4 * (q + 1));
+                        h0n = lds4(T0 + rd32 + 4 * (q + 1));
+                        h1n = lds4(T1 + rd32 + 4 * (q + 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the requests above the MFMAs they overlap with
+                    adb2[t2] += (a.x + a.y) + (a.z + a.w);
+                    const float ar[4] = {a.x, a.y, a.z, a.w}, b0[4] = {h0.x, h0.y, h0.z, h0.w}, b1v[4] = {h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        aW2[t2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[j], b0[j], aW2[t2][0], 0, 0, 0);
+                        aW2[t2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[j], b1v[j], aW2[t2][1], 0, 0, 0);
+                    }
+                }
+            }
+            wave_lds_fence();
+        }
+
+        // ---- B2: dH1^T = (W2^T dH2^T) . [H1 > 0]; B operands are the dH2^T registers
+        f32x16 c3[2] = {zero16(), zero16()};
+        {
+            float4 w0n = lds4(w2trow), w1n = lds4(w2trow + 32 * LW2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t2 = i >> 2, g = i & 3;
+                const float4 w0 = w0n, w1 = w1n;
+                if (i + 1 < 8) {
+                    w0n = lds4(w2trow + 8 * (i + 1));
+                    w1n = lds4(w2trow + 32 * LW2 + 8 * (i + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the requests above the MFMAs they overlap with
+                const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c3[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], c2[t2][4 * g + j], c3[0], 0, 0, 0);
+                    c3[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], c2[t2][4 * g + j], c3[1], 0, 0, 0);
+                }
+            }
+        }
+
+        // relu mask of layer 1: H1^T is still in T0 / T1 (same lane, same slot it was written from)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = wr_base + (8 * (r >> 2) + (r & 3)) * LT;
+            c3[0][r] = (T0[o] > 0.f) ? c3[0][r] : 0.f;
+            c3[1][r] = (T1[o] > 0.f) ? c3[1][r] : 0.f;
+        }
+        wave_lds_fence();
+        // ---- G1: X goes to T0 as [k][m] (the H1^T tiles are no longer needed), dH1^T through TD 32 rows at a time
+#pragma unroll
+        for (int s = 0; s < 8; ++s) T0[(8 * lhi + s) * LT + l31] = xr[s];
+#pragma unroll
+        for (int t1 = 0; t1 < 2; ++t1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) TD[wr_base + (8 * (r >> 2) + (r & 3)) * LT] = c3[t1][r];
+            wave_lds_fence();
+            const float4 x0 = lds4(T0 + rd16), x1 = lds4(T0 + rd16 + 4);
+            const float xb[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};   // X[m = 8 kk + s][k = l15]
+            {
+                const float4 d0 = lds4(TD + rd16), d1 = lds4(TD + rd16 + 4);
+                const float4 e0 = lds4(TD + 16 * LT + rd16), e1 = lds4(TD + 16 * LT + rd16 + 4);
+                const float da[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                const float ea[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                adb1[2 * t1] += ((d0.x + d0.y) + (d0.z + d0.w)) + ((d1.x + d1.y) + (d1.z + d1.w));
+                adb1[2 * t1 + 1] += ((e0.x + e0.y) + (e0.z + e0.w)) + ((e1.x + e1.y) + (e1.z + e1.w));
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    aW1[2 * t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[s], xb[s], aW1[2 * t1], 0, 0, 0);
+                    aW1[2 * t1 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], xb[s], aW1[2 * t1 + 1], 0, 0, 0);
+                }
+            }
+            wave_lds_fence();
         }
     }
 
-    // ---- workgroup reduction of the partial gradient in LDS, then one coalesced row of `partial`
+    // ---- workgroup reduction of the 8 waves' partial gradients in LDS, then one coalesced row of `partial`
     __syncthreads();
-    float* red = sm.HB;
+    float* red = sm.wv;
     for (int k = tid; k < P + 4; k += NT) red[k] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = c_row(r, lane);
-        const int q = wave & 3;
-        atomicAdd(&red[OFF_W2 + (32 * (q >> 1) + row) * H + 32 * (q & 1) + l31], accW2[r]);
-        if (l31 < IN) atomicAdd(&red[OFF_W1 + (32 * (wave & 1) + row) * IN + l31], accW1[r]);
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+        for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                atomicAdd(&red[OFF_W2 + (32 * t2 + c_row(r, lane)) * H + 32 * t1 + l31], aW2[t2][t1][r]);
+        atomicAdd(&red[OFF_B2 + 32 * t2 + l31], adb2[t2]);
+        atomicAdd(&red[OFF_W3 + 32 * t2 + l31], adw3[t2]);
+        if (ACTOR) atomicAdd(&red[OFF_W4 + 32 * t2 + l31], adw4[t2]);
     }
-    atomicAdd(&red[OFF_B1 + 32 * ct + l31], acc_db1);
-    atomicAdd(&red[OFF_B2 + (tid & 63)], acc_db2);
-    atomicAdd(&red[OFF_W3 + (tid & 63)], acc_dw3);
-    if (ACTOR) atomicAdd(&red[OFF_W4 + (tid & 63)], acc_dw4);
-    if ((tid & 3) == 0) {
-        atomicAdd(&red[OFF_B3], acc_db3);
-        if (ACTOR) atomicAdd(&red[OFF_B4], acc_db4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&red[OFF_W1 + (16 * u + 4 * kk + r) * IN + l15], aW1[u][r]);
+        atomicAdd(&red[OFF_B1 + 16 * u + l15], adb1[u]);
+    }
+    if (lhi == 0) {
+        atomicAdd(&red[OFF_B3], adb3);
+        if (ACTOR) atomicAdd(&red[OFF_B4], adb4);
         atomicAdd(&red[P + 0], ACTOR ? st0 : st1);
         atomicAdd(&red[P + 1], st2);
         atomicAdd(&red[P + 2], st3);
@@ -510,16 +634,21 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
         return -1;
     }
     hipStream_t st = (hipStream_t)stream;
-    const long long tiles = (n_samples + kPassTile - 1) / kPassTile;
-    const int blocks = (int)(tiles < NAVPPO_MLP64_MAX_BLOCKS ? tiles : NAVPPO_MLP64_MAX_BLOCKS);
     float* partial = reinterpret_cast<float*>(workspace_dev);
     float* stats_partial = partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * NAVPPO_MLP64_ACTOR_PARAMS;
     const float inv_n = 1.0f / (float)n_samples;
-    hipLaunchKernelGGL((mlp64_pass<true, kPassTile>), dim3(blocks), dim3(kPassThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
+    if (((uintptr_t)obs_dev & 15) || ((uintptr_t)act_dev & 7)) {
+        g_err = "navppo_mlp64_loss_grad: obs must be 16-byte and act 8-byte aligned";
+        return -1;
+    }
+    const long long wtiles = (n_samples + 31) / 32;
+    const long long want = (wtiles + kWWaves - 1) / kWWaves;
+    const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
+    hipLaunchKernelGGL((mlp64_pass_w<true>), dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
                        rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, grad_dev, stats_dev);
     hipLaunchKernelGGL(reduce_partials, dim3((P_ACTOR + 63) / 64, kRedSlices), dim3(256), 0, st, partial, stats_partial, blocks,
                        P_ACTOR, inv_n, grad_dev, stats_dev);
-    hipLaunchKernelGGL((mlp64_pass<false, kPassTile>), dim3(blocks), dim3(kPassThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
+    hipLaunchKernelGGL((mlp64_pass_w<false>), dim3(blocks), dim3(kWThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
                        logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial,
                        grad_dev + P_ACTOR, stats_dev + 4);
     hipLaunchKernelGGL(reduce_partials, dim3((P_CRITIC + 63) / 64, kRedSlices), dim3(256), 0, st, partial, stats_partial, blocks,

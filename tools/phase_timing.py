@@ -4,11 +4,16 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from navbot_ppo_amd import _native, maps
-_native.LIB_PATH = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else "build/libnavsim_timing.so")
+CFG2 = "--cfg2" in sys.argv
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+_native.LIB_PATH = os.path.abspath(_args[0] if _args else "build/libnavsim_timing.so")
 from navbot_ppo_amd.env import NavSim
-N = 16384
-seg = maps.replicate_per_env(maps.stage_2(), N, seed=0)
-sim = NavSim(N, max_episode_steps=500, auto_reset=True, seed=0); sim.set_map(seg, per_env=True)
+N = 4096 if CFG2 else 16384
+sim = NavSim(N, max_episode_steps=500, auto_reset=True, seed=0)
+if CFG2:
+    sim.set_map(maps.stage_1(), per_env=False)
+else:
+    sim.set_map(maps.replicate_per_env(maps.stage_2(), N, seed=0), per_env=True)
 io = sim.alloc_io(); sim.reset(io.obs)
 acts = torch.rand((N, 2), device="cuda"); acts[:, 1] = acts[:, 1] * 2 - 1
 for k in range(20): sim.step(acts, io.obs, io.reward, io.done, io.arrive, io.ended)
@@ -39,3 +44,10 @@ for tq in range(0, int(en.max()), 5000):
     print(f"  t={tq/1000:5.1f}us running blocks: {int(((st <= tq) & (en > tq)).sum())}")
 print("xcc counts", np.bincount(xcc.astype(int)).tolist())
 print("first 16 blocks xcc", xcc[:16].tolist(), "start", st[:16].tolist())
+if "--per-xcd" in sys.argv:
+    for q in range(8):
+        m = xcc == q
+        order = np.argsort(st[m])
+        print(f"xcc {q}: starts(ns) {st[m][order][:40].tolist()}")
+        print(f"        cu/se     {[(int(s), int(c)) for s, c in zip(se[m][order][:40], cu[m][order][:40])]}")
+        print(f"        ends(ns)  {en[m][order][:40].tolist()}")
