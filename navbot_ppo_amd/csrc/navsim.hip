@@ -81,6 +81,7 @@ struct Params {
     const float4* seg;        // [S] or [N][S]
     const float* spawn_scan;  // [K][B] or [N][K][B] nearest hits (+inf = none) at the K start poses (K = 1: the cfg spawn pose)
     const double* starts;     // [K][3] start poses (x, y, yaw)
+    const double* starts_sc;  // [K][2] (cos, sin)(yaw / 2) of the start poses, evaluated on the device
     const double* goals;      // [G][2] goal points; G == 0: uniform goal box + rejection rectangles
     int K, G;
     double min_dist, max_dist;
@@ -223,13 +224,16 @@ __device__ __forceinline__ float lidar_noise(uint32_t k0, uint32_t k1, uint64_t 
     return (b & 1) ? rad * sinf(ang) : rad * cosf(ang);
 }
 
-__device__ __forceinline__ bool goal_rejected(const Rects* R, int which, double gx, double gy) {
+// No early exit: the loop bounds and addresses are then wave-uniform (scalar loads from the constant cache, all
+// rectangles in flight at once) instead of one dependent L2 round trip per rectangle per lane.
+__device__ __forceinline__ bool goal_rejected(const Rects* __restrict__ R, int which, double gx, double gy) {
     const int n = R->n[which];
+    bool rej = false;
     for (int k = 0; k < n; ++k) {
         const double* q = R->r[which][k];
-        if (q[0] <= gx && gx <= q[1] && q[2] <= gy && gy <= q[3]) return true;
+        rej |= (q[0] <= gx) & (gx <= q[1]) & (q[2] <= gy) & (gy <= q[3]);
     }
-    return false;
+    return rej;
 }
 
 // goal ~ U(lo,hi)^2 with rejection (environment_new.py:337-345 reset, :245-253 respawn);
@@ -313,6 +317,13 @@ struct StepSmem {
     float2 sv_act[EPB], sv_pact[EPB];
     uint32_t sv_ctr[EPB];
     int sv_step[EPB];
+    // next-episode records prepared by pose lanes 1 and 2 of each env while the rays are cast:
+    //   [0] the reset that follows a collision / timeout, [1] the reset that follows an arrival (after the re-spawn draw)
+    double sp_d[2][9][EPB];   // start x, y, yaw, goal x, y, distance, yaw (deg), rel_theta, diff
+    uint32_t sp_ctr[2][EPB];
+    int sp_k[2][EPB];
+    double sp_rg[2][EPB];     // the arrival re-spawn goal (environment_new.py:245-253) and the draw counter after it
+    uint32_t sp_rctr[EPB];
 };
 
 // Sign-normalised ray / segment test: with sd = sign bit of den, K = k^sd, U = un^sd, Dn = |den| the
@@ -389,6 +400,8 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     __shared__ StepSmem<NB, EPB> sm;
     __shared__ float4 seg_tile[PER_ENV ? 1 : kSegTile];
     __shared__ int next_env;
+    __shared__ int tile_tiny[4];   // shared map, one slot per loading wave: its part of the staged tile holds a
+                                   // degenerate-small segment (div_pos out of range)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -490,6 +503,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             }
         }
         if (tid == 0) next_env = 4 - PW;  // the first envs are pre-assigned to the non-pose waves
+        if (lane == 0) tile_tiny[wave] = 0;
     }
     if (wave >= PW) {
         // ---------------- other waves, part 1: nothing here depends on the pose
@@ -498,7 +512,14 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             if (wave - PW < nloc) prefetch(wave - PW, pre);
         } else {
             const int ns = min(kSegTile, P.S);
-            for (int j = tid - 64 * PW; j < ns; j += kThreads - 64 * PW) seg_tile[j] = P.seg[j];
+            bool tiny = false;
+            for (int j = tid - 64 * PW; j < ns; j += kThreads - 64 * PW) {
+                const float4 g = P.seg[j];
+                seg_tile[j] = g;
+                tiny |= fmaxf(fabsf(g.z - g.x), fabsf(g.w - g.y)) < 0x1p-10f;
+            }
+            const int any_tiny = __any(tiny) ? 1 : 0;
+            if (lane == 0) tile_tiny[wave] = any_tiny;
         }
     }
     __syncthreads();  // barrier A: origins / directions / first segment tile visible
@@ -508,15 +529,53 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         for (int b = rr; b < B; b += 8)
             sm.noise[b * EPB + el_pose] = lidar_noise(P.key0, P.key1, P.env_id_base + (uint64_t)i, ctr, (uint32_t)step0, b);
     }
-    if (own) {
-        // ---------------- pose lanes, part 2 (the other waves are already ray-casting): goal geometry
-        goal_angles_q(x, y, sm.sc[el_pose][7][1], sm.sc[el_pose][7][0], gx, gy, yaw, rel_theta, diff);
-        dist = hypot(gx - x, gy - y);  // environment_new.py:203
+    // ---------------- pose lanes, part 2 (the other waves are already ray-casting): goal geometry.
+    // Lane 0 of an env works on the pose it just moved to.  Lanes 1 and 2 prepare, in the same instructions, the episode
+    // that starts if this step ends the current one (ppo.py:582-593 + Env.reset, environment_new.py:312-382): an episode
+    // draws from the goal stream only when it ends, so its successor is known now -- lane 1 for an end by collision or
+    // timeout, lane 2 for an end by arrival (the arrival re-spawn draw of :245-253 comes first).  The owner picks one of
+    // the two records in part 3 instead of running Philox + a second goal geometry behind everyone else.
+    const bool spec = pose_lane && (rr == 1 || rr == 2) && (el_pose < nloc) && (P.auto_reset || (rr == 2 && P.respawn));
+    if (own || spec) {
+        double px = x, py = y, pth = th, qz = 0, qw = 1, tgx = gx, tgy = gy, rgx = 0, rgy = 0;
+        uint32_t sctr = ctr, rctr = ctr;
+        int sk = 0;
+        if (own) {
+            qz = sm.sc[el_pose][7][1];
+            qw = sm.sc[el_pose][7][0];
+        } else {
+            if (rr == 2 && P.respawn) {
+                sample_goal(P, i, 1, sctr, rgx, rgy);
+                rctr = sctr;
+            }
+            if (P.auto_reset) {
+                sample_episode(P, i, sctr, sk, tgx, tgy);
+                px = P.starts[3 * sk]; py = P.starts[3 * sk + 1]; pth = P.starts[3 * sk + 2];
+                qw = P.starts_sc[2 * sk]; qz = P.starts_sc[2 * sk + 1];
+            }
+        }
+        if (own || P.auto_reset) {
+            goal_angles_q(px, py, qz, qw, tgx, tgy, yaw, rel_theta, diff);
+            dist = hypot(tgx - px, tgy - py);  // environment_new.py:203 ; getGoalDistace, :116-120
+        }
         const int e = el_pose;
-        sm.sv_d[0][e] = x; sm.sv_d[1][e] = y; sm.sv_d[2][e] = th; sm.sv_d[3][e] = gx; sm.sv_d[4][e] = gy;
-        sm.sv_d[5][e] = pdist; sm.sv_d[6][e] = dist; sm.sv_d[7][e] = yaw; sm.sv_d[8][e] = rel_theta;
-        sm.sv_d[9][e] = diff; sm.sv_d[10][e] = ret0;
-        sm.sv_act[e] = act; sm.sv_pact[e] = pact; sm.sv_ctr[e] = ctr; sm.sv_step[e] = step0;
+        if (own) {
+            sm.sv_d[0][e] = x; sm.sv_d[1][e] = y; sm.sv_d[2][e] = th; sm.sv_d[3][e] = gx; sm.sv_d[4][e] = gy;
+            sm.sv_d[5][e] = pdist; sm.sv_d[6][e] = dist; sm.sv_d[7][e] = yaw; sm.sv_d[8][e] = rel_theta;
+            sm.sv_d[9][e] = diff; sm.sv_d[10][e] = ret0;
+            sm.sv_act[e] = act; sm.sv_pact[e] = pact; sm.sv_ctr[e] = ctr; sm.sv_step[e] = step0;
+        } else {
+            const int c = rr - 1;
+            sm.sp_d[c][0][e] = px; sm.sp_d[c][1][e] = py; sm.sp_d[c][2][e] = pth; sm.sp_d[c][3][e] = tgx;
+            sm.sp_d[c][4][e] = tgy; sm.sp_d[c][5][e] = dist; sm.sp_d[c][6][e] = yaw; sm.sp_d[c][7][e] = rel_theta;
+            sm.sp_d[c][8][e] = diff;
+            sm.sp_ctr[c][e] = sctr;
+            sm.sp_k[c][e] = sk;
+            if (rr == 2) {
+                sm.sp_rg[0][e] = rgx; sm.sp_rg[1][e] = rgy;
+                sm.sp_rctr[e] = rctr;
+            }
+        }
     }
     if constexpr (PER_ENV) {
         auto grab = [&]() {
@@ -569,46 +628,72 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             cur = nxt;
         }
     } else {
-        // lane = ray (env, beam); segments come from the LDS tile two at a time (wave-wide broadcast reads)
+        // lane = ray (env, beam) on the NON-pose waves only (the pose waves are busy with the goal geometry until later
+        // than the whole cast takes); segments come from the LDS tile as wave-wide broadcast reads
         constexpr int NR = EPB * NB;                          // rays of this block
-        constexpr int RPT = (NR + kThreads - 1) / kThreads;   // rays per thread
+        constexpr int NRT = kThreads - 64 * PW;               // ray threads
+        constexpr int RPT = (NR + NRT - 1) / NRT;             // rays per ray thread
+        const int rt = tid - 64 * PW;
         float ox[RPT], oy[RPT], dc[RPT], ds[RPT];
         unsigned best[RPT];
+        if (rt >= 0) {
 #pragma unroll
-        for (int m = 0; m < RPT; ++m) {
-            const int r = min(tid + m * kThreads, NR - 1);
-            const int el = r / NB, b = r % NB;
-            const float2 o = sm.org[el];
-            const float2 d = sm.dir[b * EPB + el];
-            ox[m] = o.x; oy[m] = o.y; dc[m] = d.x; ds[m] = d.y;
-            best[m] = kInfBits;
+            for (int m = 0; m < RPT; ++m) {
+                const int r = min(rt + m * NRT, NR - 1);
+                const int el = r / NB, b = r % NB;
+                const float2 o = sm.org[el];
+                const float2 d = sm.dir[b * EPB + el];
+                ox[m] = o.x; oy[m] = o.y; dc[m] = d.x; ds[m] = d.y;
+                best[m] = kInfBits;
+            }
         }
         for (int s0 = 0; s0 < P.S; s0 += kSegTile) {  // uniform trip count
             const int ns = min(kSegTile, P.S - s0);
             if (s0 > 0) {
                 __syncthreads();
-                for (int j = tid; j < ns; j += kThreads) seg_tile[j] = P.seg[s0 + j];
+                bool tiny = false;
+                for (int j = tid; j < ns; j += kThreads) {
+                    const float4 g = P.seg[s0 + j];
+                    seg_tile[j] = g;
+                    tiny |= fmaxf(fabsf(g.z - g.x), fabsf(g.w - g.y)) < 0x1p-10f;
+                }
+                const int any_tiny = __any(tiny) ? 1 : 0;
+            if (lane == 0) tile_tiny[wave] = any_tiny;
                 __syncthreads();
             }
-            for (int j = 0; j < ns; ++j) {
-                const float4 g = seg_tile[j];
-                const float ex = g.z - g.x, ey = g.w - g.y;
-                const bool tiny = fmaxf(fabsf(ex), fabsf(ey)) < 0x1p-10f;  // wave-uniform: the segment is broadcast
+            if (rt < 0) continue;
+            if (__builtin_expect(tile_tiny[0] | tile_tiny[1] | tile_tiny[2] | tile_tiny[3], 0)) {   // div_pos needs |den| >= 2^-60: such tiles take the plain IEEE divide
+                for (int j = 0; j < ns; ++j) {
+                    const float4 g = seg_tile[j];
+                    const float ex = g.z - g.x, ey = g.w - g.y;
 #pragma unroll
-                for (int m = 0; m < RPT; ++m) {
-                    const float rx = g.x - ox[m], ry = g.y - oy[m];
-                    const float k = fmaf(rx, ey, -(ry * ex));
-                    const unsigned t = __builtin_expect(tiny, 0)
-                                           ? (__float_as_uint(ray_seg(rx, ry, ex, ey, k, dc[m], ds[m])) & 0x7fffffffu)
-                                           : ray_seg_bits(rx, ry, ex, ey, k, dc[m], ds[m]);
-                    best[m] = min(best[m], t);
+                    for (int m = 0; m < RPT; ++m) {
+                        const float rx = g.x - ox[m], ry = g.y - oy[m];
+                        const float k = fmaf(rx, ey, -(ry * ex));
+                        best[m] = min(best[m], __float_as_uint(ray_seg(rx, ry, ex, ey, k, dc[m], ds[m])) & 0x7fffffffu);
+                    }
+                }
+            } else {
+                // branch-free body: iterations are independent, so the unrolled copies overlap their division chains
+#pragma unroll 4
+                for (int j = 0; j < ns; ++j) {
+                    const float4 g = seg_tile[j];
+                    const float ex = g.z - g.x, ey = g.w - g.y;
+#pragma unroll
+                    for (int m = 0; m < RPT; ++m) {
+                        const float rx = g.x - ox[m], ry = g.y - oy[m];
+                        const float k = fmaf(rx, ey, -(ry * ex));
+                        best[m] = min(best[m], ray_seg_bits(rx, ry, ex, ey, k, dc[m], ds[m]));
+                    }
                 }
             }
         }
+        if (rt >= 0) {
 #pragma unroll
-        for (int m = 0; m < RPT; ++m) {
-            const int r = tid + m * kThreads;
-            if (r < NR) sm.rng[(r % NB) * EPB + (r / NB)] = best[m];
+            for (int m = 0; m < RPT; ++m) {
+                const int r = rt + m * NRT;
+                if (r < NR) sm.rng[(r % NB) * EPB + (r / NB)] = best[m];
+            }
         }
     }
     __syncthreads();  // barrier B: nearest hits complete
@@ -632,9 +717,10 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         pdist = dist;
         if (d) r = -100.;
         if (a) r = 120.;
-        if (a && P.respawn) {  // :245-267
-            sample_goal(P, i, 1, ctr, gx, gy);
-            pdist = hypot(gx - x, gy - y);
+        if (a && P.respawn) {  // :245-267 (drawn by lane 2 in part 2)
+            gx = sm.sp_rg[0][e]; gy = sm.sp_rg[1][e];
+            ctr = sm.sp_rctr[e];
+            if (!P.auto_reset) pdist = hypot(gx - x, gy - y);  // with auto_reset the arrival ends the episode: pdist is re-based below
         }
         int step = step0 + 1;
         double ret = ret0 + r;
@@ -649,15 +735,15 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             if (ep_length) ep_length[i] = step;
         }
         float2 next_pact = act;  // ppo.py:543
-        if (end && P.auto_reset) {  // ppo.py:582-593 + Env.reset, environment_new.py:312-382
-            int k0;
-            sample_episode(P, i, ctr, k0, gx, gy);
-            x = P.starts[3 * k0]; y = P.starts[3 * k0 + 1]; th = P.starts[3 * k0 + 2];
+        if (end && P.auto_reset) {  // ppo.py:582-593 + Env.reset, environment_new.py:312-382: the record prepared in part 2
+            const int c = a ? 1 : 0;
+            x = sm.sp_d[c][0][e]; y = sm.sp_d[c][1][e]; th = sm.sp_d[c][2][e]; gx = sm.sp_d[c][3][e]; gy = sm.sp_d[c][4][e];
+            dist = sm.sp_d[c][5][e]; yaw = sm.sp_d[c][6][e]; rel_theta = sm.sp_d[c][7][e]; diff = sm.sp_d[c][8][e];
+            ctr = sm.sp_ctr[c][e];
+            const int k0 = sm.sp_k[c][e];
             step = 0;
             ret = 0;
             next_pact = make_float2(0.f, 0.f);
-            goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
-            dist = hypot(gx - x, gy - y);
             pdist = dist;  // getGoalDistace, :116-120,:359
             const float* sp = P.spawn_scan + ((PER_ENV ? (size_t)i * P.K : 0) + k0) * B;
             write_obs_row(row, sp, 1, noise, EPB, sigma, below_min, B, 0.f, 0.f, dist, yaw, rel_theta, diff, P.diag);
@@ -680,6 +766,16 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         float* o = reinterpret_cast<float*>(obs_out) + (size_t)base * D;
         for (int k = tid; k < n_out; k += kThreads) o[k] = sm.obs[(k / D) * DP + (k % D)];
     }
+}
+
+// (cos, sin)(yaw / 2) of the start poses: the orientation quaternion goal_angles() derives from a yaw, tabulated with
+// the device's own cos / sin so that the step kernel's speculative lanes reproduce goal_angles(x, y, yaw, ...) bit for bit
+__global__ void starts_sc_kernel(const double* __restrict__ starts, int K, double* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const double th = starts[3 * k + 2];
+    out[2 * k] = cos(th / 2);
+    out[2 * k + 1] = sin(th / 2);
 }
 
 // ---------------------------------------------------------------- reset (Env.reset, masked)
@@ -782,6 +878,7 @@ struct navsim {
     Rects rects_host;
     float* spawn_scan_dev = nullptr;
     double* starts_dev = nullptr;   // [K][3]
+    double* starts_sc_dev = nullptr;  // [K][2]
     double* goals_dev = nullptr;    // [G][2]
     const float* seg_dev = nullptr;
     bool has_map = false;
@@ -814,6 +911,22 @@ static void launch_step(const navsim* h, const float* action, const float* past,
         case 8: launch_step_epb<NB, 8>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
         default: launch_step_epb<NB, 16>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
     }
+}
+
+// Uploads the start-pose table [K][3] and tabulates its half-angle (cos, sin) on the device.
+static int upload_starts(navsim* h, const double* starts_host, int K, hipStream_t st) {
+    (void)hipFree(h->starts_dev);
+    (void)hipFree(h->starts_sc_dev);
+    h->starts_dev = h->starts_sc_dev = nullptr;
+    HIP_TRY(hipMalloc(&h->starts_dev, sizeof(double) * 3 * K));
+    HIP_TRY(hipMalloc(&h->starts_sc_dev, sizeof(double) * 2 * K));
+    HIP_TRY(hipMemcpy(h->starts_dev, starts_host, sizeof(double) * 3 * K, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(starts_sc_kernel, dim3((K + 63) / 64), dim3(64), 0, st, h->starts_dev, K, h->starts_sc_dev);
+    HIP_TRY(hipGetLastError());
+    h->P.starts = h->starts_dev;
+    h->P.starts_sc = h->starts_sc_dev;
+    h->P.K = K;
+    return NAVSIM_OK;
 }
 
 #pragma GCC visibility push(default)
@@ -912,10 +1025,8 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
     // start-pose table: K = 1, the cfg spawn pose (turtlebot3_stage_1.launch:3-5) until navsim_set_spawn_sampler
     {
         const double sp[3] = {cfg->spawn_x, cfg->spawn_y, cfg->spawn_yaw};
-        HIP_TRY(hipMalloc(&h->starts_dev, sizeof(sp)));
-        HIP_TRY(hipMemcpy(h->starts_dev, sp, sizeof(sp), hipMemcpyHostToDevice));
-        P.starts = h->starts_dev;
-        P.K = 1;
+        const int rc = upload_starts(h, sp, 1, nullptr);
+        if (rc != NAVSIM_OK) return rc;
         P.G = 0;
         P.goals = nullptr;
     }
@@ -930,6 +1041,7 @@ void navsim_destroy(navsim_t* h) {
     (void)hipFree(h->rects_dev);
     (void)hipFree(h->spawn_scan_dev);
     (void)hipFree(h->starts_dev);
+    (void)hipFree(h->starts_sc_dev);
     (void)hipFree(h->goals_dev);
     delete h;
 }
@@ -979,18 +1091,17 @@ int navsim_set_spawn_sampler(navsim_t* h, const double* starts_host, int32_t n_s
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipStreamSynchronize(st));
     Params& P = h->P;
-    (void)hipFree(h->starts_dev);
     (void)hipFree(h->goals_dev);
-    h->starts_dev = h->goals_dev = nullptr;
-    HIP_TRY(hipMalloc(&h->starts_dev, sizeof(double) * 3 * n_starts));
-    HIP_TRY(hipMemcpy(h->starts_dev, starts_host, sizeof(double) * 3 * n_starts, hipMemcpyHostToDevice));
+    h->goals_dev = nullptr;
+    {
+        const int rc = upload_starts(h, starts_host, n_starts, st);
+        if (rc != NAVSIM_OK) return rc;
+    }
     if (n_goals > 0) {
         HIP_TRY(hipMalloc(&h->goals_dev, sizeof(double) * 2 * n_goals));
         HIP_TRY(hipMemcpy(h->goals_dev, goals_host, sizeof(double) * 2 * n_goals, hipMemcpyHostToDevice));
     }
-    P.starts = h->starts_dev;
     P.goals = h->goals_dev;
-    P.K = n_starts;
     P.G = n_goals;
     P.min_dist = min_dist;
     P.max_dist = max_dist;
