@@ -37,12 +37,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 128;    // samples per workgroup of mlp64_act
 constexpr int H = 64;      // hidden width
 constexpr int IN = 16;     // observation width
-constexpr int LDH = H + 1; // padded LDS row strides (odd: conflict-free for row-per-lane and column-per-lane reads)
-constexpr int LDX = IN + 1;
-constexpr int kThreads = 256;
 
 // flat parameter layout of one net (nn.Module.named_parameters order: layer1.weight, layer1.bias, layer2.weight,
 // layer2.bias, layer3.weight, layer3.bias [, layer4.weight, layer4.bias])
@@ -517,72 +513,91 @@ __device__ __forceinline__ void philox10(uint32_t c0, uint32_t c1, uint32_t c2, 
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__global__ __launch_bounds__(kThreads) void mlp64_act(const float* __restrict__ params, const float* __restrict__ obs,
-                                                      const float* __restrict__ noise, long long n,
-                                                      const float* __restrict__ var_ptr, uint64_t seed,
-                                                      uint64_t env_id_base, const uint32_t* __restrict__ step_base,
-                                                      uint32_t step_offset,
-                                                      float* __restrict__ act, float* __restrict__ logp,
-                                                      float* __restrict__ mean_out) {
-    __shared__ float X[TM * LDX], H1[TM * LDH], H2[TM * LDH], W1[H * LDX], W2[H * LDH], b1s[H], b2s[H], w3s[H], w4s[H];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-    const long long m_base = (long long)blockIdx.x * TM;
+// One wave = 16 envs, no LDS and no barrier: the 4096-env step of BASELINE configs[1] is 256 independent waves, one per
+// CU (round-1 history: 32 workgroups of 128 envs staging weights and activations through LDS took 10.9 us per call,
+// most of it on 32 of the 256 CUs).  Computed transposed like the pass kernel, on v_mfma_f32_16x16x4_f32:
+//   H1^T[n][m] = relu(b1 + W1 X^T)   A = W1 rows (k-permuted: lane group kk reads columns 4 kk .. 4 kk + 3, one dwordx4),
+//                                     B = the lane's own 4 observation floats
+//   H2^T       = relu(b2 + W2 H1^T)  B = the H1^T accumulators: register r of lane (m, kk) is row 4 kk + r of its tile
+// weights come straight from L2 (21 KB shared by every wave), 37 dwordx4 per lane, all requested up front.
+constexpr int kActEnvs = 16;   // envs per wave
+
+__global__ __launch_bounds__(64) void mlp64_act(const float* __restrict__ params, const float* __restrict__ obs,
+                                                const float* __restrict__ noise, long long n,
+                                                const float* __restrict__ var_ptr, uint64_t seed, uint64_t env_id_base,
+                                                const uint32_t* __restrict__ step_base, uint32_t step_offset,
+                                                float* __restrict__ act, float* __restrict__ logp,
+                                                float* __restrict__ mean_out) {
+    const int lane = threadIdx.x, l15 = lane & 15, kk = lane >> 4;
+    const long long m = (long long)blockIdx.x * kActEnvs + l15;
+    const bool valid = m < n;
+    auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+    // ---- every operand request goes out before the first MFMA
+    const float4 xq = valid ? ld4(obs + m * IN + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);   // X[m][4 kk + s]
+    float4 w1q[4], b1q[4], b2q[4], w3q[4], w4q[4], w2q[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        w1q[t] = ld4(params + OFF_W1 + (16 * t + l15) * IN + 4 * kk);   // W1[16 t + l15][4 kk + s]
+        b1q[t] = ld4(params + OFF_B1 + 16 * t + 4 * kk);                 // rows 16 t + 4 kk + r of the accumulator
+        b2q[t] = ld4(params + OFF_B2 + 16 * t + 4 * kk);
+        w3q[t] = ld4(params + OFF_W3 + 16 * t + 4 * kk);
+        {   // layer4.weight starts one float after layer3.bias: not 16-byte aligned, so four dword loads
+            const float* w4p = params + OFF_W4 + 16 * t + 4 * kk;
+            w4q[t] = make_float4(w4p[0], w4p[1], w4p[2], w4p[3]);
+        }
+#pragma unroll
+        for (int t1 = 0; t1 < 4; ++t1) w2q[t][t1] = ld4(params + OFF_W2 + (16 * t + l15) * H + 16 * t1 + 4 * kk);
+    }
     const float var = *var_ptr;
     const uint32_t step = (step_base ? *step_base : 0u) + step_offset;
-    for (int k = tid; k < H * IN; k += kThreads) W1[(k / IN) * LDX + (k % IN)] = params[OFF_W1 + k];
-    for (int k = tid; k < H * H; k += kThreads) W2[(k / H) * LDH + (k % H)] = params[OFF_W2 + k];
-    if (tid < H) {
-        b1s[tid] = params[OFF_B1 + tid]; b2s[tid] = params[OFF_B2 + tid];
-        w3s[tid] = params[OFF_W3 + tid]; w4s[tid] = params[OFF_W4 + tid];
-    }
-    for (int k = tid; k < TM * IN; k += kThreads) {
-        const int m = k / IN, c = k % IN;
-        X[m * LDX + c] = (m_base + m < n) ? obs[(m_base + m) * IN + c] : 0.f;
-    }
-    __syncthreads();
-    {
-        f32x16 c0 = zero16(), c1 = zero16();
-        const float* a_ptr = X + (32 * wave + l31) * LDX + lhi;
+    const float b3 = params[OFF_B3], b4 = params[OFF_B4];
+
+    const float xs[4] = {xq.x, xq.y, xq.z, xq.w};
+    f32x4 c1[4], c2[4];
 #pragma unroll
-        for (int k0 = 0; k0 < IN; k0 += 2) {
-            const float a = a_ptr[k0];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, W1[l31 * LDX + lhi + k0], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, W1[(32 + l31) * LDX + lhi + k0], c1, 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+        c1[t] = f32x4{b1q[t].x, b1q[t].y, b1q[t].z, b1q[t].w};
+        c2[t] = f32x4{b2q[t].x, b2q[t].y, b2q[t].z, b2q[t].w};
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {   // four independent accumulators back to back
+            const float a = s4 == 0 ? w1q[t].x : s4 == 1 ? w1q[t].y : s4 == 2 ? w1q[t].z : w1q[t].w;
+            c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xs[s4], c1[t], 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * wave + c_row(r, lane);
-            H1[row * LDH + l31] = fmaxf(c0[r] + b1s[l31], 0.f);
-            H1[row * LDH + 32 + l31] = fmaxf(c1[r] + b1s[32 + l31], 0.f);
-        }
-    }
-    __syncthreads();
-    {
-        f32x16 c0 = zero16(), c1 = zero16();
-        const float* a_ptr = H1 + (32 * wave + l31) * LDH + lhi;
-#pragma unroll 8
-        for (int k0 = 0; k0 < H; k0 += 2) {
-            const float a = a_ptr[k0];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, W2[l31 * LDH + lhi + k0], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, W2[(32 + l31) * LDH + lhi + k0], c1, 0, 0, 0);
-        }
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * wave + c_row(r, lane);
-            H2[row * LDH + l31] = fmaxf(c0[r] + b2s[l31], 0.f);
-            H2[row * LDH + 32 + l31] = fmaxf(c1[r] + b2s[32 + l31], 0.f);
+        for (int r = 0; r < 4; ++r) c1[t][r] = relu_bits(c1[t][r]);
+#pragma unroll
+    for (int t1 = 0; t1 < 4; ++t1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+                const float4 w = w2q[t2][t1];   // W2[16 t2 + l15][16 t1 + 4 kk + r]
+                const float a = r == 0 ? w.x : r == 1 ? w.y : r == 2 ? w.z : w.w;
+                c2[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, c1[t1][r], c2[t2], 0, 0, 0);
+            }
+    float z3 = 0.f, z4 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float w3v[4] = {w3q[t].x, w3q[t].y, w3q[t].z, w3q[t].w}, w4v[4] = {w4q[t].x, w4q[t].y, w4q[t].z, w4q[t].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float h = relu_bits(c2[t][r]);
+            z3 = fmaf(h, w3v[r], z3);
+            z4 = fmaf(h, w4v[r], z4);
         }
     }
-    __syncthreads();
-    if (tid < TM && m_base + tid < n) {
-        const long long m = m_base + tid;
-        float z3 = params[OFF_B3], z4 = params[OFF_B4];
-#pragma unroll 8
-        for (int k = 0; k < H; ++k) {
-            const float h = H2[tid * LDH + k];
-            z3 = fmaf(h, w3s[k], z3);
-            z4 = fmaf(h, w4s[k], z4);
-        }
+    z3 += __shfl_xor(z3, 16, 64);
+    z4 += __shfl_xor(z4, 16, 64);
+    z3 += __shfl_xor(z3, 32, 64);
+    z4 += __shfl_xor(z4, 32, 64);
+    z3 += b3;
+    z4 += b4;
+    if (kk == 0 && valid) {
         const float mu0 = 1.0f / (1.0f + expf(-z3)), mu1 = tanhf(z4);
         float e0, e1;
         if (noise) {
@@ -668,8 +683,12 @@ int navppo_mlp64_act(const float* actor_params_dev, const float* obs_dev, const 
         g_err = "navppo_mlp64_act: bad argument";
         return -1;
     }
-    const int blocks = (int)((n_envs + TM - 1) / TM);
-    hipLaunchKernelGGL(mlp64_act, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, actor_params_dev, obs_dev, noise_dev,
+    if (((uintptr_t)actor_params_dev & 15) || ((uintptr_t)obs_dev & 15)) {
+        g_err = "navppo_mlp64_act: params and obs must be 16-byte aligned";
+        return -1;
+    }
+    const int blocks = (int)((n_envs + kActEnvs - 1) / kActEnvs);
+    hipLaunchKernelGGL(mlp64_act, dim3(blocks), dim3(64), 0, (hipStream_t)stream, actor_params_dev, obs_dev, noise_dev,
                        (long long)n_envs, var_dev, seed, env_id_base, step_base_dev, step_offset, act_dev, logp_dev, mean_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
