@@ -607,6 +607,8 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
                 // (coordinates are documented to be < 2^19); such tiles take the plain IEEE divide.
                 const bool tiny = fmaxf(fabsf(ex), fabsf(ey)) < 0x1p-10f;
                 if (__builtin_expect(__any(tiny), 0)) {
+                    // the empty volatile asm keeps this a real (wave-uniform) branch the compiler cannot speculate
+                    asm volatile("; degenerate-segment tile" ::: "memory");
 #pragma unroll
                     for (int b = 0; b < NB; ++b)
                         best[b] = min(best[b], __float_as_uint(ray_seg(rx, ry, ex, ey, k, dc[b], ds[b])) & 0x7fffffffu);
