@@ -430,8 +430,16 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     const int el_pose = 8 * wave + (lane >> 3);  // env (local) this pose lane works for
     const int rr = lane & 7;
     const bool pose_lane = (wave < PW) && (el_pose < EPB);
-    const bool own = pose_lane && (rr == 0) && (el_pose < nloc);
     const int i = base + el_pose;
+    // Parts 2 and 3 run lane-dense instead (a wave instruction costs the same with 8 or 64 active lanes, and the float64
+    // geometry is ~1000 of them): the goal geometry and the rules of ALL the block's envs on lanes 0..EPB-1 of wave 0,
+    // the two next-episode records per env on 2 EPB lanes of the last pose wave (the same wave, behind the owners, when
+    // there is only one).  State crosses from the part-1 lanes through LDS (sv_*).
+    const bool own = (wave == 0) && (lane < nloc);            // lane = env for the geometry / rules lanes
+    constexpr int kSpecWave = PW - 1;
+    constexpr int kSpecLane0 = (PW == 1) ? EPB : 0;
+    const int sl = lane - kSpecLane0;                         // spec lane index: case (sl / EPB), env (sl % EPB)
+    const bool spec_lane = (wave == kSpecWave) && (sl >= 0) && (sl < 2 * EPB) && ((sl % EPB) < nloc);
 
     float4 pre[PF];  // prefetched segments of the current work item (per-env maps)
     auto prefetch = [&](int el, float4 (&dst)[PF]) {
@@ -491,6 +499,12 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
                 const double ox = x + kLidarX * cth;
                 const double oy = y + kLidarX * sth;
                 sm.org[el_pose] = make_float2((float)ox, (float)oy);
+                if (el_pose < nloc) {  // hand the env over to its geometry / rules lane
+                    const int e = el_pose;
+                    sm.sv_d[0][e] = x; sm.sv_d[1][e] = y; sm.sv_d[2][e] = th; sm.sv_d[3][e] = gx; sm.sv_d[4][e] = gy;
+                    sm.sv_d[5][e] = pdist; sm.sv_d[10][e] = ret0;
+                    sm.sv_act[e] = act; sm.sv_pact[e] = pact; sm.sv_ctr[e] = ctr; sm.sv_step[e] = step0;
+                }
             }
             {
                 const double cth = sm.sc[el_pose][6][0], sth = sm.sc[el_pose][6][1];
@@ -529,27 +543,30 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         for (int b = rr; b < B; b += 8)
             sm.noise[b * EPB + el_pose] = lidar_noise(P.key0, P.key1, P.env_id_base + (uint64_t)i, ctr, (uint32_t)step0, b);
     }
-    // ---------------- pose lanes, part 2 (the other waves are already ray-casting): goal geometry.
-    // Lane 0 of an env works on the pose it just moved to.  Lanes 1 and 2 prepare, in the same instructions, the episode
-    // that starts if this step ends the current one (ppo.py:582-593 + Env.reset, environment_new.py:312-382): an episode
-    // draws from the goal stream only when it ends, so its successor is known now -- lane 1 for an end by collision or
-    // timeout, lane 2 for an end by arrival (the arrival re-spawn draw of :245-253 comes first).  The owner picks one of
-    // the two records in part 3 instead of running Philox + a second goal geometry behind everyone else.
-    const bool spec = pose_lane && (rr == 1 || rr == 2) && (el_pose < nloc) && (P.auto_reset || (rr == 2 && P.respawn));
+    // ---------------- part 2 (the other waves are already ray-casting): goal geometry.
+    // An owner lane works on the pose its env just moved to.  The spec lanes prepare, with the same instructions, the
+    // episode that starts if this step ends the current one (ppo.py:582-593 + Env.reset, environment_new.py:312-382): an
+    // episode draws from the goal stream only when it ends, so its successor is known now -- record 0 for an end by
+    // collision or timeout, record 1 for an end by arrival (the arrival re-spawn draw of :245-253 comes first).  The
+    // owner picks one of the two in part 3 instead of running Philox + a second goal geometry behind everyone else.
+    const bool spec = spec_lane && (P.auto_reset || (sl >= EPB && P.respawn));
     if (own || spec) {
-        double px = x, py = y, pth = th, qz = 0, qw = 1, tgx = gx, tgy = gy, rgx = 0, rgy = 0;
-        uint32_t sctr = ctr, rctr = ctr;
+        const int e = own ? lane : sl % EPB;
+        const int ie = base + e;
+        double px = 0, py = 0, pth = 0, qz = 0, qw = 1, tgx = 0, tgy = 0, rgx = 0, rgy = 0;
+        uint32_t sctr = sm.sv_ctr[e], rctr = sctr;
         int sk = 0;
         if (own) {
-            qz = sm.sc[el_pose][7][1];
-            qw = sm.sc[el_pose][7][0];
+            px = sm.sv_d[0][e]; py = sm.sv_d[1][e]; tgx = sm.sv_d[3][e]; tgy = sm.sv_d[4][e];
+            qz = sm.sc[e][7][1];
+            qw = sm.sc[e][7][0];
         } else {
-            if (rr == 2 && P.respawn) {
-                sample_goal(P, i, 1, sctr, rgx, rgy);
+            if (sl >= EPB && P.respawn) {
+                sample_goal(P, ie, 1, sctr, rgx, rgy);
                 rctr = sctr;
             }
             if (P.auto_reset) {
-                sample_episode(P, i, sctr, sk, tgx, tgy);
+                sample_episode(P, ie, sctr, sk, tgx, tgy);
                 px = P.starts[3 * sk]; py = P.starts[3 * sk + 1]; pth = P.starts[3 * sk + 2];
                 qw = P.starts_sc[2 * sk]; qz = P.starts_sc[2 * sk + 1];
             }
@@ -558,20 +575,16 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             goal_angles_q(px, py, qz, qw, tgx, tgy, yaw, rel_theta, diff);
             dist = hypot(tgx - px, tgy - py);  // environment_new.py:203 ; getGoalDistace, :116-120
         }
-        const int e = el_pose;
         if (own) {
-            sm.sv_d[0][e] = x; sm.sv_d[1][e] = y; sm.sv_d[2][e] = th; sm.sv_d[3][e] = gx; sm.sv_d[4][e] = gy;
-            sm.sv_d[5][e] = pdist; sm.sv_d[6][e] = dist; sm.sv_d[7][e] = yaw; sm.sv_d[8][e] = rel_theta;
-            sm.sv_d[9][e] = diff; sm.sv_d[10][e] = ret0;
-            sm.sv_act[e] = act; sm.sv_pact[e] = pact; sm.sv_ctr[e] = ctr; sm.sv_step[e] = step0;
+            sm.sv_d[6][e] = dist; sm.sv_d[7][e] = yaw; sm.sv_d[8][e] = rel_theta; sm.sv_d[9][e] = diff;
         } else {
-            const int c = rr - 1;
+            const int c = sl / EPB;
             sm.sp_d[c][0][e] = px; sm.sp_d[c][1][e] = py; sm.sp_d[c][2][e] = pth; sm.sp_d[c][3][e] = tgx;
             sm.sp_d[c][4][e] = tgy; sm.sp_d[c][5][e] = dist; sm.sp_d[c][6][e] = yaw; sm.sp_d[c][7][e] = rel_theta;
             sm.sp_d[c][8][e] = diff;
             sm.sp_ctr[c][e] = sctr;
             sm.sp_k[c][e] = sk;
-            if (rr == 2) {
+            if (c == 1) {
                 sm.sp_rg[0][e] = rgx; sm.sp_rg[1][e] = rgy;
                 sm.sp_rctr[e] = rctr;
             }
@@ -700,9 +713,10 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     }
     __syncthreads();  // barrier B: nearest hits complete
 
-    // ---------------- pose wave, part 3: rules of getState / step / setReward + episode logic
+    // ---------------- part 3 (wave 0, lane = env): rules of getState / step / setReward + episode logic
     if (own) {
-        const int e = el_pose;
+        const int e = lane;
+        const int i = base + e;
         x = sm.sv_d[0][e]; y = sm.sv_d[1][e]; th = sm.sv_d[2][e]; gx = sm.sv_d[3][e]; gy = sm.sv_d[4][e];
         pdist = sm.sv_d[5][e]; dist = sm.sv_d[6][e]; yaw = sm.sv_d[7][e]; rel_theta = sm.sv_d[8][e];
         diff = sm.sv_d[9][e]; ret0 = sm.sv_d[10][e];
