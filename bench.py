@@ -178,7 +178,7 @@ def main():
             "rollout_ms": round(roll_t / K * 1e3, 3), "update_ms": round(upd_t / K * 1e3, 3),
             "last_iter": {k: lg[k] for k in ("avg_ep_rews", "success_rate", "episodes", "actor_loss", "critic_loss", "approx_kl")},
         }
-    if not args.no_extras and ctx.world == 1:
+    if not args.no_extras and ctx.rank == 0:   # rank 0 only (the other ranks wait at the barrier below)
         del trainer
         torch.cuda.empty_cache()
         out["roofline"] = step_kernel_roofline(16384, "stage_2", per_env=True)
@@ -188,7 +188,8 @@ def main():
             t = json.load(open(pmc))
             out["roofline"]["traffic"] = t.get("cfg3_step_bytes_per_launch")
             out["roofline_timed_region"]["traffic"] = t.get("cfg2_step_bytes_per_launch")
-        out["cpu_baseline"] = cpu_baseline(n_local)
+        if ctx.world == 1:
+            out["cpu_baseline"] = cpu_baseline(n_local)
     if ctx.rank == 0:
         print(json.dumps(out), flush=True)
     ctx.barrier()

@@ -391,6 +391,29 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     js = json.loads(lines[0])
     assert js["n_gpus"] == 2 and js["config"]["n_envs_total"] == 1024 and js["scaling"] == "weak"
     assert js["value"] > 0 and js["metric"] == "env_steps_per_sec"
+    assert js["roofline"]["bound"] == "hbm" and js["roofline"]["frac"] > 0   # measured on rank 0 at every N
+    assert "cpu_baseline" not in js                                            # N == 1 only
+
+
+def test_degenerate_small_segments_take_the_ieee_divide_path():
+    """Segments shorter than 2^-10 m (and zero-length ones) are outside the range of the kernel's unscaled exact divide;
+    tiles that hold one must fall back to the plain IEEE divide and still agree with the oracle bit for bit on flags.
+    Covers the shared-map tile flag and the per-env wave-uniform branch."""
+    rng = np.random.default_rng(77)
+    base = maps.stage_1()
+    extra = np.array([[0.50, 0.00, 0.50 + 3e-4, 2e-4],      # tiny, right on the spawn's forward beam
+                      [-0.30, 0.20, -0.30, 0.20],           # zero length
+                      [0.80, -0.40, 0.80 + 1e-5, -0.40],    # tiny, axis aligned
+                      [1.10, 0.60, 1.10, 0.60 + 9e-4]],     # just under the 2^-10 threshold
+                     dtype=np.float32)
+    seg = np.concatenate([base, extra]).astype(np.float32)
+    gpu, cpu = _mk(256, seg, max_episode_steps=40, auto_reset=True, seed=5)
+    st = _lockstep(gpu, cpu, _actions(rng, 60, 256))
+    assert st["ended"] > 256
+    segp = np.repeat(seg[None], 64, axis=0).copy()
+    segp[:, :, [0, 2]] += rng.uniform(-0.05, 0.05, (64, 1, 1)).astype(np.float32)   # per-env jitter, tiny segments stay tiny
+    gpu, cpu = _mk(64, segp, per_env=True, max_episode_steps=40, auto_reset=True, seed=6)
+    _lockstep(gpu, cpu, _actions(rng, 60, 64))
 
 
 def test_table_sampler_parity_shared_and_per_env():
