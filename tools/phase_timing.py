@@ -51,3 +51,11 @@ if "--per-xcd" in sys.argv:
         print(f"xcc {q}: starts(ns) {st[m][order][:40].tolist()}")
         print(f"        cu/se     {[(int(s), int(c)) for s, c in zip(se[m][order][:40], cu[m][order][:40])]}")
         print(f"        ends(ns)  {en[m][order][:40].tolist()}")
+if "--simd" in sys.argv:
+    simd = (hw & 0xffffffff) >> 4 & 0x3
+    key = (xcc.astype(np.int64) << 16) | (se.astype(np.int64) << 8) | cu.astype(np.int64)
+    import collections
+    per_cu = collections.defaultdict(list)
+    for k_, s_ in zip(key.tolist(), simd.tolist()): per_cu[k_].append(int(s_))
+    print("SIMD of wave 0 of the workgroups sharing a CU (first 12 CUs):", [v for _, v in list(sorted(per_cu.items()))[:12]])
+    print("wave-0 SIMD histogram:", np.bincount(simd.astype(int), minlength=4).tolist())
