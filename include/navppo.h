@@ -9,7 +9,8 @@
  *
  * All pointers are DEVICE pointers owned by the caller; calls are asynchronous on `stream` (hipStream_t as void*);
  * return 0 or a negative code, message in navppo_last_error().  float32 throughout (f32-input MFMA: exact f32 fma
- * chains); no CPU fallback.
+ * chains); no CPU fallback.  Alignment: params_dev / actor_params_dev and obs_dev 16 bytes, act_dev 8 bytes (rows are
+ * read as dwordx4 / dwordx2; torch allocations are 256-byte aligned), checked at the call.
  */
 #ifndef NAVPPO_H
 #define NAVPPO_H
@@ -23,7 +24,7 @@ extern "C" {
 
 #define NAVPPO_MLP64_ACTOR_PARAMS 5378  /* 16*64+64 + 64*64+64 + 64+1 + 64+1 */
 #define NAVPPO_MLP64_CRITIC_PARAMS 5313 /* 16*64+64 + 64*64+64 + 64+1 */
-#define NAVPPO_MLP64_MAX_BLOCKS 512     /* persistent workgroups: two per CU */
+#define NAVPPO_MLP64_MAX_BLOCKS 512     /* rows of the workspace (the kernel launches one persistent workgroup per CU) */
 
 const char* navppo_last_error(void);
 

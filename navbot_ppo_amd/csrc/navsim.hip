@@ -378,17 +378,24 @@ constexpr int kThreads = 256;   // 4 waves.  (A workgroup reserves ceil(waves/4)
                                 // a 5-wave block costs as much residency as an 8-wave one: measured 1 block/CU.)
 
 // ---------------------------------------------------------------- the step kernel
-// One workgroup = 4 waves = EPB consecutive envs.
-//   wave 0 (lane = env): state loads, motion, sensor frame -> LDS | barrier A | goal angles / distance, then
-//          joins the ray-cast | barrier B | rules, reward, reset, state stores | barrier C
-//   waves 1-3: prefetch the segments of their first env (HBM loads do not depend on the pose) | barrier A |
-//          ray-cast | barrier B | barrier C
-//   per-env maps: an env is one work item taken from an LDS counter (wave 0 arrives late, so static
-//          assignment would idle three waves); lane = segment, 16 B/lane coalesced, every segment read from HBM
-//          once; the next item's segments are in flight while the current one is computed; nearest hit per
-//          beam = per-lane min over its segments, then one LDS atomic-min per lane that saw a hit.
-//   shared map: lane = ray (env, beam); segments staged in LDS tiles, read two at a time as wave-wide broadcasts.
-//   all:   the EPB x (B+6) observation tile leaves LDS as one contiguous, fully coalesced store.
+// One workgroup = 4 waves = EPB consecutive envs (EPB = 16: waves 0-1 are the "pose waves", 2-3 the "ray waves").
+//   part 1   pose waves, 8 lanes per env: state loads, float64 motion, the 8 sincos of the step one per lane -> LDS
+//            sensor origin + beam directions; the env's state is parked in LDS for its part-2/3 lane.
+//            ray waves: prefetch the segments of their first env / stage the shared map tile (nothing depends on the pose)
+//   barrier A
+//   part 2   lane-dense (a wave instruction costs the same with 8 or 64 active lanes): wave 0, lane = env: goal geometry
+//            of the new pose; last pose wave, 2 EPB lanes: the two possible next-episode records of every env (see there).
+//            Meanwhile the cast:
+//            per-env maps: an env is one work item taken from an LDS counter (the pose waves join when part 2 is done;
+//              a static split was measured 11 % slower); lane = segment, 16 B/lane coalesced, every segment read from HBM
+//              once; the next item's segments are in flight while the current one is tested; nearest hit per beam =
+//              per-lane min over its segments, then one LDS atomic-min per lane that saw a hit.
+//            shared map: lane = ray (env, beam) on the ray waves; segments staged in LDS tiles, wave-wide broadcast reads.
+//   barrier B
+//   part 3   wave 0, lane = env: rules of getState / step / setReward, episode logic, state stores
+//   barrier C
+//   all:     the EPB x (B+6) observation tile leaves LDS as one contiguous, fully coalesced store.
+// SENS = false compiles the sensor-fidelity options (range noise, -inf below range_min) out.
 template <int NB, bool PER_ENV, int EPB, bool SENS>
 __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* __restrict__ action,
                                                         const float2* __restrict__ past_override,
