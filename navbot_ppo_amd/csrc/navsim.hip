@@ -390,7 +390,8 @@ constexpr int kThreads = 256;   // 4 waves.  (A workgroup reserves ceil(waves/4)
 //              a static split was measured 11 % slower); lane = segment, 16 B/lane coalesced, every segment read from HBM
 //              once; the next item's segments are in flight while the current one is tested; nearest hit per beam =
 //              per-lane min over its segments, then one LDS atomic-min per lane that saw a hit.
-//            shared map: lane = ray (env, beam) on the ray waves; segments staged in LDS tiles, wave-wide broadcast reads.
+//            shared map: segments staged in LDS tiles; every wave holds all rays of the block (lane + 64 m = ray) and takes
+//              chunks of the tile from the LDS counter, wave-wide broadcast reads, per-wave minima merged by LDS atomic-min.
 //   barrier B
 //   part 3   wave 0, lane = env: rules of getState / step / setReward, episode logic, state stores
 //   barrier C
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
                 }
             }
         }
-        if (tid == 0) next_env = 4 - PW;  // the first envs are pre-assigned to the non-pose waves
+        if (tid == 0) next_env = PER_ENV ? 4 - PW : 0;  // per-env: the first envs are pre-assigned to the ray waves; shared: chunk counter
         if (lane == 0) tile_tiny[wave] = 0;
     }
     if (wave >= PW) {
@@ -650,24 +651,21 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             cur = nxt;
         }
     } else {
-        // lane = ray (env, beam) on the NON-pose waves only (the pose waves are busy with the goal geometry until later
-        // than the whole cast takes); segments come from the LDS tile as wave-wide broadcast reads
-        constexpr int NR = EPB * NB;                          // rays of this block
-        constexpr int NRT = kThreads - 64 * PW;               // ray threads
-        constexpr int RPT = (NR + NRT - 1) / NRT;             // rays per ray thread
-        const int rt = tid - 64 * PW;
-        float ox[RPT], oy[RPT], dc[RPT], ds[RPT];
-        unsigned best[RPT];
-        if (rt >= 0) {
+        // Every wave holds ALL rays of the block (lane + 64 m = ray (env, beam)) and takes CHUNKS of the staged tile from
+        // an LDS counter: the ray waves start at once, the pose waves join when part 2 is done, and a large map keeps all
+        // four waves busy.  Segments are wave-wide broadcast reads; the per-wave minima meet in LDS atomic-mins.
+        constexpr int NR = EPB * NB;                 // rays of this block
+        constexpr int RPL = (NR + 63) / 64;          // rays per lane
+        float ox[RPL], oy[RPL], dc[RPL], ds[RPL];
+        unsigned best[RPL];
 #pragma unroll
-            for (int m = 0; m < RPT; ++m) {
-                const int r = min(rt + m * NRT, NR - 1);
-                const int el = r / NB, b = r % NB;
-                const float2 o = sm.org[el];
-                const float2 d = sm.dir[b * EPB + el];
-                ox[m] = o.x; oy[m] = o.y; dc[m] = d.x; ds[m] = d.y;
-                best[m] = kInfBits;
-            }
+        for (int m = 0; m < RPL; ++m) {
+            const int r = min(lane + 64 * m, NR - 1);
+            const int el = r / NB, b = r % NB;
+            const float2 o = sm.org[el];
+            const float2 d = sm.dir[b * EPB + el];
+            ox[m] = o.x; oy[m] = o.y; dc[m] = d.x; ds[m] = d.y;
+            best[m] = kInfBits;
         }
         for (int s0 = 0; s0 < P.S; s0 += kSegTile) {  // uniform trip count
             const int ns = min(kSegTile, P.S - s0);
@@ -680,42 +678,50 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
                     tiny |= fmaxf(fabsf(g.z - g.x), fabsf(g.w - g.y)) < 0x1p-10f;
                 }
                 const int any_tiny = __any(tiny) ? 1 : 0;
-            if (lane == 0) tile_tiny[wave] = any_tiny;
+                if (lane == 0) tile_tiny[wave] = any_tiny;
+                if (tid == 0) next_env = 0;
                 __syncthreads();
             }
-            if (rt < 0) continue;
-            if (__builtin_expect(tile_tiny[0] | tile_tiny[1] | tile_tiny[2] | tile_tiny[3], 0)) {   // div_pos needs |den| >= 2^-60: such tiles take the plain IEEE divide
-                for (int j = 0; j < ns; ++j) {
-                    const float4 g = seg_tile[j];
-                    const float ex = g.z - g.x, ey = g.w - g.y;
+            const int chunk = max(4, min(32, ns >> 3));
+            const bool slow = (tile_tiny[0] | tile_tiny[1] | tile_tiny[2] | tile_tiny[3]) != 0;
+            for (;;) {
+                int c = 0;
+                if (lane == 0) c = atomicAdd(&next_env, 1);
+                c = __builtin_amdgcn_readfirstlane(c);
+                const int j0 = c * chunk, j1 = min(j0 + chunk, ns);
+                if (j0 >= ns) break;
+                if (__builtin_expect(slow, 0)) {   // div_pos needs |den| >= 2^-60: such tiles take the plain IEEE divide
+                    asm volatile("; degenerate-segment tile" ::: "memory");
+                    for (int j = j0; j < j1; ++j) {
+                        const float4 g = seg_tile[j];
+                        const float ex = g.z - g.x, ey = g.w - g.y;
 #pragma unroll
-                    for (int m = 0; m < RPT; ++m) {
-                        const float rx = g.x - ox[m], ry = g.y - oy[m];
-                        const float k = fmaf(rx, ey, -(ry * ex));
-                        best[m] = min(best[m], __float_as_uint(ray_seg(rx, ry, ex, ey, k, dc[m], ds[m])) & 0x7fffffffu);
+                        for (int m = 0; m < RPL; ++m) {
+                            const float rx = g.x - ox[m], ry = g.y - oy[m];
+                            const float k = fmaf(rx, ey, -(ry * ex));
+                            best[m] = min(best[m], __float_as_uint(ray_seg(rx, ry, ex, ey, k, dc[m], ds[m])) & 0x7fffffffu);
+                        }
                     }
-                }
-            } else {
-                // branch-free body: iterations are independent, so the unrolled copies overlap their division chains
-#pragma unroll 4
-                for (int j = 0; j < ns; ++j) {
-                    const float4 g = seg_tile[j];
-                    const float ex = g.z - g.x, ey = g.w - g.y;
+                } else {
+                    // branch-free body: iterations are independent, so the unrolled copies overlap their division chains
+#pragma unroll 2
+                    for (int j = j0; j < j1; ++j) {
+                        const float4 g = seg_tile[j];
+                        const float ex = g.z - g.x, ey = g.w - g.y;
 #pragma unroll
-                    for (int m = 0; m < RPT; ++m) {
-                        const float rx = g.x - ox[m], ry = g.y - oy[m];
-                        const float k = fmaf(rx, ey, -(ry * ex));
-                        best[m] = min(best[m], ray_seg_bits(rx, ry, ex, ey, k, dc[m], ds[m]));
+                        for (int m = 0; m < RPL; ++m) {
+                            const float rx = g.x - ox[m], ry = g.y - oy[m];
+                            const float k = fmaf(rx, ey, -(ry * ex));
+                            best[m] = min(best[m], ray_seg_bits(rx, ry, ex, ey, k, dc[m], ds[m]));
+                        }
                     }
                 }
             }
         }
-        if (rt >= 0) {
 #pragma unroll
-            for (int m = 0; m < RPT; ++m) {
-                const int r = rt + m * NRT;
-                if (r < NR) sm.rng[(r % NB) * EPB + (r / NB)] = best[m];
-            }
+        for (int m = 0; m < RPL; ++m) {
+            const int r = lane + 64 * m;
+            if (r < NR && best[m] < kInfBits) atomicMin(&sm.rng[(r % NB) * EPB + (r / NB)], best[m]);
         }
     }
     __syncthreads();  // barrier B: nearest hits complete

@@ -44,5 +44,8 @@ for w in which:
         S = int(w[4:]); sides = (S - 32) // 4
         seg = maps.replicate_per_env(maps.stage_2(sides=sides), 16384, seed=0); us = run(16384, seg, True)
         print(f"16384 envs per-env S={seg.shape[1]}: {us:8.2f} us  -> {16384*(134+16*seg.shape[1])/us/1e3:8.1f} GB/s")
+    elif w == "--cfg5":   # BASELINE configs[4] per GPU: 65536 / 8 envs, house map (~2k segments, shared), 10 beams
+        seg = maps.house(2048); us = run(8192, seg, False)
+        print(f"cfg5 8192 envs shared S={seg.shape[0]}: {us:8.2f} us  -> {8192*seg.shape[0]*10/us/1e3:8.1f} G ray-segment tests/s")
     elif w == "--big":
         us = run(65536, maps.stage_1(), False); print(f"65536 envs shared S=32: {us:8.2f} us")
