@@ -704,7 +704,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
                     }
                 } else {
                     // branch-free body: iterations are independent, so the unrolled copies overlap their division chains
-#pragma unroll 2
+#pragma unroll 4
                     for (int j = j0; j < j1; ++j) {
                         const float4 g = seg_tile[j];
                         const float ex = g.z - g.x, ey = g.w - g.y;
