@@ -68,6 +68,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NavsimError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc, gfx950).  There is no CPU implementation to fall back to.")
+        # The HIP runtime of the process must be the one PyTorch ships: every device pointer crossing this ABI is a
+        # torch allocation.  Importing torch first makes its bundled libamdhip64 the loaded instance; loading
+        # libnavsim.so first would pull in /opt/rocm's copy (same soname), which torch would then be bound to as well
+        # -- on the GPU boxes that copy reports "no ROCm-capable device".
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the library does not export the symbol
