@@ -416,6 +416,29 @@ def test_degenerate_small_segments_take_the_ieee_divide_path():
     _lockstep(gpu, cpu, _actions(rng, 60, 64))
 
 
+@pytest.mark.parametrize("per_env", [False, True])
+def test_soak_all_episode_ends_with_respawn_and_autoreset(per_env):
+    """Long lockstep run with every way an episode can end, auto_reset AND respawn_on_arrive together: an arrival draws
+    the re-spawn goal and then the next episode's goal from the same Philox stream (the step kernel prepares both
+    possible next-episode records ahead of the rules), with the reference's rejection rectangles active so the draw
+    loops run more than once.  Thousands of resets; counters, goals and poses must stay identical to the oracle."""
+    rng = np.random.default_rng(91 + per_env)
+    N, K = (768, 700) if not per_env else (256, 500)
+    seg = maps.stage_1()
+    if per_env:
+        seg = maps.replicate_per_env(seg, N, seed=8)
+    gpu, cpu = _mk(N, seg, per_env=per_env, max_episode_steps=70, auto_reset=True, respawn_on_arrive=True, seed=17,
+                   goal_box=(-1.5, 1.5), threshold_arrive=0.4)
+    rects = np.array([[0.3, 0.9, -0.6, 0.6], [-0.9, -0.3, -0.6, 0.6]])   # rejects ~27 % of the draws
+    for s_ in (gpu, cpu):
+        s_.set_goal_rects(0, rects)
+        s_.set_goal_rects(1, rects * 1.1)
+    a = _actions(rng, K, N)
+    a[:, N // 2:, 0] = np.maximum(a[:, N // 2:, 0], 0.6)   # half of the envs keep moving: arrivals and collisions
+    st = _lockstep(gpu, cpu, a, check_state_every=50)
+    assert st["arrive"] > 200 and st["done"] > 10 and st["ended"] > 4 * N
+
+
 def test_table_sampler_parity_shared_and_per_env():
     """navsim_set_spawn_sampler (GoalSpawnSampler tables) vs the oracle: resets and in-step auto-resets pick the same start
     poses / goals (same Philox stream) and observe the scan of the picked pose."""
