@@ -182,16 +182,6 @@ __device__ __forceinline__ float sensor_value(float best, float sigma, float n, 
     const float r = fmaf(sigma, n, best);
     return fminf(fmaxf(r, kRangeMin), kRangeMax);
 }
-__device__ __forceinline__ float scan_value(float best) { return sensor_value(best, 0.f, 0.f, 0); }
-
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float o = __shfl_xor(v, m, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -325,21 +315,6 @@ struct StepSmem {
     double sp_rg[2][EPB];     // the arrival re-spawn goal (environment_new.py:245-253) and the draw counter after it
     uint32_t sp_rctr[EPB];
 };
-
-// Sign-normalised ray / segment test: with sd = sign bit of den, K = k^sd, U = un^sd, Dn = |den| the
-// hit conditions of ray_seg() become  K >= 0, 0 <= U <= Dn  (Dn == 0 gives K/Dn = inf or NaN, which
-// never wins the min), and K/Dn == k/den bit for bit.  Returns the candidate range (+inf if no hit).
-__device__ __forceinline__ float ray_seg_fast(float rx, float ry, float ex, float ey, float k, float c, float s) {
-    const float den = fmaf(c, ey, -(s * ex));
-    const float un = fmaf(rx, s, -(ry * c));
-    const unsigned sd = __float_as_uint(den) & 0x80000000u;
-    const float K = __uint_as_float(__float_as_uint(k) ^ sd);
-    const float U = __uint_as_float(__float_as_uint(un) ^ sd);
-    const float Dn = fabsf(den);
-    const bool ok = (fminf(K, U) >= 0.0f) && (U <= Dn);
-    const float t = K / Dn;
-    return ok ? t : INFINITY;
-}
 
 // Correctly rounded K / Dn for positive, normal-range operands (Dn in [2^-60, 2^20], K in {0} U [2^-60, 2^20]):
 // the reciprocal-refinement sequence the compiler emits for an IEEE float32 divide (v_rcp, 2 fma to refine,
