@@ -933,55 +933,19 @@ static int upload_starts(navsim* h, const double* starts_host, int K, hipStream_
     return NAVSIM_OK;
 }
 
-#pragma GCC visibility push(default)
-extern "C" {
-
-int navsim_version(void) { return NAVSIM_ABI_VERSION; }
-
-const char* navsim_last_error(void) { return g_err.c_str(); }
-
-void navsim_default_cfg(navsim_cfg* c) {
-    if (!c) return;
-    std::memset(c, 0, sizeof(*c));
-    c->n_envs = 1;
-    c->n_beams = 10;            // gazebo.xacro:111
-    c->threshold_arrive = 0.2;  // environment_new.py:45
-    c->goal_lo = -3.6;          // environment_new.py:337
-    c->goal_hi = 3.6;
-}
-
 static const double kResetRects[4][4] = {  // environment_new.py:340-343
     {1.7, 2.3, -1.2, 1.2}, {-2.3, -1.7, -1.2, 1.2}, {-1.2, 1.2, 1.7, 2.3}, {-1.2, 1.2, -2.3, -1.7}};
 static const double kRespawnRects[4][4] = {  // environment_new.py:248-251
     {1.6, 2.4, -1.4, 1.4}, {-2.4, -1.6, -1.4, 1.4}, {-1.4, 1.4, 1.6, 2.4}, {-1.4, 1.4, -2.4, -1.6}};
 
-int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
-    if (!cfg || !out) return fail(NAVSIM_E_ARG, "navsim_create: null argument");
-    *out = nullptr;
-    if (cfg->n_envs < 1) return fail(NAVSIM_E_ARG, "navsim_create: n_envs must be >= 1");
-    if (cfg->n_beams != 10 && cfg->n_beams != 36)
-        return fail(NAVSIM_E_ARG, "navsim_create: n_beams must be 10 or 36");
-    if (!(cfg->goal_hi > cfg->goal_lo)) return fail(NAVSIM_E_ARG, "navsim_create: empty goal box");
-    if (!(cfg->lidar_noise_sigma >= 0.f)) return fail(NAVSIM_E_ARG, "navsim_create: negative lidar_noise_sigma");
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (ndev < 1) return fail(NAVSIM_E_HIP, "navsim_create: no HIP device (there is no CPU path)");
-
-    if (const char* e = std::getenv("NAVSIM_EPB")) {
-        const int v = std::atoi(e);
-        if (v == 8 || v == 16) g_epb = v;
-    }
-    navsim* h = new navsim();
+// Allocations and tables of a new handle (navsim_create frees the handle if any step fails).
+static int init_handle(navsim* h, const navsim_cfg* cfg) {
     h->cfg = *cfg;
     const size_t N = (size_t)cfg->n_envs;
     const int B = cfg->n_beams;
     // one block: 7 f64 arrays, float2 past_action, i32 ep_step, u32 rng_ctr
     const size_t bytes = N * (7 * sizeof(double) + sizeof(float2) + sizeof(int32_t) + sizeof(uint32_t));
-    hipError_t e = hipMalloc(&h->state_block, bytes);
-    if (e != hipSuccess) {
-        delete h;
-        return fail(NAVSIM_E_HIP, std::string("hipMalloc(state): ") + hipGetErrorString(e));
-    }
+    HIP_TRY(hipMalloc(&h->state_block, bytes));
     HIP_TRY(hipMemset(h->state_block, 0, bytes));
     Params& P = h->P;
     std::memset(&P, 0, sizeof(P));
@@ -1033,6 +997,48 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
         if (rc != NAVSIM_OK) return rc;
         P.G = 0;
         P.goals = nullptr;
+    }
+    return NAVSIM_OK;
+}
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int navsim_version(void) { return NAVSIM_ABI_VERSION; }
+
+const char* navsim_last_error(void) { return g_err.c_str(); }
+
+void navsim_default_cfg(navsim_cfg* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->n_envs = 1;
+    c->n_beams = 10;            // gazebo.xacro:111
+    c->threshold_arrive = 0.2;  // environment_new.py:45
+    c->goal_lo = -3.6;          // environment_new.py:337
+    c->goal_hi = 3.6;
+}
+
+int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
+    if (!cfg || !out) return fail(NAVSIM_E_ARG, "navsim_create: null argument");
+    *out = nullptr;
+    if (cfg->n_envs < 1) return fail(NAVSIM_E_ARG, "navsim_create: n_envs must be >= 1");
+    if (cfg->n_beams != 10 && cfg->n_beams != 36)
+        return fail(NAVSIM_E_ARG, "navsim_create: n_beams must be 10 or 36");
+    if (!(cfg->goal_hi > cfg->goal_lo)) return fail(NAVSIM_E_ARG, "navsim_create: empty goal box");
+    if (!(cfg->lidar_noise_sigma >= 0.f)) return fail(NAVSIM_E_ARG, "navsim_create: negative lidar_noise_sigma");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(NAVSIM_E_HIP, "navsim_create: no HIP device (there is no CPU path)");
+
+    if (const char* e = std::getenv("NAVSIM_EPB")) {
+        const int v = std::atoi(e);
+        if (v == 8 || v == 16) g_epb = v;
+    }
+    navsim* h = new navsim();
+    const int rc = init_handle(h, cfg);
+    if (rc != NAVSIM_OK) {
+        navsim_destroy(h);   // frees whatever was allocated before the failure
+        return rc;
     }
     *out = h;
     return NAVSIM_OK;
