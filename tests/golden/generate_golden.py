@@ -20,6 +20,8 @@ Sets:
   g7_update.npz      PPO.learn on a fixed batch: V, log-probs, losses, weights after k epochs (ppo.py:275-397)
   g8_nets.npz/.json  NetActor/NetCritic forward + state_dict keys (net_actor.py, net_critic.py)
   g9_closed_loop.npz K-step closed loop: oracle sim poses/scans -> reference Env.step outputs
+  g10_rollout.npz    PPO.rollout (ppo.py:463-641) + compute_rtgs over the reference Env: batch_obs/acts/log_probs/rtgs/lens,
+                     per-episode metrics (length, return, path_length), for a replayed action tape
 """
 import json
 import math
@@ -498,9 +500,122 @@ def gen_g9():
     print("g9", K, E, "episodes ended:", int((~alive).sum()), "collisions", int(ref_flags[..., 0].sum()),
           "arrivals", int(ref_flags[..., 1].sum()))
 
+# ------------------------------------------------------------------ G10
+class _PhiloxRandom:
+    """Stands in for the `random` module inside environment_new (the reference draws goals from the UNSEEDED global
+    `random`): uniform(a, b) = a + (b - a) * u like CPython's, with u taken from the simulator's documented
+    goal stream -- Philox4x32-10 keyed by (seed, env id), counter = draws so far, one call per (x, y) pair."""
+
+    def __init__(self, seed, gid):
+        self.key = [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF]
+        self.gid, self.ctr, self.pending = gid, 0, None
+
+    def uniform(self, a, b):
+        from oracle import navsim_oracle as O
+        if self.pending is None:
+            r = [int(v) for v in O.philox4x32_10([self.gid & 0xFFFFFFFF, self.gid >> 32, self.ctr, 0x6e617673], self.key)]
+            self.ctr += 1
+            ux = float(((r[0] << 32) | r[1]) >> 11) * 2.0 ** -53
+            self.pending = float(((r[2] << 32) | r[3]) >> 11) * 2.0 ** -53
+            return a + (b - a) * ux
+        u, self.pending = self.pending, None
+        return a + (b - a) * u
+
+
+def gen_g10():
+    """The reference's own PPO.rollout + compute_rtgs drive the reference's own Env; the oracle simulator only plays
+    Gazebo's part (pose after 0.2 s of motion, the scan at that pose) and `random` is the injected Philox goal stream, so
+    a NavSim(1, auto_reset, respawn_on_arrive) handle with the same seed must reproduce every output."""
+    import torch
+    from oracle import navsim_oracle as O
+    from navbot_ppo_amd import maps
+    REF_PPO, _, _ = import_ppo()
+    seg = maps.stage_1()
+    SEED, T, CAP, GAMMA = 10, 600, 45, 0.99
+    rng = np.random.default_rng(1010)
+    acts = np.stack([rng.uniform(0.55, 1.0, T), rng.uniform(-1, 1, T)], 1).astype(np.float32)
+    # stretches of nearly straight full-speed driving so that collisions and arrivals occur, not only timeouts
+    for s0 in range(0, T, 90):
+        acts[s0:s0 + 45, 0] = 1.0
+        acts[s0:s0 + 45, 1] *= 0.1
+    logps = rng.normal(-1.5, 0.3, T).astype(np.float32)
+
+    sim = O.OracleSim(1, n_beams=10, max_episode_steps=0, auto_reset=False, respawn_on_arrive=False, seed=SEED)
+    sim.set_map(seg)
+    ref = mk_env(True)
+    fake_random = _PhiloxRandom(SEED, 0)
+    REF_ENV.random = fake_random
+    goals, tape = [], {"k": 0}
+
+    def feed(x, y, th):
+        # Gazebo's part: while Env.step / Env.reset block on the 5 Hz scan (environment_new.py:282-286, :352-357) the 30 Hz
+        # odometry callback (:33,:138) delivers the new pose -- after reset() has drawn its goal
+        odom = mk_odom(float(x), float(y), 0.0, 0.0, math.sin(th / 2), math.cos(th / 2))
+        scan = NS(ranges=[float(v) for v in O.raycast(seg, x, y, th, 10)])
+
+        def wait_for_message(*a, **k):
+            ref.getOdometry(odom)
+            return scan
+        REF_ENV.rospy.wait_for_message = wait_for_message
+
+    class BackedEnv:
+        use_vision = False
+
+        @property
+        def position(self):
+            return ref.position
+
+        def reset(self):
+            sim.set_state(pose=np.zeros((1, 3)))   # /gazebo/reset_world: spawn pose (turtlebot3_stage_1.launch:3-5)
+            feed(0.0, 0.0, 0.0)
+            o = ref.reset()
+            goals.append([ref.goal_position.position.x, ref.goal_position.position.y])
+            return o
+
+        def step(self, action, past_action):
+            sim.step(np.asarray(action, dtype=np.float32).reshape(1, 2))
+            x, y, th = sim.get_state()["pose"][0]
+            feed(x, y, th)
+            return ref.step(action, past_action)
+
+    episodes = []
+
+    def get_action(obs, t_so_far, one_round, vision_feat=None):
+        # every other episode is driven at its goal by a bang-bang controller on diff_angle (obs[15] * 180) so that
+        # arrivals occur; the emitted actions ARE the tape the GPU test replays
+        k = tape["k"]
+        tape["k"] += 1
+        if one_round == 0:
+            tape["ep"] = tape.get("ep", -1) + 1
+        if tape["ep"] % 2 == 0:
+            diff = float(obs[15]) * 180.0
+            acts[k] = [1.0 if abs(diff) < 30 else 0.3, min(1.0, max(-1.0, -diff / 30.0))]
+        return acts[k].copy(), logps[k]
+
+    tmp = tempfile.mkdtemp(prefix="g10_")
+    me = NS(use_vision=False, env=BackedEnv(), timesteps_per_batch=T, max_timesteps_per_episode=CAP, gamma=GAMMA,
+            get_action=get_action, episode_count=0, logger={"Episode_Rewards": []}, log_dir_path=tmp,
+            _log_episode_metrics=lambda **kw: episodes.append(kw))
+    me.compute_rtgs = types.MethodType(REF_PPO.PPO.compute_rtgs, me)
+    b_obs, b_acts, b_logp, b_rtgs, b_lens, metrics, _ = REF_PPO.PPO.rollout(me, np.array([0.0, 0.0]), 0)
+    rews = [r for e in me.logger["batch_rews"] for r in e]
+    ep = {k: np.array([e[k] for e in episodes], dtype=np.float64)
+          for k in ("timestep", "success", "collision", "timeout", "length", "ep_return", "path_length")}
+    np.savez_compressed(
+        os.path.join(HERE, "g10_rollout.npz"), seed=np.array(SEED), cap=np.array(CAP), gamma=np.array(GAMMA), acts_tape=acts,
+        logp_tape=logps, batch_obs=b_obs.numpy(), batch_acts=b_acts.numpy(), batch_log_probs=b_logp.numpy(),
+        batch_rtgs=b_rtgs.numpy(), batch_lens=np.array(b_lens, dtype=np.int32), rews=np.array(rews, dtype=np.float64),
+        goals=np.array(goals), rng_ctr_final=np.array(fake_random.ctr),
+        trailing_len=np.array(len(me.logger["batch_rews"][-1])),
+        episode_rewards_log=np.array(me.logger["Episode_Rewards"], dtype=np.float64),
+        iter_counts=np.array([metrics["successes"], metrics["collisions"], metrics["timeouts"], metrics["ep_count"]]),
+        **{"ep_" + k: v for k, v in ep.items()})
+    print("g10", T, "episodes", len(b_lens), "lens", b_lens, "succ/coll/timeout",
+          metrics["successes"], metrics["collisions"], metrics["timeouts"], "trailing", len(me.logger["batch_rews"][-1]))
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5", "g6", "g7", "g9"]
-    fns = dict(g1=gen_g1, g2=gen_g2, g3=gen_g3, g3b=gen_g3b, g4=gen_g4, g5=gen_g5, g6=gen_g6, g7=gen_g7_g8, g9=gen_g9)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5", "g6", "g7", "g9", "g10"]
+    fns = dict(g1=gen_g1, g2=gen_g2, g3=gen_g3, g3b=gen_g3b, g4=gen_g4, g5=gen_g5, g6=gen_g6, g7=gen_g7_g8, g9=gen_g9, g10=gen_g10)
     for w in which:
         fns[w]()

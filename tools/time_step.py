@@ -10,7 +10,7 @@ if len(sys.argv) > 1 and sys.argv[1].endswith(".so"):
 from navbot_ppo_amd.env import NavSim
 
 def run(N, seg, per_env, iters=300, B=10):
-    sim = NavSim(N, n_beams=B, max_episode_steps=500, auto_reset=True, seed=0)
+    sim = NavSim(N, n_beams=B, max_episode_steps=500, auto_reset=os.environ.get("TS_AUTORESET", "1") == "1", seed=0)
     sim.set_map(seg, per_env=per_env)
     io = sim.alloc_io(); sim.reset(io.obs)
     acts = torch.rand((64, N, 2), device="cuda"); acts[..., 1] = acts[..., 1] * 2 - 1
