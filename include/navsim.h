@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NAVSIM_ABI_VERSION 2
+#define NAVSIM_ABI_VERSION 3
 
 #define NAVSIM_OK 0
 #define NAVSIM_E_ARG (-1)   /* bad argument / unsupported configuration */
@@ -133,10 +133,13 @@ int navsim_reset(navsim_t* h, const uint8_t* mask_dev, void* obs_dev, void* stre
  *   ended_dev        [N] u8     out  nullable: done | arrive | timeout (the RTG episode-end flag)
  *   ep_return_dev    [N] f32    out  nullable: written only where ended: sum of the episode's rewards
  *   ep_length_dev    [N] i32    out  nullable: written only where ended: episode length in steps
+ *   ep_path_dev      [N] f32    out  nullable: written only where ended: the episode's path length as PPO.rollout
+ *                                    accumulates it (ppo.py:533-537: distances between the positions read BEFORE each
+ *                                    step, so the last step's displacement is not part of it)
  */
 int navsim_step(navsim_t* h, const float* action_dev, const float* past_action_dev, void* obs_dev,
                 float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,
-                float* ep_return_dev, int32_t* ep_length_dev, void* stream);
+                float* ep_return_dev, int32_t* ep_length_dev, float* ep_path_dev, void* stream);
 
 /*
  * Env attributes the reference's callers read or that tests / checkpoints need

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnavsim.so")
 
-NAVSIM_ABI_VERSION = 2
+NAVSIM_ABI_VERSION = 3
 
 
 class NavsimError(RuntimeError):
@@ -46,7 +46,7 @@ SYMBOLS = [
     ("navsim_set_goal_rects", C.c_int, [_vp, _i32, _vp, _i32]),
     ("navsim_set_spawn_sampler", C.c_int, [_vp, _vp, _i32, _vp, _i32, _d, _d, _vp]),
     ("navsim_reset", C.c_int, [_vp, _vp, _vp, _vp]),
-    ("navsim_step", C.c_int, [_vp] * 11),
+    ("navsim_step", C.c_int, [_vp] * 12),
     ("navsim_get_state", C.c_int, [_vp] * 8),
     ("navsim_set_state", C.c_int, [_vp] * 8),
     ("navsim_rtg_scan", C.c_int, [_vp, _vp, _i32, _i32, _d, _vp, _vp]),

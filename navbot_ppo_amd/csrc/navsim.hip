@@ -74,12 +74,20 @@ struct Params {
     uint32_t key0, key1;
     uint64_t env_id_base;
     double thr, spawn_x, spawn_y, spawn_yaw, goal_lo, goal_hi, diag;
-    double *x, *y, *th, *gx, *gy, *past_dist, *ep_ret;
+    double *x, *y, *th, *gx, *gy, *past_dist, *ep_ret, *ep_path;
     float2* past_action;
-    int32_t* ep_step;
+    int32_t* ep_step;         // low 30 bits: steps taken in the episode; kRecValid: the records below are current
     uint32_t* rng_ctr;
+    // next-episode records, written by the step kernel when an env's goal stream has moved, read otherwise:
+    double* rec_g;            // [2][3][N] goal x, y and start-to-goal distance
+    float4* rec_tail;         // [2][N] the reset observation's (dist/diag, yaw/360, rel_theta/360, diff/180)
+    uint2* rec_ck;            // [2][N] (draw counter after the reset, start-pose index)
+    double* rsp_g;            // [2][N] the arrival re-spawn goal (respawn_on_arrive)
+    uint32_t* rsp_ctr;        // [N] draw counter after the re-spawn draw
+    int seg_pack_log2;        // cast: log2(lanes per env in one 64-lane pass) = 6, or log2(pow2ceil(S)) when S <= 32
     const float4* seg;        // [S] or [N][S]
     const float* spawn_scan;  // [K][B] or [N][K][B] nearest hits (+inf = none) at the K start poses (K = 1: the cfg spawn pose)
+    const float* spawn_obs;   // same shape: the noise-free lidar entries of the reset observation (sanitised scan / 3.5)
     const double* starts;     // [K][3] start poses (x, y, yaw)
     const double* starts_sc;  // [K][2] (cos, sin)(yaw / 2) of the start poses, evaluated on the device
     const double* goals;      // [G][2] goal points; G == 0: uniform goal box + rejection rectangles
@@ -91,75 +99,85 @@ struct Params {
 
 // ---------------------------------------------------------------- device helpers
 
+// q / s for an integer-valued q with |q| < 2^26 and s in {10, 100} (also k/100 values over 180 or 360): one multiply by
+// the rounded reciprocal plus one fma correction gives the correctly rounded quotient -- verified exhaustively over those
+// domains by tools/verify/div_by_const_exact.c -- instead of the ~30-instruction IEEE float64 division sequence.
+__device__ __forceinline__ double div_const(double q, double s, double inv_s) {
+    const double r0 = q * inv_s;
+    return fma(fma(-s, r0, q), inv_s, r0);
+}
+
 // Python round(x, nd), s = 10^nd: decimal rounding, ties-to-even on the exact binary value
-// (environment_new.py:149-150,169-176).  x*s is held exactly as p + err.
-__device__ __forceinline__ double py_round(double x, double s) {
-    if (!isfinite(x)) return x;
+// (environment_new.py:149-150,169-176).  x*s is held exactly as p + err.  Branch-free except for the out-of-domain
+// quotient (|x s| >= 2^26: never with map coordinates in metres and angles in degrees).
+__device__ __forceinline__ double py_round(double x, double s, double inv_s) {
     const double p = x * s;
     const double err = fma(x, s, -p);
     const double fl = floor(p);
     const double frac = p - fl;
-    double q = fl;
-    if (frac > 0.5) {
-        q = fl + 1.0;
-    } else if (frac == 0.5) {
-        if (err > 0.0) {
-            q = fl + 1.0;
-        } else if (err == 0.0) {
-            const double h = fl * 0.5;
-            if (h != floor(h)) q = fl + 1.0;  // fl odd -> the even neighbour is fl + 1
-        }
-    }
-    double r = q / s;
+    const double h = fl * 0.5;
+    const bool odd = h != floor(h);                     // fl odd -> the even neighbour is fl + 1
+    const bool up = (frac > 0.5) || ((frac == 0.5) && ((err > 0.0) || ((err == 0.0) && odd)));
+    const double q = up ? fl + 1.0 : fl;
+    double r = div_const(q, s, inv_s);
+    if (__builtin_expect(!(fabs(q) < 0x1p26), 0)) r = q / s;   // also NaN / inf
     if (r == 0.0) r = copysign(0.0, x);
-    return r;
+    return isfinite(x) ? r : x;
+}
+
+// yaw of Env.getOdometry, environment_new.py:142-147, for the yaw-only quaternion (qz, qw) = (sin, cos)(theta / 2)
+__device__ __forceinline__ double yaw_from_quat(double qz, double qw) {
+    const double rad2deg = 180.0 / 3.14159265358979323846;
+    const double qx = 0.0, qy = 0.0;
+    double yaw = rint(atan2(2 * (qx * qy + qw * qz), 1 - 2 * (qy * qy + qz * qz)) * rad2deg);  // :142
+    if (!(yaw >= 0)) yaw = yaw + 360;                                                            // :144-147
+    return yaw + 0.0;   // Python's round() returns the int 0 for -0.4: no negative zero
+}
+
+// The same integer without the quaternion round trip: atan2(sin th, cos th) is th wrapped to (-pi, pi], so the yaw is
+// rint(th in degrees, wrapped to [-180, 180]).  The two routes differ by < 1e-9 degree for |th| < 1e7 rad, so they round
+// to the same integer unless the angle sits within 1e-6 of a half degree: then (*exact = false) the caller takes the
+// quaternion route.
+__device__ __forceinline__ double yaw_fast(double th, bool* exact) {
+    const double rad2deg = 180.0 / 3.14159265358979323846;
+    const double d = th * rad2deg;
+    const double m = d - 360.0 * rint(d * (1.0 / 360.0));
+    double yaw = rint(m);
+    *exact = (fabs(d) < 5e8) && (fabs(fabs(m - yaw) - 0.5) > 1e-6);
+    if (!(yaw >= 0)) yaw = yaw + 360;
+    return yaw + 0.0;
+}
+
+// rel_theta and diff_angle of Env.getOdometry, environment_new.py:149-176; branch-free
+__device__ __forceinline__ void goal_rel(double x, double y, double gx, double gy, double yaw, double& rel_theta, double& diff) {
+    const double kPi = 3.14159265358979323846;
+    const double rad2deg = 180.0 / kPi;
+    const double dx = py_round(gx - x, 10.0, 0.1);                                       // :149
+    const double dy = py_round(gy - y, 10.0, 0.1);                                       // :150
+    const double at = atan(dy / dx);                                                     // :153-168
+    double theta = kPi;
+    theta = (dy == 0 && dx > 0) ? 0.0 : theta;
+    theta = (dx == 0 && dy < 0) ? 1.5 * kPi : theta;
+    theta = (dx == 0 && dy > 0) ? 0.5 * kPi : theta;
+    theta = (dx < 0 && (dy < 0 || dy > 0)) ? kPi + at : theta;
+    theta = (dx > 0 && dy < 0) ? 2 * kPi + at : theta;
+    theta = (dx > 0 && dy > 0) ? at : theta;
+    rel_theta = py_round(theta * rad2deg, 100.0, 0.01);                                  // :169
+    const double d = yaw - rel_theta;                                                    // :170
+    const double w = (d >= -180 && d <= 180) ? d : ((d < -180) ? 360 + d : -360 + d);    // :171-176
+    diff = py_round(w, 100.0, 0.01);
 }
 
 // Env.getOdometry, environment_new.py:138-181, for the yaw-only quaternion Gazebo publishes.
 __device__ __forceinline__ void goal_angles_q(double x, double y, double qz, double qw, double gx, double gy,
-                                              double& yaw, double& rel_theta, double& diff);
+                                              double& yaw, double& rel_theta, double& diff) {
+    yaw = yaw_from_quat(qz, qw);
+    goal_rel(x, y, gx, gy, yaw, rel_theta, diff);
+}
 
 __device__ __forceinline__ void goal_angles(double x, double y, double th, double gx, double gy,
                                             double& yaw, double& rel_theta, double& diff) {
     goal_angles_q(x, y, sin(th / 2), cos(th / 2), gx, gy, yaw, rel_theta, diff);
-}
-
-// (qz, qw) = (sin(theta/2), cos(theta/2)): the odom orientation quaternion of a planar robot
-__device__ __forceinline__ void goal_angles_q(double x, double y, double qz, double qw, double gx, double gy,
-                                              double& yaw, double& rel_theta, double& diff) {
-    const double kPi = 3.14159265358979323846;
-    const double rad2deg = 180.0 / kPi;
-    const double qx = 0.0, qy = 0.0;
-    yaw = rint(atan2(2 * (qx * qy + qw * qz), 1 - 2 * (qy * qy + qz * qz)) * rad2deg);  // :142
-    if (!(yaw >= 0)) yaw = yaw + 360;                                                    // :144-147
-    const double dx = py_round(gx - x, 10.0);                                            // :149
-    const double dy = py_round(gy - y, 10.0);                                            // :150
-    double theta;
-    if (dx > 0 && dy > 0)                                                                // :153-168
-        theta = atan(dy / dx);
-    else if (dx > 0 && dy < 0)
-        theta = 2 * kPi + atan(dy / dx);
-    else if (dx < 0 && dy < 0)
-        theta = kPi + atan(dy / dx);
-    else if (dx < 0 && dy > 0)
-        theta = kPi + atan(dy / dx);
-    else if (dx == 0 && dy > 0)
-        theta = 0.5 * kPi;
-    else if (dx == 0 && dy < 0)
-        theta = 1.5 * kPi;
-    else if (dy == 0 && dx > 0)
-        theta = 0;
-    else
-        theta = kPi;
-    rel_theta = py_round(theta * rad2deg, 100.0);                                        // :169
-    double d = yaw - rel_theta;                                                          // :170
-    if ((0 <= d && d <= 180) || (-180 <= d && d < 0))                                    // :171-176
-        d = py_round(d, 100.0);
-    else if (d < -180)
-        d = py_round(360 + d, 100.0);
-    else
-        d = py_round(-360 + d, 100.0);
-    diff = d;
 }
 
 // Parametric ray / segment test.  o + t d = a + u e  =>  t = cross(a-o, e) / cross(d, e),
@@ -270,50 +288,39 @@ __device__ __forceinline__ void sample_episode(const Params& P, int i, uint32_t&
     }
 }
 
-// Observation row (environment_new.py:289-301) into a row of stride-1 floats.
-// `best` holds this env's NEAREST HITS (raw, +inf if none) with element stride `bstride`; `noise` (nullable) the
-// per-beam standard-normal draws with stride `nstride`.  Returns min(sanitised scan) for the collision rule (:200).
-__device__ __forceinline__ float write_obs_row(float* row, const float* best, int bstride, const float* noise, int nstride,
-                                               float sigma, int below_min_mode, int B, float pa0, float pa1, double dist,
-                                               double yaw, double rel_theta, double diff, double diag) {
-    float mn = INFINITY;
-    for (int b = 0; b < B; ++b) {
-        float r = sensor_value(best[b * bstride], sigma, noise ? noise[b * nstride] : 0.f, below_min_mode);
-        if (r == INFINITY) r = 3.5f;  // :193-194 (+inf only: -inf passes through like in the reference; NaN cannot occur)
-        mn = r < mn ? r : mn;
-        // (float)((double)r / 3.5) == r / 3.5f : double rounding is innocuous for a quotient of
-        // two float32 values (53 >= 2*24+2), so the float32 divide gives the reference's bits.
-        row[b] = r / 3.5f;            // :289
-    }
-    row[B + 0] = pa0;                 // :299-300
-    row[B + 1] = pa1;
-    row[B + 2] = (float)(dist / diag);       // :301
-    row[B + 3] = (float)(yaw / 360);
-    row[B + 4] = (float)(rel_theta / 360);
-    row[B + 5] = (float)(diff / 180);
-    return mn;
-}
+constexpr uint32_t kRecValid = 0x40000000u;   // bit of the ep_step word: the cached next-episode records of this env are current
+constexpr uint32_t kStepMask = 0x3FFFFFFFu;
 
 template <int NB, int EPB>
 struct StepSmem {
     float2 org[EPB];             // sensor origin per env
+    float2 hd[EPB];              // heading (cos, sin) as float32: the cull only (never the ranges)
     float2 dir[NB * EPB];        // [beam][env] unit direction
     unsigned rng[NB * EPB];      // [beam][env] nearest hit as float bits (non-negative floats order like uints)
     float obs[EPB * (NB + 7)];   // [env][B+6 (+1 pad: odd row stride, conflict-free)] the block's output tile
-    float noise[NB * EPB];     // [beam][env] standard-normal draws for the range noise (only written when sigma > 0)
-    double sc[EPB][8][2];  // pose phase: (cos, sin) of the 6 substep angles, of theta and of theta/2, one per lane
-    // pose-wave values parked here while wave 0 ray-casts (keeps the kernel under 128 VGPRs = 4 blocks per CU)
-    double sv_d[11][EPB];
+    float noise[NB * EPB];       // [beam][env] standard-normal draws for the range noise (only written when sigma > 0)
+    double sc[EPB][8][2];        // pose phase: (cos, sin) of the 6 substep angles, of theta and of theta/2, one per lane
+    // env state parked by the part-1 lanes for the part-2/3 lanes
+    double sv_d[13][EPB];        // x, y, th, gx, gy, past_dist, dist, yaw, rel_theta, diff, ep_ret, step displacement, ep_path
     float2 sv_act[EPB], sv_pact[EPB];
     uint32_t sv_ctr[EPB];
-    int sv_step[EPB];
-    // next-episode records prepared by pose lanes 1 and 2 of each env while the rays are cast:
-    //   [0] the reset that follows a collision / timeout, [1] the reset that follows an arrival (after the re-spawn draw)
-    double sp_d[2][9][EPB];   // start x, y, yaw, goal x, y, distance, yaw (deg), rel_theta, diff
+    uint32_t sv_step[EPB];       // raw ep_step word (kRecValid | step)
+    // next-episode records (cached in HBM, see Params::rec_*): [0] the reset that follows a collision / timeout,
+    // [1] the reset that follows an arrival when the arrival re-spawn draw comes first (respawn_on_arrive)
+    double sp_d[2][6][EPB];      // start x, y, yaw, goal x, y, distance
+    float4 sp_tail[2][EPB];      // the four goal entries of the reset observation
     uint32_t sp_ctr[2][EPB];
     int sp_k[2][EPB];
-    double sp_rg[2][EPB];     // the arrival re-spawn goal (environment_new.py:245-253) and the draw counter after it
+    double sp_rg[2][EPB];        // the arrival re-spawn goal (environment_new.py:245-253) and the draw counter after it
     uint32_t sp_rctr[EPB];
+    float sp_scan[2][EPB][NB];   // lidar entries of the reset observation (SENS: the raw nearest hits at the start pose)
+    unsigned mn_bits[EPB];       // min over the sanitised scan as float bits, and whether a reading is negative (-inf, SENS)
+    unsigned neg[EPB];
+    // cast: per-wave queue of the segments that survive the cull (ring of 128)
+    float4 q4[4][128];
+    unsigned qe[4][128];
+    float4 r4[4][128];           // ... and of those whose angular extent holds at least one beam
+    unsigned re[4][128];
 };
 
 // Correctly rounded K / Dn for positive, normal-range operands (Dn in [2^-60, 2^20], K in {0} U [2^-60, 2^20]):
@@ -349,42 +356,76 @@ __device__ __forceinline__ unsigned ray_seg_bits(float rx, float ry, float ex, f
     return __float_as_uint(div_pos(fabsf(k), fabsf(den))) | miss;
 }
 
+// Beam coordinate of a point (x ahead, y left) in the robot frame: f = (theta + A) / delta, beam b sits at f = b.
+// theta = 2 atan(u) with the half-angle tangent u = y / (r + x), monotone over (-pi, pi) and clamped to |u| <= 1.1 (just
+// past the +-90 degree fan edge, where only the side matters); atan by a degree-9 odd polynomial, |error| < 2.4e-5 rad.
+// Used ONLY to decide which segments are tested exactly, with a margin 40x above its error.  *bad: the point is within
+// 3 cm of the sensor or within 4.5e-3 rad of straight behind it, where u is ill-conditioned -- the caller keeps the segment.
+__device__ __forceinline__ float beam_coord(float x, float y, float two_inv_delta, float a_inv_delta, bool* bad) {
+    const float r = __builtin_amdgcn_sqrtf(fmaf(x, x, y * y));
+    const float d = r + x;
+    *bad = !(d > 1e-5f * r) || (r < 0.03f);
+    float u = y * __builtin_amdgcn_rcpf(d);
+    u = __builtin_amdgcn_fmed3f(u, -1.1f, 1.1f);
+    const float z = u * u;
+    float p = fmaf(0.01608042f, z, -0.07488631f);
+    p = fmaf(p, z, 0.1729194f);
+    p = fmaf(p, z, -0.32846571f);
+    p = fmaf(p, z, 0.99974538f);
+    return fmaf(u * p, two_inv_delta, a_inv_delta);
+}
+
 constexpr int kThreads = 256;   // 4 waves.  (A workgroup reserves ceil(waves/4) slots on EVERY SIMD of its CU, so
                                 // a 5-wave block costs as much residency as an 8-wave one: measured 1 block/CU.)
+
+// lidar part of an observation row (environment_new.py:289-294) from nearest hits `best` (stride `bstride`);
+// returns min(sanitised scan) for the collision rule (:200)
+__device__ __forceinline__ float write_lidar(float* row, const float* best, int bstride, const float* noise, int nstride,
+                                             float sigma, int below_min_mode, int B) {
+    float mn = INFINITY;
+    for (int b = 0; b < B; ++b) {
+        float r = sensor_value(best[b * bstride], sigma, noise ? noise[b * nstride] : 0.f, below_min_mode);
+        if (r == INFINITY) r = 3.5f;  // :193-194 (+inf only: -inf passes through like in the reference; NaN cannot occur)
+        mn = r < mn ? r : mn;
+        // (float)((double)r / 3.5) == r / 3.5f : double rounding is innocuous for a quotient of
+        // two float32 values (53 >= 2*24+2), so the float32 divide gives the reference's bits.
+        row[b] = r / 3.5f;            // :289
+    }
+    return mn;
+}
 
 // ---------------------------------------------------------------- the step kernel
 // One workgroup = 4 waves = EPB consecutive envs (EPB = 16: waves 0-1 are the "pose waves", 2-3 the "ray waves").
 //   part 1   pose waves, 8 lanes per env: state loads, float64 motion, the 8 sincos of the step one per lane -> LDS
 //            sensor origin + beam directions; the env's state is parked in LDS for its part-2/3 lane.
-//            ray waves: prefetch the segments of their first env / stage the shared map tile (nothing depends on the pose)
+//            ray waves: the first segment loads of their first work item (nothing there depends on the pose)
 //   barrier A
 //   part 2   lane-dense (a wave instruction costs the same with 8 or 64 active lanes): wave 0, lane = env: goal geometry
-//            of the new pose; last pose wave, 2 EPB lanes: the two possible next-episode records of every env (see there).
-//            Meanwhile the cast:
-//            per-env maps: an env is one work item taken from an LDS counter (the pose waves join when part 2 is done;
-//              a static split was measured 11 % slower); lane = segment, 16 B/lane coalesced, every segment read from HBM
-//              once; the next item's segments are in flight while the current one is tested; nearest hit per beam =
-//              per-lane min over its segments, then one LDS atomic-min per lane that saw a hit.
-//            shared map: segments staged in LDS tiles; every wave holds all rays of the block (lane + 64 m = ray) and takes
-//              chunks of the tile from the LDS counter, wave-wide broadcast reads, per-wave minima merged by LDS atomic-min.
+//            of the new pose; last pose wave: the next-episode records of every env -- read back from HBM, or, for an env
+//            whose goal stream moved since they were written, recomputed (Philox draw + start-pose geometry) and stored.
+//            Meanwhile the cast, one work item = one env (several envs when the map has <= 32 segments), taken from an
+//            LDS counter; lane = segment, 16 B/lane coalesced, every segment read from HBM once, two tiles ahead:
+//              stage A  cull: a segment that lies wholly behind the +-90 degree beam fan, or farther than the 3.5 m sensor
+//                       range, cannot change the scan (ranges >= 3.5 read as "no return", gazebo.xacro:119); the cull
+//                       is conservative (margins far above float32 noise) so the result keeps its bits.  Survivors
+//                       (about a quarter) are compacted into a per-wave LDS queue.
+//              stage B  whenever 64 survivors are queued: the exact ray/segment test of every beam, nearest hit per
+//                       (env, beam) by LDS atomic-min over float bit patterns.
 //   barrier B
 //   part 3   wave 0, lane = env: rules of getState / step / setReward, episode logic, state stores
 //   barrier C
 //   all:     the EPB x (B+6) observation tile leaves LDS as one contiguous, fully coalesced store.
 // SENS = false compiles the sensor-fidelity options (range noise, -inf below range_min) out.
-template <int NB, bool PER_ENV, int EPB, bool SENS>
+template <int NB, int EPB, bool SENS>
 __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* __restrict__ action,
                                                         const float2* __restrict__ past_override,
                                                         void* __restrict__ obs_out, float* __restrict__ reward,
                                                         uint8_t* __restrict__ done, uint8_t* __restrict__ arrive,
                                                         uint8_t* __restrict__ ended, float* __restrict__ ep_return,
-                                                        int32_t* __restrict__ ep_length) {
+                                                        int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out) {
     static_assert(EPB <= 64 && EPB >= 4 && NB % 2 == 0, "EPB / NB");
     __shared__ StepSmem<NB, EPB> sm;
-    __shared__ float4 seg_tile[PER_ENV ? 1 : kSegTile];
     __shared__ int next_env;
-    __shared__ int tile_tiny[4];   // shared map, one slot per loading wave: its part of the staged tile holds a
-                                   // degenerate-small segment (div_pos out of range)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -393,7 +434,6 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     constexpr int B = NB;       // host dispatch guarantees P.B == NB
     constexpr int D = B + 6;
     constexpr int DP = D + 1;   // padded LDS row stride
-    constexpr int PF = 2;       // segment tiles (64 segments each) of one env held in registers
     const int nloc = min(EPB, P.N - base);  // envs in this block
     const unsigned kInfBits = 0x7f800000u;
     // sensor-fidelity options (range noise, -inf below range_min) are compiled out of the default instantiation:
@@ -401,53 +441,67 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     const float sigma = SENS ? P.sigma : 0.f;
     const int below_min = SENS ? P.below_min_mode : 0;
 
-    // Pose lanes: 8 lanes per env (lane r of the group evaluates ONE of the 8 sincos the step needs: the six substep
-    // headings, the final heading, and half of it), so the pose phase costs one sincos latency instead of eight.
+    // Pose lanes: 8 lanes per env (lane r of the group evaluates ONE of the 7 sincos the step needs: the six substep
+    // headings and the final heading), so the pose phase costs one sincos latency instead of seven.
     // Lane r == 0 of each group owns the env's float64 state across the phases.  EPB envs -> EPB/8 waves (0, 1).
     constexpr int PW = (EPB + 7) / 8;          // pose waves
     static_assert(PW <= 2, "pose lanes live in waves 0 and 1");
-    double x = 0, y = 0, th = 0, gx = 0, gy = 0, pdist = 0, dist = 0, yaw = 0, rel_theta = 0, diff = 0, ret0 = 0;
+    double x = 0, y = 0, th = 0, gx = 0, gy = 0, pdist = 0, dist = 0, yaw = 0, rel_theta = 0, diff = 0, ret0 = 0, path0 = 0;
     float2 act = make_float2(0.f, 0.f), pact = make_float2(0.f, 0.f);
-    uint32_t ctr = 0;
-    int step0 = 0;
+    uint32_t ctr = 0, stepw = 0;
     const int el_pose = 8 * wave + (lane >> 3);  // env (local) this pose lane works for
     const int rr = lane & 7;
     const bool pose_lane = (wave < PW) && (el_pose < EPB);
     const int i = base + el_pose;
     // Parts 2 and 3 run lane-dense instead (a wave instruction costs the same with 8 or 64 active lanes, and the float64
     // geometry is ~1000 of them): the goal geometry and the rules of ALL the block's envs on lanes 0..EPB-1 of wave 0,
-    // the two next-episode records per env on 2 EPB lanes of the last pose wave (the same wave, behind the owners, when
+    // the next-episode records on n_rec EPB lanes of the last pose wave (the same wave, behind the owners, when
     // there is only one).  State crosses from the part-1 lanes through LDS (sv_*).
     const bool own = (wave == 0) && (lane < nloc);            // lane = env for the geometry / rules lanes
     constexpr int kSpecWave = PW - 1;
     constexpr int kSpecLane0 = (PW == 1) ? EPB : 0;
-    const int sl = lane - kSpecLane0;                         // spec lane index: case (sl / EPB), env (sl % EPB)
-    const bool spec_lane = (wave == kSpecWave) && (sl >= 0) && (sl < 2 * EPB) && ((sl % EPB) < nloc);
+    const int n_rec = P.respawn ? 2 : 1;
+    const int sl = lane - kSpecLane0;                         // spec lane index: record (sl / EPB), env (sl % EPB)
+    const bool spec_lane = (wave == kSpecWave) && (sl >= 0) && (sl < n_rec * EPB) && ((sl % EPB) < nloc);
 
-    float4 pre[PF];  // prefetched segments of the current work item (per-env maps)
-    auto prefetch = [&](int el, float4 (&dst)[PF]) {
-        const float4* __restrict__ sp = P.seg + (size_t)(base + el) * P.S;
-#pragma unroll
-        for (int t = 0; t < PF; ++t) {
-            const int j = lane + 64 * t;
-            if (j < P.S) dst[t] = sp[j];
-        }
+    // ---- cast geometry: lane -> (env of the pass, segment of the tile)
+    const int spl = P.seg_pack_log2;            // log2(lanes per env in one pass): 6, smaller when the map has <= 32 segments
+    const int epp = 64 >> spl;                  // envs per pass
+    const int sub = lane >> spl;
+    const int j0 = lane & ((1 << spl) - 1);
+    const int n_items = (nloc + epp - 1) / epp;
+    const int ntiles = (P.S + 63) >> 6;
+    struct Pos { int it, t; };
+    auto grab = [&]() __attribute__((always_inline)) {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&next_env, 1);
+        return __builtin_amdgcn_readfirstlane(v);
     };
+    auto ld = [&](const Pos p, float4& g, bool& v) __attribute__((always_inline)) {
+        const int el = p.it * epp + sub, j = (p.t << 6) + j0;
+        v = (p.it < n_items) && (el < nloc) && (j < P.S);
+        if (v) g = P.seg[(P.per_env ? (size_t)(base + el) * (size_t)P.S : (size_t)0) + (size_t)j];
+    };
+    Pos p0 = {n_items, 0}, p1 = {n_items, 0}, p2 = {n_items, 0};
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+    bool v0 = false, v1 = false, v2 = false;
 
     if (wave < PW) {
         // ---------------- pose lanes, part 1: motion + sensor frame
         if (pose_lane) {
-            double delta_s = 0, delta_theta = 0, arg = 0;
+            double delta_s = 0, delta_theta = 0, arg = 0, x_old = 0, y_old = 0;
             if (el_pose < nloc) {
                 th = P.th[i];
                 act = action[i];
                 ctr = P.rng_ctr[i];
-                step0 = P.ep_step[i];
+                stepw = (uint32_t)P.ep_step[i];
                 if (rr == 0) {
                     x = P.x[i]; y = P.y[i];
                     gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
                     pact = past_override ? past_override[i] : P.past_action[i];
                     ret0 = P.ep_ret[i];
+                    path0 = P.ep_path[i];
+                    x_old = x; y_old = y;
                 }
                 // environment_new.py:273-278
                 const double v = (double)act.x / 4;
@@ -465,11 +519,14 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
                     if (k == rr) arg = th + (delta_theta / 2.0);  // :158-159 argument of substep rr
                     th += delta_theta;                             // :160
                 }
-                if (rr == 6) arg = th;
-                if (rr == 7) arg = th / 2;
+                if (rr >= 6) arg = th;
             }
-            sm.sc[el_pose][rr][0] = cos(arg);
-            sm.sc[el_pose][rr][1] = sin(arg);
+            {
+                double sn, cs;
+                sincos(arg, &sn, &cs);   // one shared argument reduction
+                sm.sc[el_pose][rr][0] = cs;
+                sm.sc[el_pose][rr][1] = sn;
+            }
             // same wave wrote what this lane reads next: LDS ops of a wave complete in order, no barrier needed
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -482,11 +539,15 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
                 const double ox = x + kLidarX * cth;
                 const double oy = y + kLidarX * sth;
                 sm.org[el_pose] = make_float2((float)ox, (float)oy);
+                sm.hd[el_pose] = make_float2((float)cth, (float)sth);
                 if (el_pose < nloc) {  // hand the env over to its geometry / rules lane
                     const int e = el_pose;
+                    const double mx = x - x_old, my = y - y_old;
                     sm.sv_d[0][e] = x; sm.sv_d[1][e] = y; sm.sv_d[2][e] = th; sm.sv_d[3][e] = gx; sm.sv_d[4][e] = gy;
                     sm.sv_d[5][e] = pdist; sm.sv_d[10][e] = ret0;
-                    sm.sv_act[e] = act; sm.sv_pact[e] = pact; sm.sv_ctr[e] = ctr; sm.sv_step[e] = step0;
+                    sm.sv_d[11][e] = sqrt(mx * mx + my * my);   // np.linalg.norm(curr_pos - prev_pos), ppo.py:536-537
+                    sm.sv_d[12][e] = path0;
+                    sm.sv_act[e] = act; sm.sv_pact[e] = pact; sm.sv_ctr[e] = ctr; sm.sv_step[e] = stepw;
                 }
             }
             {
@@ -499,72 +560,96 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
                 }
             }
         }
-        if (tid == 0) next_env = PER_ENV ? 4 - PW : 0;  // per-env: the first envs are pre-assigned to the ray waves; shared: chunk counter
-        if (lane == 0) tile_tiny[wave] = 0;
+        if (tid == 0) next_env = 4 - PW;  // the first work items are pre-assigned to the ray waves
     }
     if (wave >= PW) {
         // ---------------- other waves, part 1: nothing here depends on the pose
         for (int k = tid - 64 * PW; k < NB * EPB; k += kThreads - 64 * PW) sm.rng[k] = kInfBits;
-        if constexpr (PER_ENV) {
-            if (wave - PW < nloc) prefetch(wave - PW, pre);
-        } else {
-            const int ns = min(kSegTile, P.S);
-            bool tiny = false;
-            for (int j = tid - 64 * PW; j < ns; j += kThreads - 64 * PW) {
-                const float4 g = P.seg[j];
-                seg_tile[j] = g;
-                tiny |= fmaxf(fabsf(g.z - g.x), fabsf(g.w - g.y)) < 0x1p-10f;
-            }
-            const int any_tiny = __any(tiny) ? 1 : 0;
-            if (lane == 0) tile_tiny[wave] = any_tiny;
+        if (tid - 64 * PW < EPB) {
+            sm.mn_bits[tid - 64 * PW] = kInfBits;
+            sm.neg[tid - 64 * PW] = 0u;
+        }
+        p0 = Pos{wave - PW, 0};
+        ld(p0, g0, v0);
+        if (ntiles > 1) {
+            p1 = Pos{wave - PW, 1};
+            ld(p1, g1, v1);
         }
     }
-    __syncthreads();  // barrier A: origins / directions / first segment tile visible
+    __syncthreads();  // barrier A: origins / directions visible, work counter set
 
     if (sigma > 0.f && pose_lane && el_pose < nloc) {
         // range noise for this step: lane rr draws beams rr, rr + 8, ... (off the critical path: the others ray-cast)
         for (int b = rr; b < B; b += 8)
-            sm.noise[b * EPB + el_pose] = lidar_noise(P.key0, P.key1, P.env_id_base + (uint64_t)i, ctr, (uint32_t)step0, b);
+            sm.noise[b * EPB + el_pose] = lidar_noise(P.key0, P.key1, P.env_id_base + (uint64_t)i, ctr, stepw & kStepMask, b);
     }
     // ---------------- part 2 (the other waves are already ray-casting): goal geometry.
-    // An owner lane works on the pose its env just moved to.  The spec lanes prepare, with the same instructions, the
-    // episode that starts if this step ends the current one (ppo.py:582-593 + Env.reset, environment_new.py:312-382): an
-    // episode draws from the goal stream only when it ends, so its successor is known now -- record 0 for an end by
-    // collision or timeout, record 1 for an end by arrival (the arrival re-spawn draw of :245-253 comes first).  The
-    // owner picks one of the two in part 3 instead of running Philox + a second goal geometry behind everyone else.
-    const bool spec = spec_lane && (P.auto_reset || (sl >= EPB && P.respawn));
+    // An owner lane works on the pose its env just moved to.  The spec lanes hold the episode that starts if this step
+    // ends the current one (ppo.py:582-593 + Env.reset, environment_new.py:312-382): an episode draws from the goal stream
+    // only when it ends, so its successor is known from the moment it starts -- record 0 for an end by collision or
+    // timeout (and by arrival when respawn_on_arrive is off), record 1 for an end by arrival after the arrival re-spawn
+    // draw of :245-253.  Records live in HBM; kRecValid in the env's ep_step word says they match its draw counter.
+    // A spec lane of an env whose flag is clear (it was reset, or its goal stream moved) recomputes and stores them.
+    const bool spec = spec_lane && (P.auto_reset || (sl >= EPB));
     if (own || spec) {
         const int e = own ? lane : sl % EPB;
         const int ie = base + e;
-        double px = 0, py = 0, pth = 0, qz = 0, qw = 1, tgx = 0, tgy = 0, rgx = 0, rgy = 0;
-        uint32_t sctr = sm.sv_ctr[e], rctr = sctr;
-        int sk = 0;
         if (own) {
-            px = sm.sv_d[0][e]; py = sm.sv_d[1][e]; tgx = sm.sv_d[3][e]; tgy = sm.sv_d[4][e];
-            qz = sm.sc[e][7][1];
-            qw = sm.sc[e][7][0];
-        } else {
-            if (sl >= EPB && P.respawn) {
-                sample_goal(P, ie, 1, sctr, rgx, rgy);
-                rctr = sctr;
-            }
-            if (P.auto_reset) {
-                sample_episode(P, ie, sctr, sk, tgx, tgy);
-                px = P.starts[3 * sk]; py = P.starts[3 * sk + 1]; pth = P.starts[3 * sk + 2];
-                qw = P.starts_sc[2 * sk]; qz = P.starts_sc[2 * sk + 1];
-            }
-        }
-        if (own || P.auto_reset) {
-            goal_angles_q(px, py, qz, qw, tgx, tgy, yaw, rel_theta, diff);
+            const double px = sm.sv_d[0][e], py = sm.sv_d[1][e], tgx = sm.sv_d[3][e], tgy = sm.sv_d[4][e];
+            // yaw: rint of the heading in degrees; the quaternion route of :142 only when the two could round differently
+            const double pth = sm.sv_d[2][e];
+            bool exact;
+            yaw = yaw_fast(pth, &exact);
+            if (__builtin_expect(!exact, 0)) yaw = yaw_from_quat(sin(pth / 2), cos(pth / 2));
+            goal_rel(px, py, tgx, tgy, yaw, rel_theta, diff);
             dist = hypot(tgx - px, tgy - py);  // environment_new.py:203 ; getGoalDistace, :116-120
-        }
-        if (own) {
             sm.sv_d[6][e] = dist; sm.sv_d[7][e] = yaw; sm.sv_d[8][e] = rel_theta; sm.sv_d[9][e] = diff;
         } else {
             const int c = sl / EPB;
+            const size_t N = (size_t)P.N;
+            double px = 0, py = 0, pth = 0, tgx = 0, tgy = 0, rgx = 0, rgy = 0, rdist = 0;
+            float4 tl = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t sctr = sm.sv_ctr[e], rctr = sctr;
+            int sk = 0;
+            if (sm.sv_step[e] & kRecValid) {
+                if (c == 1) {
+                    rgx = P.rsp_g[ie]; rgy = P.rsp_g[N + ie]; rctr = P.rsp_ctr[ie];
+                }
+                if (P.auto_reset) {
+                    const double* rg = P.rec_g + (size_t)c * 3 * N + ie;
+                    tgx = rg[0]; tgy = rg[N]; rdist = rg[2 * N];
+                    tl = P.rec_tail[(size_t)c * N + ie];
+                    const uint2 ck = P.rec_ck[(size_t)c * N + ie];
+                    sctr = ck.x; sk = (int)ck.y;
+                    px = P.starts[3 * sk]; py = P.starts[3 * sk + 1]; pth = P.starts[3 * sk + 2];
+                }
+            } else {
+                if (c == 1) {
+                    sample_goal(P, ie, 1, sctr, rgx, rgy);
+                    rctr = sctr;
+                    P.rsp_g[ie] = rgx; P.rsp_g[N + ie] = rgy; P.rsp_ctr[ie] = rctr;
+                }
+                if (P.auto_reset) {
+                    sample_episode(P, ie, sctr, sk, tgx, tgy);
+                    px = P.starts[3 * sk]; py = P.starts[3 * sk + 1]; pth = P.starts[3 * sk + 2];
+                    double ryaw, rrel, rdiff;
+                    goal_angles_q(px, py, P.starts_sc[2 * sk + 1], P.starts_sc[2 * sk], tgx, tgy, ryaw, rrel, rdiff);
+                    rdist = hypot(tgx - px, tgy - py);
+                    tl = make_float4((float)(rdist / P.diag), (float)(ryaw / 360), (float)(rrel / 360), (float)(rdiff / 180));
+                    double* rg = P.rec_g + (size_t)c * 3 * N + ie;
+                    rg[0] = tgx; rg[N] = tgy; rg[2 * N] = rdist;
+                    P.rec_tail[(size_t)c * N + ie] = tl;
+                    P.rec_ck[(size_t)c * N + ie] = make_uint2(sctr, (uint32_t)sk);
+                }
+            }
+            if (P.auto_reset) {   // the scan every reset at start pose sk observes
+                const float* sp = (SENS ? P.spawn_scan : P.spawn_obs) + ((P.per_env ? (size_t)ie * P.K : 0) + sk) * B;
+#pragma unroll 2
+                for (int b = 0; b < NB; ++b) sm.sp_scan[c][e][b] = sp[b];
+            }
             sm.sp_d[c][0][e] = px; sm.sp_d[c][1][e] = py; sm.sp_d[c][2][e] = pth; sm.sp_d[c][3][e] = tgx;
-            sm.sp_d[c][4][e] = tgy; sm.sp_d[c][5][e] = dist; sm.sp_d[c][6][e] = yaw; sm.sp_d[c][7][e] = rel_theta;
-            sm.sp_d[c][8][e] = diff;
+            sm.sp_d[c][4][e] = tgy; sm.sp_d[c][5][e] = rdist;
+            sm.sp_tail[c][e] = tl;
             sm.sp_ctr[c][e] = sctr;
             sm.sp_k[c][e] = sk;
             if (c == 1) {
@@ -573,133 +658,169 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             }
         }
     }
-    if constexpr (PER_ENV) {
-        auto grab = [&]() {
-            int v = 0;
-            if (lane == 0) v = atomicAdd(&next_env, 1);
-            return __builtin_amdgcn_readfirstlane(v);
-        };
-        int cur = (wave < PW) ? grab() : wave - PW;
-        if (wave < PW && cur < nloc) prefetch(cur, pre);
-        while (cur < nloc) {  // wave-uniform
-            const int nxt = grab();
-            float4 pre_nxt[PF];
-            if (nxt < nloc) prefetch(nxt, pre_nxt);
-            const float2 o = sm.org[cur];
-            float dc[NB], ds[NB];
-            unsigned best[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const float2 d = sm.dir[b * EPB + cur];
-                dc[b] = d.x;
-                ds[b] = d.y;
-                best[b] = kInfBits;
-            }
-            auto accumulate = [&](const float4 g) {
-                const float rx = g.x - o.x, ry = g.y - o.y;
-                const float ex = g.z - g.x, ey = g.w - g.y;
-                const float k = fmaf(rx, ey, -(ry * ex));
-                // div_pos needs |den| in [2^-60, 2^20]: true unless the segment is degenerate-small
-                // (coordinates are documented to be < 2^19); such tiles take the plain IEEE divide.
-                const bool tiny = fmaxf(fabsf(ex), fabsf(ey)) < 0x1p-10f;
-                if (__builtin_expect(__any(tiny), 0)) {
-                    // the empty volatile asm keeps this a real (wave-uniform) branch the compiler cannot speculate
-                    asm volatile("; degenerate-segment tile" ::: "memory");
-#pragma unroll
-                    for (int b = 0; b < NB; ++b)
-                        best[b] = min(best[b], __float_as_uint(ray_seg(rx, ry, ex, ey, k, dc[b], ds[b])) & 0x7fffffffu);
-                    return;
-                }
-#pragma unroll
-                for (int b = 0; b < NB; ++b) best[b] = min(best[b], ray_seg_bits(rx, ry, ex, ey, k, dc[b], ds[b]));
-            };
-#pragma unroll
-            for (int t = 0; t < PF; ++t)
-                if (lane + 64 * t < P.S) accumulate(pre[t]);
-            const float4* __restrict__ sp = P.seg + (size_t)(base + cur) * P.S;
-            for (int j = lane + 64 * PF; j < P.S; j += 64) accumulate(sp[j]);
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                if (best[b] < kInfBits) atomicMin(&sm.rng[b * EPB + cur], best[b]);
-#pragma unroll
-            for (int t = 0; t < PF; ++t) pre[t] = pre_nxt[t];
-            cur = nxt;
-        }
-    } else {
-        // Every wave holds ALL rays of the block (lane + 64 m = ray (env, beam)) and takes CHUNKS of the staged tile from
-        // an LDS counter: the ray waves start at once, the pose waves join when part 2 is done, and a large map keeps all
-        // four waves busy.  Segments are wave-wide broadcast reads; the per-wave minima meet in LDS atomic-mins.
-        constexpr int NR = EPB * NB;                 // rays of this block
-        constexpr int RPL = (NR + 63) / 64;          // rays per lane
-        float ox[RPL], oy[RPL], dc[RPL], ds[RPL];
-        unsigned best[RPL];
-#pragma unroll
-        for (int m = 0; m < RPL; ++m) {
-            const int r = min(lane + 64 * m, NR - 1);
-            const int el = r / NB, b = r % NB;
+    // ---------------- the cast
+    {
+        float4* const q4 = sm.q4[wave];
+        unsigned* const qe = sm.qe[wave];
+        float4* const r4 = sm.r4[wave];
+        unsigned* const re = sm.re[wave];
+        int qhead = 0, qtail = 0, rhead = 0, rtail = 0;   // wave-uniform
+        // stage B: exact tests of up to 64 queued segments against every beam of their env
+        auto flushB = [&](int n) __attribute__((always_inline)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool on = lane < n;
+            const int slot = (rhead + lane) & 127;
+            const float4 g = on ? r4[slot] : make_float4(0.f, 0.f, 1.f, 0.f);
+            const unsigned el = on ? re[slot] : 0u;
             const float2 o = sm.org[el];
-            const float2 d = sm.dir[b * EPB + el];
-            ox[m] = o.x; oy[m] = o.y; dc[m] = d.x; ds[m] = d.y;
-            best[m] = kInfBits;
-        }
-        for (int s0 = 0; s0 < P.S; s0 += kSegTile) {  // uniform trip count
-            const int ns = min(kSegTile, P.S - s0);
-            if (s0 > 0) {
-                __syncthreads();
-                bool tiny = false;
-                for (int j = tid; j < ns; j += kThreads) {
-                    const float4 g = P.seg[s0 + j];
-                    seg_tile[j] = g;
-                    tiny |= fmaxf(fabsf(g.z - g.x), fabsf(g.w - g.y)) < 0x1p-10f;
+            const float rx = g.x - o.x, ry = g.y - o.y;
+            const float ex = g.z - g.x, ey = g.w - g.y;
+            const float k = fmaf(rx, ey, -(ry * ex));
+            // div_pos needs |den| in [2^-60, 2^20]: true unless the segment is degenerate-small
+            // (coordinates are documented to be < 2^19); such passes take the plain IEEE divide.
+            const bool tiny = fmaxf(fabsf(ex), fabsf(ey)) < 0x1p-10f;
+            if (__builtin_expect(__any(tiny), 0)) {
+                // the empty volatile asm keeps this a real (wave-uniform) branch the compiler cannot speculate
+                asm volatile("; degenerate-segment pass" ::: "memory");
+                for (int b = 0; b < NB; ++b) {
+                    const float2 d = sm.dir[b * EPB + el];
+                    const unsigned bits = __float_as_uint(ray_seg(rx, ry, ex, ey, k, d.x, d.y)) & 0x7fffffffu;
+                    if (on && bits < kInfBits) atomicMin(&sm.rng[b * EPB + el], bits);
                 }
-                const int any_tiny = __any(tiny) ? 1 : 0;
-                if (lane == 0) tile_tiny[wave] = any_tiny;
-                if (tid == 0) next_env = 0;
-                __syncthreads();
-            }
-            const int chunk = max(4, min(32, ns >> 3));
-            const bool slow = (tile_tiny[0] | tile_tiny[1] | tile_tiny[2] | tile_tiny[3]) != 0;
-            for (;;) {
-                int c = 0;
-                if (lane == 0) c = atomicAdd(&next_env, 1);
-                c = __builtin_amdgcn_readfirstlane(c);
-                const int j0 = c * chunk, j1 = min(j0 + chunk, ns);
-                if (j0 >= ns) break;
-                if (__builtin_expect(slow, 0)) {   // div_pos needs |den| >= 2^-60: such tiles take the plain IEEE divide
-                    asm volatile("; degenerate-segment tile" ::: "memory");
-                    for (int j = j0; j < j1; ++j) {
-                        const float4 g = seg_tile[j];
-                        const float ex = g.z - g.x, ey = g.w - g.y;
+            } else {
 #pragma unroll
-                        for (int m = 0; m < RPL; ++m) {
-                            const float rx = g.x - ox[m], ry = g.y - oy[m];
-                            const float k = fmaf(rx, ey, -(ry * ex));
-                            best[m] = min(best[m], __float_as_uint(ray_seg(rx, ry, ex, ey, k, dc[m], ds[m])) & 0x7fffffffu);
-                        }
-                    }
-                } else {
-                    // branch-free body: iterations are independent, so the unrolled copies overlap their division chains
-#pragma unroll 4
-                    for (int j = j0; j < j1; ++j) {
-                        const float4 g = seg_tile[j];
-                        const float ex = g.z - g.x, ey = g.w - g.y;
-#pragma unroll
-                        for (int m = 0; m < RPL; ++m) {
-                            const float rx = g.x - ox[m], ry = g.y - oy[m];
-                            const float k = fmaf(rx, ey, -(ry * ex));
-                            best[m] = min(best[m], ray_seg_bits(rx, ry, ex, ey, k, dc[m], ds[m]));
-                        }
-                    }
+                for (int b = 0; b < NB; ++b) {
+                    const float2 d = sm.dir[b * EPB + el];
+                    const unsigned bits = ray_seg_bits(rx, ry, ex, ey, k, d.x, d.y);
+                    // hits only: same-address LDS atomics of a wave serialise, and most lanes miss
+                    if (on && bits < kInfBits) atomicMin(&sm.rng[b * EPB + el], bits);
                 }
             }
+            rhead += n;
+        };
+        // stage A2, dense over up to 64 survivors of the range / behind cull: does the arc the segment subtends, as seen
+        // from the sensor, hold a beam at all?  (Beams are 20 degrees apart, a pillar facet at 2 m subtends 2.)
+        constexpr float kInvDelta = (float)((NB - 1) / (2.0 * kAngleMax)), kBeamMargin = 0.02f;
+        auto flushA2 = [&](int n) __attribute__((always_inline)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool on = lane < n;
+            const int slot = (qhead + lane) & 127;
+            const float4 g = on ? q4[slot] : make_float4(0.f, 0.f, 1.f, 0.f);
+            const unsigned el = on ? qe[slot] : 0u;
+            const float2 o = sm.org[el], h = sm.hd[el];
+            const float ax = g.x - o.x, ay = g.y - o.y, bx = g.z - o.x, by = g.w - o.y;
+            const float xa = fmaf(ax, h.x, ay * h.y), ya = fmaf(ay, h.x, -(ax * h.y));
+            const float xb = fmaf(bx, h.x, by * h.y), yb = fmaf(by, h.x, -(bx * h.y));
+            bool bad_a, bad_b;
+            const float fa = beam_coord(xa, ya, 2.f * kInvDelta, (float)kAngleMax * kInvDelta, &bad_a);
+            const float fb = beam_coord(xb, yb, 2.f * kInvDelta, (float)kAngleMax * kInvDelta, &bad_b);
+            const float lo = fminf(fa, fb), hi = fmaxf(fa, fb);
+            // the arc runs through straight-behind iff the segment crosses the negative X axis: Y changes sign and the
+            // crossing X = cross(a, b) / (yb - ya) is negative
+            const float kl = fmaf(xa, yb, -(xb * ya)), ey = yb - ya, ex = xb - xa;
+            const bool wrap = (ya * yb < 0.f) && (kl * ey < 0.f);
+            const bool through = kl * kl <= 1e-6f * fmaf(ex, ex, ey * ey);   // the line passes within 1 mm of the sensor
+            const float ce = ceilf(lo - kBeamMargin), fl = floorf(hi + kBeamMargin);
+            const bool inside = (fl >= ce) && (fl >= 0.f) && (ce <= (float)(NB - 1));
+            const bool outside = (lo + kBeamMargin >= 0.f) || (hi - kBeamMargin <= (float)(NB - 1));
+            const bool keep = on && (bad_a || bad_b || through || (wrap ? outside : inside));
+            qhead += n;
+            const unsigned long long bal = __ballot(keep);
+            if (bal) {
+                const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (keep) {
+                    const int s2 = (rtail + off) & 127;
+                    r4[s2] = g;
+                    re[s2] = el;
+                }
+                rtail += __popcll(bal);
+                if (rtail - rhead >= 64) flushB(64);
+            }
+        };
+        // stage A: cull + compaction of one tile (64 lanes = 64 segments, or 64 / epp segments of epp envs)
+        auto cull = [&](const Pos p, const float4 g, const bool v) __attribute__((always_inline)) {
+            const int el = min(p.it * epp + sub, nloc - 1);
+            const float2 o = sm.org[el], h = sm.hd[el];
+            // endpoints in the robot frame (X ahead, Y left); float32 throughout: this decides only what is tested exactly
+            const float ax = g.x - o.x, ay = g.y - o.y, bx = g.z - o.x, by = g.w - o.y;
+            const float xa = fmaf(ax, h.x, ay * h.y), ya = fmaf(ay, h.x, -(ax * h.y));
+            const float xb = fmaf(bx, h.x, by * h.y), yb = fmaf(by, h.x, -(bx * h.y));
+            // behind: both endpoints inside the convex cone X < -1e-3 |Y|; the beams span +-(pi/2 + 1.2e-6)
+            const bool behind = (fmaf(1e-3f, fabsf(ya), xa) < 0.f) && (fmaf(1e-3f, fabsf(yb), xb) < 0.f);
+            // far: distance from the sensor to the segment above 3.5 m (threshold 12.3 = (3.5 * 1.002)^2)
+            const float ex = xb - xa, ey = yb - ya;
+            const float e2 = fmaf(ex, ex, ey * ey), ae = fmaf(xa, ex, ya * ey), be = ae + e2;
+            const float a2 = fmaf(xa, xa, ya * ya), b2 = fmaf(xb, xb, yb * yb), kl = fmaf(xa, yb, -(xb * ya));
+            const bool far = (ae >= 0.f) ? (a2 > 12.3f) : ((be <= 0.f) ? (b2 > 12.3f) : (kl * kl > 12.3f * e2));
+            const bool near = fminf(a2, b2) < 1e-6f;   // an endpoint within 1 mm of the sensor: angles are noise, keep
+            const bool keep = v && (near || !(behind || far));
+            const unsigned long long bal = __ballot(keep);
+            if (bal) {
+                const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (keep) {
+                    const int slot = (qtail + off) & 127;
+                    q4[slot] = g;
+                    qe[slot] = (unsigned)el;
+                }
+                qtail += __popcll(bal);
+                if (qtail - qhead >= 64) flushA2(64);
+            }
+        };
+        auto advance = [&](const Pos p) __attribute__((always_inline)) -> Pos {
+            if (p.it >= n_items) return p;
+            if (p.t + 1 < ntiles) return Pos{p.it, p.t + 1};
+            return Pos{grab(), 0};
+        };
+        if (wave < PW) {   // pose waves join when part 2 is done
+            p0 = Pos{grab(), 0};
+            ld(p0, g0, v0);
+            p1 = advance(p0);
+            ld(p1, g1, v1);
+        } else if (ntiles == 1) {
+            p1 = advance(p0);
+            ld(p1, g1, v1);
         }
-#pragma unroll
-        for (int m = 0; m < RPL; ++m) {
-            const int r = lane + 64 * m;
-            if (r < NR && best[m] < kInfBits) atomicMin(&sm.rng[(r % NB) * EPB + (r / NB)], best[m]);
+        p2 = advance(p1);
+        ld(p2, g2, v2);
+        // three tiles in flight; the slots take turns (a register rotation would have to wait for the load it moves)
+        for (;;) {   // wave-uniform
+            if (p0.it >= n_items) break;
+            cull(p0, g0, v0);
+            p0 = advance(p2);
+            ld(p0, g0, v0);
+            if (p1.it >= n_items) break;
+            cull(p1, g1, v1);
+            p1 = advance(p0);
+            ld(p1, g1, v1);
+            if (p2.it >= n_items) break;
+            cull(p2, g2, v2);
+            p2 = advance(p1);
+            ld(p2, g2, v2);
         }
+        if (qtail > qhead) flushA2(qtail - qhead);
+        if (rtail > rhead) flushB(rtail - rhead);
     }
     __syncthreads();  // barrier B: nearest hits complete
+
+    // ---------------- scan -> observation entries, lane = (beam, env): sanitise (environment_new.py:192-198), / 3.5 (:289),
+    // and min(scan) for the collision rule (:200).  Nearest hits are uint bit patterns of non-negative floats (inf = none).
+    for (int idx = tid; idx < NB * EPB; idx += kThreads) {
+        const int b = idx / EPB, e = idx % EPB;
+        if (e < nloc) {
+            float r = sensor_value(__uint_as_float(sm.rng[idx]), sigma, (sigma > 0.f) ? sm.noise[idx] : 0.f, below_min);
+            if (r == INFINITY) r = 3.5f;  // :193-194 (+inf only: -inf passes through like in the reference; NaN cannot occur)
+            // (float)((double)r / 3.5) == r / 3.5f : double rounding is innocuous for a quotient of
+            // two float32 values (53 >= 2*24+2), so the float32 divide gives the reference's bits.
+            sm.obs[e * DP + b] = r / 3.5f;
+            if (SENS && r < 0.f)
+                atomicOr(&sm.neg[e], 1u);
+            else
+                atomicMin(&sm.mn_bits[e], __float_as_uint(r));
+        }
+    }
+    __syncthreads();  // barrier B2: lidar entries and their minima complete
 
     // ---------------- part 3 (wave 0, lane = env): rules of getState / step / setReward + episode logic
     if (own) {
@@ -708,12 +829,18 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         x = sm.sv_d[0][e]; y = sm.sv_d[1][e]; th = sm.sv_d[2][e]; gx = sm.sv_d[3][e]; gy = sm.sv_d[4][e];
         pdist = sm.sv_d[5][e]; dist = sm.sv_d[6][e]; yaw = sm.sv_d[7][e]; rel_theta = sm.sv_d[8][e];
         diff = sm.sv_d[9][e]; ret0 = sm.sv_d[10][e];
-        act = sm.sv_act[e]; pact = sm.sv_pact[e]; ctr = sm.sv_ctr[e]; step0 = sm.sv_step[e];
+        double path = sm.sv_d[12][e];
+        act = sm.sv_act[e]; pact = sm.sv_pact[e]; ctr = sm.sv_ctr[e];
+        const uint32_t step0 = sm.sv_step[e] & kStepMask;
         float* row = sm.obs + e * DP;
         const float* noise = (sigma > 0.f) ? sm.noise + e : nullptr;
-        // nearest hits are held as uint bit patterns of non-negative floats (inf = no hit)
-        const float mn = write_obs_row(row, reinterpret_cast<const float*>(sm.rng) + e, EPB, noise, EPB, sigma, below_min, B,
-                                       pact.x, pact.y, dist, yaw, rel_theta, diff, P.diag);
+        const float mn = (SENS && sm.neg[e]) ? -INFINITY : __uint_as_float(sm.mn_bits[e]);
+        row[B + 0] = pact.x;                        // environment_new.py:299-300
+        row[B + 1] = pact.y;
+        row[B + 2] = (float)(dist / P.diag);        // :301
+        row[B + 3] = (float)div_const(yaw, 360.0, 1.0 / 360.0);        // yaw / 360, rel_theta / 360, diff_angle / 180:
+        row[B + 4] = (float)div_const(rel_theta, 360.0, 1.0 / 360.0);  // correctly rounded over these operands' domains
+        row[B + 5] = (float)div_const(diff, 180.0, 1.0 / 180.0);       // (integers, k/100), tools/verify
         const bool d = (0.2 > (double)mn) && ((double)mn > 0);  // environment_new.py:200
         const bool a = dist <= P.thr;                             // :204
         // setReward, :209-222
@@ -721,14 +848,16 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         pdist = dist;
         if (d) r = -100.;
         if (a) r = 120.;
-        if (a && P.respawn) {  // :245-267 (drawn by lane 2 in part 2)
+        bool moved_stream = false;
+        if (a && P.respawn) {  // :245-267 (drawn ahead by the spec lane of record 1)
             gx = sm.sp_rg[0][e]; gy = sm.sp_rg[1][e];
             ctr = sm.sp_rctr[e];
+            moved_stream = true;
             if (!P.auto_reset) pdist = hypot(gx - x, gy - y);  // with auto_reset the arrival ends the episode: pdist is re-based below
         }
-        int step = step0 + 1;
+        uint32_t step = step0 + 1;
         double ret = ret0 + r;
-        const bool timeout = (P.max_ep_steps > 0) && (step >= P.max_ep_steps);  // ppo.py:552
+        const bool timeout = (P.max_ep_steps > 0) && ((int)step >= P.max_ep_steps);  // ppo.py:552
         const bool end = d || a || timeout;
         reward[i] = (float)r;
         done[i] = d ? 1 : 0;
@@ -736,27 +865,40 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         if (ended) ended[i] = end ? 1 : 0;
         if (end) {
             if (ep_return) ep_return[i] = (float)ret;
-            if (ep_length) ep_length[i] = step;
+            if (ep_length) ep_length[i] = (int32_t)step;
+            if (ep_path_out) ep_path_out[i] = (float)path;   // ppo.py:533-537: the final step's displacement is never added
         }
+        path += sm.sv_d[11][e];
         float2 next_pact = act;  // ppo.py:543
-        if (end && P.auto_reset) {  // ppo.py:582-593 + Env.reset, environment_new.py:312-382: the record prepared in part 2
-            const int c = a ? 1 : 0;
+        if (end && P.auto_reset) {  // ppo.py:582-593 + Env.reset, environment_new.py:312-382: the record read / prepared in part 2
+            const int c = (a && P.respawn) ? 1 : 0;
             x = sm.sp_d[c][0][e]; y = sm.sp_d[c][1][e]; th = sm.sp_d[c][2][e]; gx = sm.sp_d[c][3][e]; gy = sm.sp_d[c][4][e];
-            dist = sm.sp_d[c][5][e]; yaw = sm.sp_d[c][6][e]; rel_theta = sm.sp_d[c][7][e]; diff = sm.sp_d[c][8][e];
+            dist = sm.sp_d[c][5][e];
             ctr = sm.sp_ctr[c][e];
-            const int k0 = sm.sp_k[c][e];
             step = 0;
             ret = 0;
+            path = 0;
+            moved_stream = true;
             next_pact = make_float2(0.f, 0.f);
             pdist = dist;  // getGoalDistace, :116-120,:359
-            const float* sp = P.spawn_scan + ((PER_ENV ? (size_t)i * P.K : 0) + k0) * B;
-            write_obs_row(row, sp, 1, noise, EPB, sigma, below_min, B, 0.f, 0.f, dist, yaw, rel_theta, diff, P.diag);
+            if (SENS) {
+                write_lidar(row, sm.sp_scan[c][e], 1, noise, EPB, sigma, below_min, B);
+            } else {
+#pragma unroll 2
+                for (int b = 0; b < NB; ++b) row[b] = sm.sp_scan[c][e][b];
+            }
+            const float4 tl = sm.sp_tail[c][e];
+            row[B + 0] = 0.f; row[B + 1] = 0.f;        // :372-373
+            row[B + 2] = tl.x; row[B + 3] = tl.y; row[B + 4] = tl.z; row[B + 5] = tl.w;
         }
         P.x[i] = x; P.y[i] = y; P.th[i] = th;
         P.gx[i] = gx; P.gy[i] = gy; P.past_dist[i] = pdist;
         P.past_action[i] = next_pact;
-        P.ep_step[i] = step;
+        // the records written or read in part 2 stay current until the env's goal stream moves
+        const bool rec_ok = (P.auto_reset || P.respawn) && !moved_stream;
+        P.ep_step[i] = (int32_t)(step | (rec_ok ? kRecValid : 0u));
         P.ep_ret[i] = ret;
+        P.ep_path[i] = path;
         P.rng_ctr[i] = ctr;
     }
     __syncthreads();  // barrier C: observation tile complete in LDS
@@ -770,6 +912,12 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
         float* o = reinterpret_cast<float*>(obs_out) + (size_t)base * D;
         for (int k = tid; k < n_out; k += kThreads) o[k] = sm.obs[(k / D) * DP + (k % D)];
     }
+}
+
+// clears kRecValid of every env: the cached next-episode records no longer match (tables / rectangles / counters changed)
+__global__ void invalidate_records_kernel(int32_t* __restrict__ ep_step, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) ep_step[i] = (int32_t)((uint32_t)ep_step[i] & kStepMask);
 }
 
 // (cos, sin)(yaw / 2) of the start poses: the orientation quaternion goal_angles() derives from a yaw, tabulated with
@@ -816,8 +964,9 @@ __global__ void reset_kernel(Params P, const uint8_t* __restrict__ mask, void* _
     P.x[i] = x; P.y[i] = y; P.th[i] = th;
     P.gx[i] = gx; P.gy[i] = gy; P.past_dist[i] = dist;
     P.past_action[i] = make_float2(0.f, 0.f);
-    P.ep_step[i] = 0;
+    P.ep_step[i] = 0;   // also clears kRecValid: the goal stream moved
     P.ep_ret[i] = 0;
+    P.ep_path[i] = 0;
     P.rng_ctr[i] = ctr;
 }
 
@@ -853,6 +1002,15 @@ __global__ void raycast_kernel(Params P, const double* __restrict__ pose, int n_
     }
 }
 
+// noise-free lidar entries of a reset observation from the nearest hits at the start pose (environment_new.py:192-198,:362)
+__global__ void spawn_obs_kernel(const float* __restrict__ best, int n, int below_min_mode, float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float r = sensor_value(best[k], 0.f, 0.f, below_min_mode);
+    if (r == INFINITY) r = 3.5f;
+    out[k] = r / 3.5f;
+}
+
 // ---------------------------------------------------------------- return scan (PPO.compute_rtgs)
 // thread = env column, reverse over T; loads are independent of the recurrence so they pipeline.
 __global__ void rtg_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ ended, int T, int N,
@@ -881,6 +1039,7 @@ struct navsim {
     Rects* rects_dev = nullptr;
     Rects rects_host;
     float* spawn_scan_dev = nullptr;
+    float* spawn_obs_dev = nullptr;
     double* starts_dev = nullptr;   // [K][3]
     double* starts_sc_dev = nullptr;  // [K][2]
     double* goals_dev = nullptr;    // [G][2]
@@ -890,31 +1049,25 @@ struct navsim {
 
 int g_epb = 16;  // envs per workgroup (NAVSIM_EPB = 8 | 16; tuning knob)
 
-template <int NB, int EPB>
-static void launch_step_epb(const navsim* h, const float* action, const float* past, void* obs, float* reward,
-                            uint8_t* done, uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len,
-                            hipStream_t st) {
-    const dim3 grid((h->P.N + EPB - 1) / EPB), block(kThreads);
+template <int NB>
+static void launch_step(const navsim* h, const float* action, const float* past, void* obs, float* reward, uint8_t* done,
+                        uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len, float* ep_path, hipStream_t st) {
     const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
-    auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, block, 0, st, h->P, (const float2*)action, (const float2*)past, obs, reward, done,
-                           arrive, ended, ep_ret, ep_len);
+    auto go = [&](auto kernel, int epb) {
+        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(kThreads), 0, st, h->P, (const float2*)action,
+                           (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len, ep_path);
     };
-    if (h->P.per_env) {
-        if (sens) go(step_kernel<NB, true, EPB, true>); else go(step_kernel<NB, true, EPB, false>);
+    if (g_epb == 8) {
+        if (sens) go(step_kernel<NB, 8, true>, 8); else go(step_kernel<NB, 8, false>, 8);
     } else {
-        if (sens) go(step_kernel<NB, false, EPB, true>); else go(step_kernel<NB, false, EPB, false>);
+        if (sens) go(step_kernel<NB, 16, true>, 16); else go(step_kernel<NB, 16, false>, 16);
     }
 }
 
-template <int NB>
-static void launch_step(const navsim* h, const float* action, const float* past, void* obs, float* reward,
-                        uint8_t* done, uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len,
-                        hipStream_t st) {
-    switch (g_epb) {
-        case 8: launch_step_epb<NB, 8>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
-        default: launch_step_epb<NB, 16>(h, action, past, obs, reward, done, arrive, ended, ep_ret, ep_len, st); break;
-    }
+static int invalidate_records(navsim* h, hipStream_t st) {
+    hipLaunchKernelGGL(invalidate_records_kernel, dim3((h->P.N + 255) / 256), dim3(256), 0, st, h->P.ep_step, h->P.N);
+    HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
 }
 
 // Uploads the start-pose table [K][3] and tabulates its half-angle (cos, sin) on the device.
@@ -943,18 +1096,24 @@ static int init_handle(navsim* h, const navsim_cfg* cfg) {
     h->cfg = *cfg;
     const size_t N = (size_t)cfg->n_envs;
     const int B = cfg->n_beams;
-    // one block: 7 f64 arrays, float2 past_action, i32 ep_step, u32 rng_ctr
-    const size_t bytes = N * (7 * sizeof(double) + sizeof(float2) + sizeof(int32_t) + sizeof(uint32_t));
+    // one block: 8 f64 state arrays + 6 + 2 f64 record arrays, 2 float4, float2 past_action, 2 uint2, i32 ep_step, 2 u32
+    const size_t bytes = N * (16 * sizeof(double) + 2 * sizeof(float4) + sizeof(float2) + 2 * sizeof(uint2) +
+                              sizeof(int32_t) + 2 * sizeof(uint32_t));
     HIP_TRY(hipMalloc(&h->state_block, bytes));
     HIP_TRY(hipMemset(h->state_block, 0, bytes));
     Params& P = h->P;
     std::memset(&P, 0, sizeof(P));
     double* d = reinterpret_cast<double*>(h->state_block);
     P.x = d; P.y = d + N; P.th = d + 2 * N; P.gx = d + 3 * N; P.gy = d + 4 * N;
-    P.past_dist = d + 5 * N; P.ep_ret = d + 6 * N;
-    P.past_action = reinterpret_cast<float2*>(d + 7 * N);
+    P.past_dist = d + 5 * N; P.ep_ret = d + 6 * N; P.ep_path = d + 7 * N;
+    P.rec_g = d + 8 * N; P.rsp_g = d + 14 * N;
+    P.rec_tail = reinterpret_cast<float4*>(d + 16 * N);   // 16-byte aligned: hipMalloc base + a multiple of 128 N bytes
+    P.rec_ck = reinterpret_cast<uint2*>(P.rec_tail + 2 * N);
+    P.past_action = reinterpret_cast<float2*>(P.rec_ck + 2 * N);
     P.ep_step = reinterpret_cast<int32_t*>(P.past_action + N);
     P.rng_ctr = reinterpret_cast<uint32_t*>(P.ep_step + N);
+    P.rsp_ctr = P.rng_ctr + N;
+    P.seg_pack_log2 = 6;
     P.N = cfg->n_envs;
     P.B = B;
     P.max_ep_steps = cfg->max_episode_steps;
@@ -1050,6 +1209,7 @@ void navsim_destroy(navsim_t* h) {
     (void)hipFree(h->beam_cs_dev);
     (void)hipFree(h->rects_dev);
     (void)hipFree(h->spawn_scan_dev);
+    (void)hipFree(h->spawn_obs_dev);
     (void)hipFree(h->starts_dev);
     (void)hipFree(h->starts_sc_dev);
     (void)hipFree(h->goals_dev);
@@ -1063,6 +1223,9 @@ int navsim_set_goal_rects(navsim_t* h, int32_t which, const double* rects_host, 
     std::memcpy(h->rects_host.r[which], rects_host, sizeof(double) * 4 * n_rects);
     h->rects_host.n[which] = n_rects;
     HIP_TRY(hipMemcpy(h->rects_dev, &h->rects_host, sizeof(Rects), hipMemcpyHostToDevice));
+    const int rc = invalidate_records(h, nullptr);
+    if (rc != NAVSIM_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
     return NAVSIM_OK;
 }
 
@@ -1072,12 +1235,17 @@ static int rebuild_spawn_scans(navsim* h, hipStream_t st) {
     if (h->spawn_scan_dev) {
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipFree(h->spawn_scan_dev));
-        h->spawn_scan_dev = nullptr;
+        HIP_TRY(hipFree(h->spawn_obs_dev));
+        h->spawn_scan_dev = h->spawn_obs_dev = nullptr;
     }
     HIP_TRY(hipMalloc(&h->spawn_scan_dev, n_poses * P.B * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->spawn_obs_dev, n_poses * P.B * sizeof(float)));
     P.spawn_scan = h->spawn_scan_dev;
+    P.spawn_obs = h->spawn_obs_dev;
     hipLaunchKernelGGL(raycast_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, st, P, h->starts_dev, P.K, 1,
                        (int)n_poses, 1, h->spawn_scan_dev);
+    hipLaunchKernelGGL(spawn_obs_kernel, dim3((unsigned)((n_poses * P.B + 255) / 256)), dim3(256), 0, st, h->spawn_scan_dev,
+                       (int)(n_poses * P.B), P.below_min_mode, h->spawn_obs_dev);
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;
 }
@@ -1088,6 +1256,12 @@ int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_
     P.seg = reinterpret_cast<const float4*>(seg_dev);
     P.S = n_segments;
     P.per_env = per_env ? 1 : 0;
+    P.seg_pack_log2 = 6;
+    if (n_segments <= 32) {   // several envs share one 64-lane pass of the cast
+        int lg = 0;
+        while ((1 << lg) < n_segments) ++lg;
+        P.seg_pack_log2 = lg;
+    }
     const int rc = rebuild_spawn_scans(h, (hipStream_t)stream);
     if (rc != NAVSIM_OK) return rc;
     h->has_map = true;
@@ -1115,6 +1289,10 @@ int navsim_set_spawn_sampler(navsim_t* h, const double* starts_host, int32_t n_s
     P.G = n_goals;
     P.min_dist = min_dist;
     P.max_dist = max_dist;
+    {
+        const int rc = invalidate_records(h, st);
+        if (rc != NAVSIM_OK) return rc;
+    }
     if (h->has_map) return rebuild_spawn_scans(h, st);
     return NAVSIM_OK;
 }
@@ -1130,17 +1308,17 @@ int navsim_reset(navsim_t* h, const uint8_t* mask_dev, void* obs_dev, void* stre
 
 int navsim_step(navsim_t* h, const float* action_dev, const float* past_action_dev, void* obs_dev,
                 float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,
-                float* ep_return_dev, int32_t* ep_length_dev, void* stream) {
+                float* ep_return_dev, int32_t* ep_length_dev, float* ep_path_dev, void* stream) {
     if (!h || !action_dev || !obs_dev || !reward_dev || !done_dev || !arrive_dev)
         return fail(NAVSIM_E_ARG, "navsim_step: null required buffer");
     if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_step: call navsim_set_map first");
     hipStream_t st = (hipStream_t)stream;
     if (h->P.B == 10)
         launch_step<10>(h, action_dev, past_action_dev, obs_dev, reward_dev, done_dev, arrive_dev, ended_dev,
-                        ep_return_dev, ep_length_dev, st);
+                        ep_return_dev, ep_length_dev, ep_path_dev, st);
     else
         launch_step<36>(h, action_dev, past_action_dev, obs_dev, reward_dev, done_dev, arrive_dev, ended_dev,
-                        ep_return_dev, ep_length_dev, st);
+                        ep_return_dev, ep_length_dev, ep_path_dev, st);
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;
 }
@@ -1185,7 +1363,10 @@ int navsim_get_state(navsim_t* h, double* pose, double* goal, double* past_dist,
     }
     if (past_dist) HIP_TRY(hipMemcpy(past_dist, P.past_dist, sizeof(double) * N, hipMemcpyDeviceToHost));
     if (past_action) HIP_TRY(hipMemcpy(past_action, P.past_action, sizeof(float2) * N, hipMemcpyDeviceToHost));
-    if (ep_step) HIP_TRY(hipMemcpy(ep_step, P.ep_step, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    if (ep_step) {
+        HIP_TRY(hipMemcpy(ep_step, P.ep_step, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; ++i) ep_step[i] = (int32_t)((uint32_t)ep_step[i] & kStepMask);
+    }
     if (rng_ctr) HIP_TRY(hipMemcpy(rng_ctr, P.rng_ctr, sizeof(uint32_t) * N, hipMemcpyDeviceToHost));
     return NAVSIM_OK;
 }
@@ -1221,6 +1402,11 @@ int navsim_set_state(navsim_t* h, const double* pose, const double* goal, const 
     if (past_action) HIP_TRY(hipMemcpy(P.past_action, past_action, sizeof(float2) * N, hipMemcpyHostToDevice));
     if (ep_step) HIP_TRY(hipMemcpy(P.ep_step, ep_step, sizeof(int32_t) * N, hipMemcpyHostToDevice));
     if (rng_ctr) HIP_TRY(hipMemcpy(P.rng_ctr, rng_ctr, sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+    if (rng_ctr && !ep_step) {   // the goal stream moved: the cached next-episode records are stale (ep_step clears the flag itself)
+        const int rc = invalidate_records(h, (hipStream_t)stream);
+        if (rc != NAVSIM_OK) return rc;
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    }
     return NAVSIM_OK;
 }
 

@@ -81,7 +81,8 @@ class NavSim:
 
     def set_goal_rects(self, which, rects):
         r = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
-        check(lib().navsim_set_goal_rects(self._h, int(which), _np_ptr(r), r.shape[0]), "navsim_set_goal_rects")
+        with torch.cuda.device(self.device):   # the call synchronises the CURRENT device before touching the rectangles
+            check(lib().navsim_set_goal_rects(self._h, int(which), _np_ptr(r), r.shape[0]), "navsim_set_goal_rects")
 
     def set_spawn_sampler(self, starts, goals=None, min_dist=1.5, max_dist=6.0):
         """GoalSpawnSampler tables (spawn_goal_sampler.py:37-62): start poses [K,3], goal points [G,2] or None."""
@@ -101,7 +102,8 @@ class NavSim:
             arrive=torch.zeros(N, dtype=torch.uint8, device=dev),
             ended=torch.zeros(N, dtype=torch.uint8, device=dev),
             ep_return=torch.zeros(N, dtype=torch.float32, device=dev),
-            ep_length=torch.zeros(N, dtype=torch.int32, device=dev))
+            ep_length=torch.zeros(N, dtype=torch.int32, device=dev),
+            ep_path=torch.zeros(N, dtype=torch.float32, device=dev))
 
     # -- calls (all asynchronous on torch's current stream)
     def reset(self, obs, mask=None):
@@ -109,10 +111,12 @@ class NavSim:
             check(lib().navsim_reset(self._h, _ptr(mask), _ptr(obs), _stream()), "navsim_reset")
         return obs
 
-    def step(self, action, obs, reward, done, arrive, ended=None, ep_return=None, ep_length=None, past_action=None):
+    def step(self, action, obs, reward, done, arrive, ended=None, ep_return=None, ep_length=None, past_action=None,
+             ep_path=None):
         with torch.cuda.device(self.device):
             check(lib().navsim_step(self._h, _ptr(action), _ptr(past_action), _ptr(obs), _ptr(reward), _ptr(done),
-                                    _ptr(arrive), _ptr(ended), _ptr(ep_return), _ptr(ep_length), _stream()), "navsim_step")
+                                    _ptr(arrive), _ptr(ended), _ptr(ep_return), _ptr(ep_length), _ptr(ep_path), _stream()),
+                  "navsim_step")
 
     def raycast(self, pose):
         pose = pose.to(device=self.device, dtype=torch.float64).contiguous()
@@ -172,10 +176,10 @@ class VecEnv:
 
     def __init__(self, n_envs, map="stage_1", n_beams=10, max_episode_steps=500, auto_reset=True, is_training=True,
                  seed=0, env_id_base=0, per_env_map=False, map_seed=0, obs_f16=False, device=None, sampler=None,
-                 lidar_below_min="clamp", lidar_noise_sigma=0.0):
+                 lidar_below_min="clamp", lidar_noise_sigma=0.0, respawn_on_arrive=False):
         thr = 0.2 if is_training else 0.4  # environment_new.py:44-47
         self.sim = NavSim(n_envs, n_beams=n_beams, max_episode_steps=max_episode_steps, auto_reset=auto_reset,
-                          respawn_on_arrive=False, seed=seed, env_id_base=env_id_base, threshold_arrive=thr,
+                          respawn_on_arrive=respawn_on_arrive, seed=seed, env_id_base=env_id_base, threshold_arrive=thr,
                           obs_f16=obs_f16, device=device, lidar_below_min=lidar_below_min,
                           lidar_noise_sigma=lidar_noise_sigma)
         self.N, self.B, self.D, self.device = self.sim.N, self.sim.B, self.sim.D, self.sim.device
@@ -208,7 +212,7 @@ class VecEnv:
         `ep_return`, `ep_length` are in ``self.io`` (or the `io` passed in)."""
         io = io or self.io
         action = action.to(device=self.device, dtype=torch.float32).contiguous()
-        self.sim.step(action, io.obs, io.reward, io.done, io.arrive, io.ended, io.ep_return, io.ep_length)
+        self.sim.step(action, io.obs, io.reward, io.done, io.arrive, io.ended, io.ep_return, io.ep_length, ep_path=io.ep_path)
         return io.obs, io.reward, io.done, io.arrive
 
 

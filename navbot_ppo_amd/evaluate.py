@@ -5,7 +5,8 @@ DETERMINISTIC mean action (no sampling, main.py:197-199) and the evaluation arri
 (``is_training=False``, environment_new.py:44-47), and writes the reference's per-episode CSV
 ``<output_dir>/<method>/logs/<method>_eval_episodes.csv`` with its columns
 ``episode,success,collision,timeout,length,return,path_length,time`` (main.py:179) plus the summary it prints
-(main.py:236-250).  Episodes run ``n_parallel`` at a time; each env plays whole episodes back to back.
+(main.py:236-250).  Episodes run ``n_parallel`` at a time; each env plays a fixed quota of whole episodes back to back; the
+``time`` column is the episode's share of the wall clock (length x mean step time).
 
 (The reference's own loop crashes on its first step -- it feeds a (1,2) action so ``action[1]`` raises, SURVEY A3#8;
 this implements the intended behaviour.)
@@ -40,39 +41,46 @@ def load_actor(path, device):
 @torch.no_grad()
 def evaluate(actor, num_episodes=100, max_timesteps_per_episode=500, map="stage_1", n_parallel=None, seed=0, device=None,
              output_dir="", method_name="baseline", log=print):
+    """Every env plays a FIXED quota of q = ceil(num_episodes / n_parallel) whole episodes (its first q; later ones are
+    ignored) and stepping continues until every env has met it, so which episodes are reported does not depend on how
+    long they last -- taking "the first num_episodes to finish" would over-sample short episodes (early collisions) and
+    under-report timeouts.  Rows are ordered episode-slot-major (slot 0 of every env, then slot 1, ...) and cut to
+    num_episodes.  Everything stays on the device; the host looks at a counter every 16 steps."""
     n_par = int(n_parallel or min(num_episodes, 1024))
+    quota = -(-int(num_episodes) // n_par)
     env = VecEnv(n_par, map=map, max_episode_steps=max_timesteps_per_episode, auto_reset=True, is_training=False, seed=seed,
                  device=device)
     dev = env.device
     actor = actor.to(dev).eval()
     obs = env.reset()
-    pos_prev = torch.from_numpy(env.sim.get_state()["pose"][:, :2]).to(dev)
-    path_len = torch.zeros(n_par, dtype=torch.float64, device=dev)
-    rows, t_ep = [], time.time()
-    started = torch.full((n_par,), t_ep, dtype=torch.float64)
-    while len(rows) < num_episodes:
+    count = torch.zeros(n_par, dtype=torch.int64, device=dev)
+    res = torch.zeros((quota, n_par, 6), dtype=torch.float64, device=dev)   # success, collision, timeout, length, return, path
+    env_ids = torch.arange(n_par, device=dev)
+    t0, steps = time.time(), 0
+    max_steps = quota * max_timesteps_per_episode + 1
+    while steps < max_steps:
         action = actor(obs.float())                                   # deterministic mean action, main.py:197-199
         obs, rew, done, arrive = env.step(action)
-        ended = env.io.ended.bool()
-        pose = torch.from_numpy(env.sim.get_state()["pose"][:, :2]).to(dev)  # post-reset pose for ended envs
-        step_len = (pose - pos_prev).norm(dim=1)
-        path_len += torch.where(ended, torch.zeros_like(step_len), step_len)  # the terminal step's move is not observed
-        pos_prev = pose
-        if ended.any():
-            now = time.time()
-            idx = torch.nonzero(ended).flatten().tolist()
-            d, a = done.cpu().numpy(), arrive.cpu().numpy()
-            ln, rt = env.io.ep_length.cpu().numpy(), env.io.ep_return.cpu().numpy()
-            for i in idx:
-                if len(rows) >= num_episodes:
-                    break
-                succ = int(a[i])
-                coll = int(d[i] and not a[i])
-                tmo = int((not d[i]) and (not a[i]) and ln[i] >= max_timesteps_per_episode)     # main.py:214-216
-                rows.append([len(rows), succ, coll, tmo, int(ln[i]), float(rt[i]), float(path_len[i]), now - float(started[i])])
-                path_len[i] = 0.0
-                started[i] = now
+        io = env.io
+        take = io.ended.bool() & (count < quota)
+        a, d = arrive.bool(), done.bool()
+        ln = io.ep_length.double()
+        row = torch.stack([a.double(), (d & ~a).double(),
+                           (~d & ~a & (io.ep_length >= max_timesteps_per_episode)).double(),      # main.py:214-216
+                           ln, io.ep_return.double(), io.ep_path.double()], 1)                    # path: main.py:200-204
+        slot = torch.clamp(count, max=quota - 1)
+        cur = res[slot, env_ids]
+        res[slot, env_ids] = torch.where(take[:, None], row, cur)
+        count += take.long()
+        steps += 1
+        if steps % 16 == 0 and bool((count >= quota).all()):
+            break
+    torch.cuda.synchronize(dev)
+    sec_per_step = (time.time() - t0) / max(steps, 1)
     env.close()
+    flat = res.reshape(quota * n_par, 6)[:num_episodes].cpu().numpy()
+    rows = [[k, int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(r[4]), float(r[5]), float(r[3]) * sec_per_step]
+            for k, r in enumerate(flat)]
     arr = np.array([r[1:] for r in rows], dtype=np.float64)
     summary = dict(episodes=len(rows), success_rate=arr[:, 0].mean(), collision_rate=arr[:, 1].mean(), timeout_rate=arr[:, 2].mean(),
                    mean_length=arr[:, 3].mean(), std_length=arr[:, 3].std(), mean_return=arr[:, 4].mean(), std_return=arr[:, 4].std(),

@@ -283,6 +283,7 @@ typedef struct orc_sim {
     int32_t* ep_step;
     uint32_t* rng_ctr;
     double *ep_ret; /* running episode return */
+    double *ep_path; /* running episode path length, ppo.py:533-537 */
     double* beam_cos; /* cos/sin of the beam angle relative to heading */
     double* beam_sin;
     double reset_rects[16][4];
@@ -306,6 +307,7 @@ ORC_API orc_sim* orc_sim_create(const orc_cfg* cfg) {
     s->gy = calloc(N, sizeof(double));
     s->past_dist = calloc(N, sizeof(double));
     s->ep_ret = calloc(N, sizeof(double));
+    s->ep_path = calloc(N, sizeof(double));
     s->past_action = calloc(2 * (size_t)N, sizeof(float));
     s->ep_step = calloc(N, sizeof(int32_t));
     s->rng_ctr = calloc(N, sizeof(uint32_t));
@@ -348,7 +350,7 @@ ORC_API int orc_sim_set_spawn_sampler(orc_sim* s, const double* starts, int K, c
 ORC_API void orc_sim_destroy(orc_sim* s) {
     if (!s) return;
     free(s->seg); free(s->x); free(s->y); free(s->th); free(s->gx); free(s->gy);
-    free(s->past_dist); free(s->ep_ret); free(s->past_action); free(s->ep_step);
+    free(s->past_dist); free(s->ep_ret); free(s->ep_path); free(s->past_action); free(s->ep_step);
     free(s->rng_ctr); free(s->beam_cos); free(s->beam_sin); free(s->starts); free(s->goals);
     free(s);
 }
@@ -555,6 +557,7 @@ static void reset_env(orc_sim* s, int i, float* obs_row, int use_key, uint32_t n
     s->th[i] = s->starts[3 * k + 2];
     s->ep_step[i] = 0;
     s->ep_ret[i] = 0;
+    s->ep_path[i] = 0;
     s->past_action[2 * i] = 0;
     s->past_action[2 * i + 1] = 0;
     double zero[2] = {0, 0};
@@ -576,7 +579,7 @@ ORC_API void orc_sim_reset(orc_sim* s, const uint8_t* mask, float* obs) {
  * ended / ep_return / ep_length nullable. */
 ORC_API void orc_sim_step(orc_sim* s, const float* action, const float* past_action_override,
                           float* obs, float* reward, uint8_t* done, uint8_t* arrive, uint8_t* ended,
-                          float* ep_return, int32_t* ep_length) {
+                          float* ep_return, int32_t* ep_length, float* ep_path) {
     const orc_cfg* c = &s->cfg;
     int N = c->n_envs, D = c->n_beams + 6;
     for (int i = 0; i < N; ++i) {
@@ -594,6 +597,7 @@ ORC_API void orc_sim_step(orc_sim* s, const float* action, const float* past_act
         /* :154-155 */
         double delta_s = WHEEL_RADIUS * (wheel_r + wheel_l) / 2.0;
         double delta_theta = WHEEL_RADIUS * (wheel_r - wheel_l) / WHEEL_SEP;
+        const double x_old = s->x[i], y_old = s->y[i];
         for (int k = 0; k < SUBSTEPS; ++k) { /* :158-160 */
             s->x[i] += delta_s * cos(s->th[i] + (delta_theta / 2.0));
             s->y[i] += delta_s * sin(s->th[i] + (delta_theta / 2.0));
@@ -627,6 +631,13 @@ ORC_API void orc_sim_step(orc_sim* s, const float* action, const float* past_act
         if (end) {
             if (ep_return) ep_return[i] = (float)s->ep_ret[i];
             if (ep_length) ep_length[i] = s->ep_step[i];
+            /* ppo.py:533-537: the path grows by |curr_pos - prev_pos| with positions read BEFORE each step, so the
+             * displacement of the episode's last step is never added */
+            if (ep_path) ep_path[i] = (float)s->ep_path[i];
+        }
+        {
+            const double mx = s->x[i] - x_old, my = s->y[i] - y_old;
+            s->ep_path[i] += sqrt(mx * mx + my * my); /* np.linalg.norm */
         }
         s->past_action[2 * i] = action[2 * i]; /* ppo.py:543 */
         s->past_action[2 * i + 1] = action[2 * i + 1];

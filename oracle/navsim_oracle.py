@@ -87,7 +87,7 @@ def lib():
         L.orc_sim_reset.restype = None
         L.orc_sim_reset.argtypes = [vp, vp, vp]
         L.orc_sim_step.restype = None
-        L.orc_sim_step.argtypes = [vp] * 10
+        L.orc_sim_step.argtypes = [vp] * 11
         _lib = L
     return _lib
 
@@ -237,5 +237,8 @@ class OracleSim:
         ended = np.zeros(self.N, np.uint8)
         ep_ret = np.zeros(self.N, np.float32)
         ep_len = np.zeros(self.N, np.int32)
-        lib().orc_sim_step(self._h, _p(a), _p(pa), _p(obs), _p(rew), _p(done), _p(arrive), _p(ended), _p(ep_ret), _p(ep_len))
-        return dict(obs=obs, reward=rew, done=done, arrive=arrive, ended=ended, ep_return=ep_ret, ep_length=ep_len)
+        ep_path = np.zeros(self.N, np.float32)
+        lib().orc_sim_step(self._h, _p(a), _p(pa), _p(obs), _p(rew), _p(done), _p(arrive), _p(ended), _p(ep_ret), _p(ep_len),
+                           _p(ep_path))
+        return dict(obs=obs, reward=rew, done=done, arrive=arrive, ended=ended, ep_return=ep_ret, ep_length=ep_len,
+                    ep_path=ep_path)

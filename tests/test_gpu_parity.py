@@ -49,7 +49,7 @@ def _lockstep(gpu, cpu, actions, check_state_every=25):
     stats = dict(done=0, arrive=0, ended=0, exact_obs=0, total=0)
     for k in range(actions.shape[0]):
         a = torch.from_numpy(actions[k]).to(gpu.device)
-        gpu.step(a, io.obs, io.reward, io.done, io.arrive, io.ended, io.ep_return, io.ep_length)
+        gpu.step(a, io.obs, io.reward, io.done, io.arrive, io.ended, io.ep_return, io.ep_length, ep_path=io.ep_path)
         out = cpu.step(actions[k])
         og = io.obs.float().cpu().numpy()
         np.testing.assert_array_equal(io.done.cpu().numpy(), out["done"], err_msg=f"done, step {k}")
@@ -60,6 +60,7 @@ def _lockstep(gpu, cpu, actions, check_state_every=25):
         e = out["ended"].astype(bool)
         np.testing.assert_array_equal(io.ep_length.cpu().numpy()[e], out["ep_length"][e])
         np.testing.assert_allclose(io.ep_return.cpu().numpy()[e], out["ep_return"][e], rtol=REW_RTOL, atol=1e-4)
+        np.testing.assert_allclose(io.ep_path.cpu().numpy()[e], out["ep_path"][e], rtol=1e-6, atol=1e-7)
         stats["done"] += int(out["done"].sum())
         stats["arrive"] += int(out["arrive"].sum())
         stats["ended"] += int(e.sum())
@@ -574,3 +575,57 @@ def test_sensor_options_parity_noise_and_gazebo_below_min():
     fin = np.isfinite(out["obs"])
     np.testing.assert_allclose(og[fin], out["obs"][fin], atol=OBS_ATOL)
     np.testing.assert_array_equal(io.done.cpu().numpy(), out["done"])
+
+
+def test_cull_is_conservative_on_segment_soups():
+    """The cast only tests segments that survive a range / behind-the-fan cull; whatever the geometry, the scan must keep
+    the oracle's bits.  Random soups: long, short and degenerate segments, some through or next to the robots' paths (the
+    sim is kinematic: nothing stops a robot from crossing a segment the beams miss)."""
+    rng = np.random.default_rng(77)
+    for S, B in ((48, 10), (200, 10), (90, 36), (7, 10)):
+        N = 160
+        c = rng.uniform(-3.0, 3.0, (N, S, 2))
+        ln = rng.choice([1e-4, 0.02, 0.4, 3.0, 9.0], (N, S, 1))
+        d = rng.normal(size=(N, S, 2))
+        seg = np.concatenate([c - d * ln / 2, c + d * ln / 2], 2).astype(np.float32)
+        seg[:, 0] = [0.05, -1.0, 0.05, 1.0]          # a wall 5 cm ahead of the spawn pose: robots drive through it
+        seg[:, 1 % S] = [-0.032, 0.0, 2.0, 0.0]      # starts exactly at the sensor origin of the spawn pose
+        seg[:, 2 % S] = [1.0, 1.0, 1.0, 1.0]         # zero length
+        gpu, cpu = _mk(N, seg, per_env=True, B=B, max_episode_steps=25, auto_reset=True, seed=3)
+        for s in (gpu, cpu):
+            s.set_goal_rects(0, np.zeros((0, 4)))
+            s.set_goal_rects(1, np.zeros((0, 4)))
+        a = _actions(rng, 60, N)
+        a[..., 0] = np.maximum(a[..., 0], 0.6)
+        st = _lockstep(gpu, cpu, a)
+        assert st["exact_obs"] > 0.98 * st["total"]
+        # shared-map form of the same soup (env 0's)
+        gpu, cpu = _mk(N, seg[0], per_env=False, B=B, max_episode_steps=25, auto_reset=True, seed=4)
+        _lockstep(gpu, cpu, a[:30])
+
+
+def test_g10_reference_rollout_through_the_kernel():
+    """a-8: the reference's PPO.rollout + compute_rtgs over its own Env (G10) replayed on NavSim(1, auto_reset,
+    respawn_on_arrive) + navsim_rtg_scan: store-obs-before-act order, past_action rule, termination, reset obs, trailing
+    partial episode, batch_lens / t_so_far accounting, returns (ppo.py:463-671)."""
+    from navbot_ppo_amd.env import NavSim, rtg_scan
+    from test_rollout_golden_cpu import check_against_g10, replay_on
+    d = np.load(os.path.join(G, "g10_rollout.npz"))
+    sim = NavSim(1, max_episode_steps=int(d["cap"]), auto_reset=True, respawn_on_arrive=True, seed=int(d["seed"]))
+    sim.set_map(maps.stage_1())
+    io = sim.alloc_io()
+
+    class Adapter:
+        def reset(self):
+            return sim.reset(io.obs).cpu().numpy()
+
+        def step(self, a):
+            sim.step(torch.from_numpy(a).cuda(), io.obs, io.reward, io.done, io.arrive, io.ended, io.ep_return, io.ep_length,
+                     ep_path=io.ep_path)
+            return {k: getattr(io, k).cpu().numpy() for k in ("obs", "reward", "done", "arrive", "ended", "ep_return", "ep_length", "ep_path")}
+
+    obs, rew, ended, flags, eplen, epret, eppath = replay_on(Adapter(), d)
+    rtg = rtg_scan(torch.from_numpy(rew[:, None].copy()).cuda(), torch.from_numpy(ended[:, None].copy()).cuda(),
+                   float(d["gamma"])).cpu().numpy()[:, 0]
+    check_against_g10(d, obs, rew, ended, flags, eplen, epret, eppath, rtg)
+    assert int(sim.get_state()["rng_ctr"][0]) == int(d["rng_ctr_final"])

@@ -21,6 +21,7 @@ def replay_on(sim, d):
     flags = np.zeros((T, 2), np.uint8)
     eplen = np.zeros(T, np.int32)
     epret = np.zeros(T, np.float32)
+    eppath = np.zeros(T, np.float32)
     o = sim.reset()
     for t in range(T):
         obs[t] = o[0]                                  # ppo.py:508: the obs is stored BEFORE acting
@@ -28,11 +29,11 @@ def replay_on(sim, d):
         o = out["obs"]                                 # post-reset obs when the episode ended (ppo.py:593)
         rew[t], ended[t] = out["reward"][0], out["ended"][0]
         flags[t] = out["done"][0], out["arrive"][0]
-        eplen[t], epret[t] = out["ep_length"][0], out["ep_return"][0]
-    return obs, rew, ended, flags, eplen, epret
+        eplen[t], epret[t], eppath[t] = out["ep_length"][0], out["ep_return"][0], out["ep_path"][0]
+    return obs, rew, ended, flags, eplen, epret, eppath
 
 
-def check_against_g10(d, obs, rew, ended, flags, eplen, epret, rtg):
+def check_against_g10(d, obs, rew, ended, flags, eplen, epret, eppath, rtg):
     np.testing.assert_allclose(obs, d["batch_obs"], atol=1e-6, rtol=0)          # store-before-act order, reset obs, past_action rule
     np.testing.assert_allclose(rew, d["rews"].astype(np.float32), rtol=1e-5, atol=1e-5)
     ends = np.nonzero(ended)[0]
@@ -48,6 +49,7 @@ def check_against_g10(d, obs, rew, ended, flags, eplen, epret, rtg):
     np.testing.assert_array_equal(tmo, d["ep_timeout"].astype(bool))
     np.testing.assert_array_equal([succ.sum(), coll.sum(), tmo.sum(), len(ends)], d["iter_counts"])
     np.testing.assert_allclose(epret[ends], d["ep_ep_return"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(eppath[ends], d["ep_path_length"], rtol=1e-5, atol=1e-6)             # ppo.py:533-537
     np.testing.assert_allclose(epret[ends] / lens, d["episode_rewards_log"], rtol=1e-5, atol=1e-5)   # ppo.py:586
     np.testing.assert_array_equal(ends + 1, d["ep_timestep"].astype(np.int64))   # t_so_far + sum(batch_lens) + one_round, :564
     # returns: every episode end AND the batch end restart the scan at 0 (ppo.py:658-666); f64 accumulate, f32 store
@@ -59,9 +61,9 @@ def test_g10_reference_rollout_vs_oracle():
     assert d["ep_success"].sum() >= 1 and d["ep_collision"].sum() >= 1 and d["ep_timeout"].sum() >= 1
     sim = O.OracleSim(1, max_episode_steps=int(d["cap"]), auto_reset=True, respawn_on_arrive=True, seed=int(d["seed"]))
     sim.set_map(maps.stage_1())
-    obs, rew, ended, flags, eplen, epret = replay_on(sim, d)
+    obs, rew, ended, flags, eplen, epret, eppath = replay_on(sim, d)
     rtg = O.compute_rtgs_tn(rew[:, None], ended[:, None], float(d["gamma"]))[:, 0]
-    check_against_g10(d, obs, rew, ended, flags, eplen, epret, rtg)
+    check_against_g10(d, obs, rew, ended, flags, eplen, epret, eppath, rtg)
     assert int(sim.get_state()["rng_ctr"][0]) == int(d["rng_ctr_final"])         # same number of goal draws as the reference made
     # stored actions / log-probs are the tape itself (ppo.py:546-547)
     np.testing.assert_array_equal(d["batch_acts"], d["acts_tape"])

@@ -19,7 +19,7 @@ rep("    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motio
 rep("    __syncthreads();  // barrier A:", "    STAMP(1);\n    __syncthreads();  STAMP(2); // barrier A:")
 rep("    __syncthreads();  // barrier B:", "    STAMP(3);\n    __syncthreads();  STAMP(4); // barrier B:")
 rep("    __syncthreads();  // barrier C:", "    STAMP(5);\n    __syncthreads();  STAMP(6); // barrier C:")
-idx = t.index("// ---------------------------------------------------------------- reset (Env.reset, masked)")
+idx = t.index("// clears kRecValid of every env")
 j = t.rfind("}\n\n", 0, idx)
 t = t[:j] + "    STAMP(7);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk[blockIdx.x * 3 + 1] = wall_clock64();\n" + t[j:]
 rep("int navsim_version(void) { return NAVSIM_ABI_VERSION; }",
@@ -31,7 +31,7 @@ if "--lb4" in extra_flags:
 os.makedirs(os.path.join(R, "build"), exist_ok=True)
 open("/tmp/navsim_timing.hip", "w").write(t)
 out = os.path.join(R, "build", "libnavsim_timing.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
                        "-fvisibility=hidden", "-I", os.path.join(R, "include"), "/tmp/navsim_timing.hip",
                        os.path.join(R, "navbot_ppo_amd/csrc/ppo_mlp64.hip"), "-o", out])
 print(out)
