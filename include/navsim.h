@@ -163,6 +163,25 @@ int navsim_set_state(navsim_t* h, const double* pose_host, const double* goal_ho
 int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, int32_t N, double gamma,
                     float* out_dev, void* stream);
 
+/*
+ * The hot loop of PPO.rollout (project_ppo/src/ppo.py:505-594) for the 16-64-64 policy, all n_steps steps in ONE launch:
+ * per step PPO.get_action (ppo.py:673-706; what navppo_mlp64_act computes, include/navppo.h) followed by what navsim_step
+ * computes, for every env, with the rows of step t written at offset t * N of each [n_steps, N, .] buffer.  A workgroup
+ * keeps its envs for the whole rollout, so there is no kernel boundary and no observation round trip between steps; the
+ * results are bit-identical to n_steps pairs of navppo_mlp64_act / navsim_step calls with the same seeds.
+ *   actor_params_dev [5378] f32  the actor in the layout of navppo.h
+ *   obs_buf_dev  [n_steps + 1, N, 16] f32   row 0 in: the observations the rollout starts from (navsim_reset); rows 1.. out
+ *   act_buf_dev  [n_steps, N, 2]   logp_buf_dev [n_steps, N]   reward_dev [n_steps, N]   done / arrive / ended [n_steps, N] u8
+ *   ep_return_dev / ep_length_dev / ep_path_dev  [n_steps, N], nullable, written where ended (as in navsim_step)
+ *   var_dev  device scalar: exploration variance (ppo.py:123-124)
+ *   act_seed, step_base_dev (device scalar, nullable = 0): action noise = Philox(act_seed, env id, *step_base_dev + t)
+ * Needs n_beams == 10 and float32 observations.
+ */
+int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_buf_dev, float* act_buf_dev,
+                         float* logp_buf_dev, float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,
+                         float* ep_return_dev, int32_t* ep_length_dev, float* ep_path_dev, const float* var_dev,
+                         uint64_t act_seed, const uint32_t* step_base_dev, int32_t n_steps, void* stream);
+
 /* LiDAR only (no state change): ranges_dev [N,B] f32 raw scan (inf = no return) for poses
  * pose_dev [N,3] f64.  Used by tests and by map tooling (spawn_goal_sampler-style validation). */
 int navsim_raycast(navsim_t* h, const double* pose_dev, float* ranges_dev, void* stream);

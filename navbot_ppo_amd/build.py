@@ -28,7 +28,8 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in SRCS + [os.path.join(INC, h) for h in HDRS])
+    deps = SRCS + [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", "mlp64_policy.h")]
+    return any(os.path.getmtime(p) > t for p in deps)
 
 
 def build_native(force=False, verbose=False):

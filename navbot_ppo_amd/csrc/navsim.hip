@@ -36,6 +36,7 @@
 #include <string>
 
 #include "navsim.h"
+#include "mlp64_policy.h"
 
 namespace {
 
@@ -291,7 +292,7 @@ __device__ __forceinline__ void sample_episode(const Params& P, int i, uint32_t&
 constexpr uint32_t kRecValid = 0x40000000u;   // bit of the ep_step word: the cached next-episode records of this env are current
 constexpr uint32_t kStepMask = 0x3FFFFFFFu;
 
-template <int NB, int EPB>
+template <int NB, int EPB, int NW = 4>
 struct StepSmem {
     float2 org[EPB];             // sensor origin per env
     float2 hd[EPB];              // heading (cos, sin) as float32: the cull only (never the ranges)
@@ -317,10 +318,11 @@ struct StepSmem {
     unsigned mn_bits[EPB];       // min over the sanitised scan as float bits, and whether a reading is negative (-inf, SENS)
     unsigned neg[EPB];
     // cast: per-wave queue of the segments that survive the cull (ring of 128)
-    float4 q4[4][128];
-    unsigned qe[4][128];
-    float4 r4[4][128];           // ... and of those whose angular extent holds at least one beam
-    unsigned re[4][128];
+    float4 q4[NW][128];
+    unsigned qe[NW][128];
+    float4 r4[NW][128];          // ... and of those whose angular extent holds at least one beam
+    unsigned re[NW][128];
+    float2 act_l[EPB];           // persistent rollout: the action the policy phase chose for this step
 };
 
 // Correctly rounded K / Dn for positive, normal-range operands (Dn in [2^-60, 2^20], K in {0} U [2^-60, 2^20]):
@@ -375,7 +377,7 @@ __device__ __forceinline__ float beam_coord(float x, float y, float two_inv_delt
     return fmaf(u * p, two_inv_delta, a_inv_delta);
 }
 
-constexpr int kThreads = 256;   // 4 waves.  (A workgroup reserves ceil(waves/4) slots on EVERY SIMD of its CU, so
+constexpr int kThreads4 = 256;  // 4 waves.  (A workgroup reserves ceil(waves/4) slots on EVERY SIMD of its CU, so
                                 // a 5-wave block costs as much residency as an 8-wave one: measured 1 block/CU.)
 
 // lidar part of an observation row (environment_new.py:289-294) from nearest hits `best` (stride `bstride`);
@@ -416,16 +418,17 @@ __device__ __forceinline__ float write_lidar(float* row, const float* best, int 
 //   barrier C
 //   all:     the EPB x (B+6) observation tile leaves LDS as one contiguous, fully coalesced store.
 // SENS = false compiles the sensor-fidelity options (range noise, -inf below range_min) out.
-template <int NB, int EPB, bool SENS>
-__global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* __restrict__ action,
-                                                        const float2* __restrict__ past_override,
-                                                        void* __restrict__ obs_out, float* __restrict__ reward,
-                                                        uint8_t* __restrict__ done, uint8_t* __restrict__ arrive,
-                                                        uint8_t* __restrict__ ended, float* __restrict__ ep_return,
-                                                        int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out) {
+// PERSIST: called once per step by the persistent rollout kernel; the action comes from the policy phase through LDS.
+// NW: waves per workgroup (4; the persistent rollout kernel, one workgroup per CU, runs 8 for a shorter cast).
+template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4>
+__device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>& sm, int& next_env,
+                                          const float2* __restrict__ action, const float2* __restrict__ past_override,
+                                          void* __restrict__ obs_out, float* __restrict__ reward,
+                                          uint8_t* __restrict__ done, uint8_t* __restrict__ arrive,
+                                          uint8_t* __restrict__ ended, float* __restrict__ ep_return,
+                                          int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out) {
     static_assert(EPB <= 64 && EPB >= 4 && NB % 2 == 0, "EPB / NB");
-    __shared__ StepSmem<NB, EPB> sm;
-    __shared__ int next_env;
+    constexpr int kThreads = 64 * NW;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             double delta_s = 0, delta_theta = 0, arg = 0, x_old = 0, y_old = 0;
             if (el_pose < nloc) {
                 th = P.th[i];
-                act = action[i];
+                act = PERSIST ? sm.act_l[el_pose] : action[i];
                 ctr = P.rng_ctr[i];
                 stepw = (uint32_t)P.ep_step[i];
                 if (rr == 0) {
@@ -560,7 +563,8 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
                 }
             }
         }
-        if (tid == 0) next_env = 4 - PW;  // the first work items are pre-assigned to the ray waves
+        // the ray waves' first three tiles are pre-assigned (requested before barrier A): 1, 2 or 3 items per ray wave
+        if (tid == 0) next_env = (NW - PW) * (ntiles == 1 ? 3 : (ntiles == 2 ? 2 : 1));
     }
     if (wave >= PW) {
         // ---------------- other waves, part 1: nothing here depends on the pose
@@ -569,12 +573,15 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             sm.mn_bits[tid - 64 * PW] = kInfBits;
             sm.neg[tid - 64 * PW] = 0u;
         }
-        p0 = Pos{wave - PW, 0};
+        // static positions k = 0, 1, 2 of ray wave r: item r + RW (k / ntiles), tile k % ntiles
+        constexpr int RW = NW - PW;
+        const int r = wave - PW;
+        p0 = Pos{r, 0};
+        p1 = (ntiles >= 2) ? Pos{r, 1} : Pos{r + RW, 0};
+        p2 = (ntiles >= 3) ? Pos{r, 2} : ((ntiles == 2) ? Pos{r + RW, 0} : Pos{r + 2 * RW, 0});
         ld(p0, g0, v0);
-        if (ntiles > 1) {
-            p1 = Pos{wave - PW, 1};
-            ld(p1, g1, v1);
-        }
+        ld(p1, g1, v1);
+        ld(p2, g2, v2);
     }
     __syncthreads();  // barrier A: origins / directions visible, work counter set
 
@@ -778,12 +785,9 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
             ld(p0, g0, v0);
             p1 = advance(p0);
             ld(p1, g1, v1);
-        } else if (ntiles == 1) {
-            p1 = advance(p0);
-            ld(p1, g1, v1);
+            p2 = advance(p1);
+            ld(p2, g2, v2);
         }
-        p2 = advance(p1);
-        ld(p2, g2, v2);
         // three tiles in flight; the slots take turns (a register rotation would have to wait for the load it moves)
         for (;;) {   // wave-uniform
             if (p0.it >= n_items) break;
@@ -911,6 +915,100 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params P, const float2* 
     } else {
         float* o = reinterpret_cast<float*>(obs_out) + (size_t)base * D;
         for (int k = tid; k < n_out; k += kThreads) o[k] = sm.obs[(k / D) * DP + (k % D)];
+    }
+}
+
+template <int NB, int EPB, bool SENS>
+__global__ __launch_bounds__(kThreads4) void step_kernel(Params P, const float2* __restrict__ action,
+                                                        const float2* __restrict__ past_override,
+                                                        void* __restrict__ obs_out, float* __restrict__ reward,
+                                                        uint8_t* __restrict__ done, uint8_t* __restrict__ arrive,
+                                                        uint8_t* __restrict__ ended, float* __restrict__ ep_return,
+                                                        int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out) {
+    __shared__ StepSmem<NB, EPB> sm;
+    __shared__ int next_env;
+    step_body<NB, EPB, SENS, false>(P, sm, next_env, action, past_override, obs_out, reward, done, arrive, ended, ep_return,
+                                    ep_length, ep_path_out);
+}
+
+// ---------------------------------------------------------------- the persistent rollout kernel (PPO.rollout, ppo.py:463-641)
+// All T steps of the rollout in ONE launch for the 16-64-64 policy: a workgroup owns its EPB envs for the whole rollout and
+// alternates   policy phase (wave 0: PPO.get_action of mlp64_policy.h on the observation tile in LDS -> action, log-prob)
+//              step phases  (step_body above: motion, cast, rules, auto-reset; the next observation tile lands in LDS)
+// with workgroup barriers only: no kernel boundary, no launch ramp and no observation round trip through HBM between the
+// 2 T phases.  Every row of the [T, N, .] buffers is written exactly as the per-step entry points would write it (same
+// device functions, same Philox keys), so the two paths produce the same bits.
+struct RolloutArgs {
+    const float* params;      // actor parameters (mlp64 layout)
+    float* obs_buf;           // [T + 1, N, 16]: row 0 = the reset observations (input), rows 1..T written here
+    float* act_buf;           // [T, N, 2]
+    float* logp_buf;          // [T, N]
+    float* reward;            // [T, N]
+    uint8_t *done, *arrive, *ended;   // [T, N]
+    float* ep_return;         // [T, N], nullable
+    int32_t* ep_length;       // [T, N], nullable
+    float* ep_path;           // [T, N], nullable
+    const float* var_ptr;     // device scalar: exploration variance
+    const uint32_t* step_base;   // device scalar, nullable: rollout steps taken before this launch (noise counter)
+    uint64_t seed;
+    int T;
+};
+
+template <int EPB, bool SENS, int NW>
+__global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs R) {
+    constexpr int NB = 10, D = NB + 6, DP = D + 1, kThreads = 64 * NW;
+    static_assert(D == mlp64::IN, "the 16-64-64 policy reads 16-wide observations");
+    __shared__ StepSmem<NB, EPB, NW> sm;
+    __shared__ int next_env;
+    __shared__ __attribute__((aligned(16))) float wts[mlp64::P_ACTOR + 2];   // the actor, staged once for all T steps
+    __shared__ float2 pol_z[4][16];   // policy phase: per-tile partial sums of the two output units
+    __shared__ float2 pol_eps[16];    // ... and the step's action noise
+    static_assert(NW >= 5 && EPB <= 16, "policy phase: waves 0-3 MFMA, wave 4 noise; one 16-env policy tile per workgroup");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = blockIdx.x * EPB;
+    const int nloc = min(EPB, P.N - base);
+    const size_t N = (size_t)P.N;
+    for (int k = tid; k < mlp64::P_ACTOR; k += kThreads) wts[k] = R.params[k];
+    for (int k = tid; k < nloc * D; k += kThreads) sm.obs[(k / D) * DP + (k % D)] = R.obs_buf[(size_t)base * D + k];
+    const uint32_t step0 = R.step_base ? *R.step_base : 0u;
+    const float var = *R.var_ptr;
+    __syncthreads();
+    for (int t = 0; t < R.T; ++t) {
+        const size_t tn = (size_t)t * N;
+        asm volatile("" ::: "memory");   // keeps the weight reads of the policy phase inside the loop (registers are scarce)
+        // ---------------- policy phase (mlp64_policy.h): waves 0-3 each compute layer 1 and one 16-row tile of layer 2 with
+        // its share of the two output units; wave 4 draws the step's action noise meanwhile; wave 0 then finishes.
+        if (wave < 4) {
+            const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]
+            const bool valid = e < nloc;
+            const float* row = sm.obs + min(e, nloc - 1) * DP + 4 * kk;
+            const float4 xq = valid ? make_float4(row[0], row[1], row[2], row[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            mlp64::f32x4 c1[4];
+            mlp64::policy_hidden1(wts, xq, lane, c1);
+            float pz3, pz4;
+            mlp64::policy_tile2(wts, c1, lane, wave, pz3, pz4);
+            if (kk == 0) pol_z[wave][e] = make_float2(pz3, pz4);
+        } else if (wave == 4 && lane < nloc) {
+            float e0, e1;
+            mlp64::policy_noise(step0 + (uint32_t)t, R.seed, P.env_id_base + (uint64_t)(base + lane), e0, e1);
+            pol_eps[lane] = make_float2(e0, e1);
+        }
+        __syncthreads();
+        if (wave == 0 && lane < nloc) {
+            const int e = lane;
+            const float pz3[4] = {pol_z[0][e].x, pol_z[1][e].x, pol_z[2][e].x, pol_z[3][e].x};
+            const float pz4[4] = {pol_z[0][e].y, pol_z[1][e].y, pol_z[2][e].y, pol_z[3][e].y};
+            const float2 eps = pol_eps[e];
+            const mlp64::PolicyOut o = mlp64::policy_finish(wts, pz3, pz4, var, eps.x, eps.y);
+            sm.act_l[e] = make_float2(o.a0, o.a1);
+            reinterpret_cast<float2*>(R.act_buf)[tn + base + e] = make_float2(o.a0, o.a1);
+            R.logp_buf[tn + base + e] = o.logp;
+        }
+        __syncthreads();
+        step_body<NB, EPB, SENS, true, NW>(P, sm, next_env, nullptr, nullptr, R.obs_buf + (tn + N) * D, R.reward + tn, R.done + tn,
+                                       R.arrive + tn, R.ended + tn, R.ep_return ? R.ep_return + tn : nullptr,
+                                       R.ep_length ? R.ep_length + tn : nullptr, R.ep_path ? R.ep_path + tn : nullptr);
+        // the observation tile of step t + 1 is in sm.obs; its store only reads it, like the next policy phase
     }
 }
 
@@ -1054,7 +1152,7 @@ static void launch_step(const navsim* h, const float* action, const float* past,
                         uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len, float* ep_path, hipStream_t st) {
     const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
     auto go = [&](auto kernel, int epb) {
-        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(kThreads), 0, st, h->P, (const float2*)action,
+        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(kThreads4), 0, st, h->P, (const float2*)action,
                            (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len, ep_path);
     };
     if (g_epb == 8) {
@@ -1319,6 +1417,41 @@ int navsim_step(navsim_t* h, const float* action_dev, const float* past_action_d
     else
         launch_step<36>(h, action_dev, past_action_dev, obs_dev, reward_dev, done_dev, arrive_dev, ended_dev,
                         ep_return_dev, ep_length_dev, ep_path_dev, st);
+    HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
+}
+
+int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_buf_dev, float* act_buf_dev,
+                         float* logp_buf_dev, float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,
+                         float* ep_return_dev, int32_t* ep_length_dev, float* ep_path_dev, const float* var_dev,
+                         uint64_t act_seed, const uint32_t* step_base_dev, int32_t n_steps, void* stream) {
+    if (!h || !actor_params_dev || !obs_buf_dev || !act_buf_dev || !logp_buf_dev || !reward_dev || !done_dev || !arrive_dev ||
+        !ended_dev || !var_dev || n_steps < 0)
+        return fail(NAVSIM_E_ARG, "navsim_rollout_mlp64: bad argument");
+    if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_rollout_mlp64: call navsim_set_map first");
+    if (h->P.B != 10 || h->P.obs_f16)
+        return fail(NAVSIM_E_ARG, "navsim_rollout_mlp64: the 16-64-64 policy needs 10 beams and float32 observations");
+    if (((uintptr_t)actor_params_dev & 15) || ((uintptr_t)act_buf_dev & 7))
+        return fail(NAVSIM_E_ARG, "navsim_rollout_mlp64: params must be 16-byte and act 8-byte aligned");
+    if (n_steps == 0) return NAVSIM_OK;
+    RolloutArgs R;
+    R.params = actor_params_dev; R.obs_buf = obs_buf_dev; R.act_buf = act_buf_dev; R.logp_buf = logp_buf_dev;
+    R.reward = reward_dev; R.done = done_dev; R.arrive = arrive_dev; R.ended = ended_dev; R.ep_return = ep_return_dev;
+    R.ep_length = ep_length_dev; R.ep_path = ep_path_dev; R.var_ptr = var_dev; R.step_base = step_base_dev;
+    R.seed = act_seed; R.T = n_steps;
+    const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
+    const int epb = (g_epb == 8) ? 8 : 16;
+    // 8 waves per workgroup: a workgroup is one latency chain per step, more ray waves shorten its cast
+    constexpr int kRollWaves = 8;
+    const dim3 grid((h->P.N + epb - 1) / epb), block(64 * kRollWaves);
+    hipStream_t st = (hipStream_t)stream;
+    if (epb == 8) {
+        if (sens) hipLaunchKernelGGL((rollout_kernel<8, true, kRollWaves>), grid, block, 0, st, h->P, R);
+        else hipLaunchKernelGGL((rollout_kernel<8, false, kRollWaves>), grid, block, 0, st, h->P, R);
+    } else {
+        if (sens) hipLaunchKernelGGL((rollout_kernel<16, true, kRollWaves>), grid, block, 0, st, h->P, R);
+        else hipLaunchKernelGGL((rollout_kernel<16, false, kRollWaves>), grid, block, 0, st, h->P, R);
+    }
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;
 }

@@ -32,21 +32,15 @@
 #include <string>
 
 #include "navppo.h"
+#include "mlp64_policy.h"
 
 namespace {
 
+using namespace mlp64;
+static_assert(P_ACTOR == NAVPPO_MLP64_ACTOR_PARAMS && P_CRITIC == NAVPPO_MLP64_CRITIC_PARAMS, "layout");
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int H = 64;      // hidden width
-constexpr int IN = 16;     // observation width
-
-// flat parameter layout of one net (nn.Module.named_parameters order: layer1.weight, layer1.bias, layer2.weight,
-// layer2.bias, layer3.weight, layer3.bias [, layer4.weight, layer4.bias])
-constexpr int OFF_W1 = 0, OFF_B1 = OFF_W1 + H * IN, OFF_W2 = OFF_B1 + H, OFF_B2 = OFF_W2 + H * H, OFF_W3 = OFF_B2 + H,
-              OFF_B3 = OFF_W3 + H, OFF_W4 = OFF_B3 + 1, OFF_B4 = OFF_W4 + H;
-constexpr int P_ACTOR = OFF_B4 + 1;   // 5378
-constexpr int P_CRITIC = OFF_B3 + 1;  // 5313
-static_assert(P_ACTOR == NAVPPO_MLP64_ACTOR_PARAMS && P_CRITIC == NAVPPO_MLP64_CRITIC_PARAMS, "layout");
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -72,7 +66,6 @@ __device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r 
 //   pass through three 32x32 wave-private LDS tiles and come back as k-contiguous ds_read_b128 operands; the same
 //   operand registers give db2 / db1, and one more tile round trip of H2^T gives dW3 / dW4.
 // LDS: W1 5 KB + W2 and W2^T 17 KB each + vectors 1 KB + 8 x 13.75 KB wave tiles = 150 KB -> one workgroup per CU.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int LW1 = 20;                   // row strides (floats): 16-byte aligned rows, conflict-free ds_read_b128
 constexpr int LW2 = 68;
 constexpr int LT = 36;
@@ -93,9 +86,6 @@ static_assert(sizeof(SmemW) <= 160 * 1024, "LDS");
 static_assert(kWWaves * WAVE_F >= P_ACTOR + 4, "reduction buffer");
 
 __device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-// relu as an integer max on the bit pattern: negative floats (sign bit set, incl. -0) -> +0, positive unchanged.
-// One v_max_i32 instead of the canonicalise + v_max_f32 pair the compiler emits for fmaxf(x, 0).
-__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave are performed in issue order: this only stops the compiler from moving them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -497,31 +487,8 @@ __global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__
 }
 
 // ---------------------------------------------------------------- rollout-time policy step (PPO.get_action, ppo.py:673-706)
-// mean = actor(obs) (same F1/F2 MFMA tiles as above), action = clamp(mean + sqrt(var) * eps), log-prob of the CLAMPED
-// action under N(mean, var I).  eps comes from `noise` ([n,2], e.g. torch.randn) or, when noise == nullptr, from
-// Philox4x32-10 keyed by (seed, global env id, step) + Box-Muller, so a rollout step is one launch.
-__device__ __forceinline__ void philox10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                         uint32_t out[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// One wave = 16 envs, no LDS and no barrier: the 4096-env step of BASELINE configs[1] is 256 independent waves, one per
-// CU (round-1 history: 32 workgroups of 128 envs staging weights and activations through LDS took 10.9 us per call,
-// most of it on 32 of the 256 CUs).  Computed transposed like the pass kernel, on v_mfma_f32_16x16x4_f32:
-//   H1^T[n][m] = relu(b1 + W1 X^T)   A = W1 rows (k-permuted: lane group kk reads columns 4 kk .. 4 kk + 3, one dwordx4),
-//                                     B = the lane's own 4 observation floats
-//   H2^T       = relu(b2 + W2 H1^T)  B = the H1^T accumulators: register r of lane (m, kk) is row 4 kk + r of its tile
-// weights come straight from L2 (21 KB shared by every wave), 37 dwordx4 per lane, all requested up front.
-constexpr int kActEnvs = 16;   // envs per wave
-
+// PPO.get_action for all envs, one launch: one wave = 16 envs, the policy step itself is mlp64_policy.h (shared with the
+// persistent rollout kernel of navsim.hip so that both produce the same bits)
 __global__ __launch_bounds__(64) void mlp64_act(const float* __restrict__ params, const float* __restrict__ obs,
                                                 const float* __restrict__ noise, long long n,
                                                 const float* __restrict__ var_ptr, uint64_t seed, uint64_t env_id_base,
@@ -531,98 +498,17 @@ __global__ __launch_bounds__(64) void mlp64_act(const float* __restrict__ params
     const int lane = threadIdx.x, l15 = lane & 15, kk = lane >> 4;
     const long long m = (long long)blockIdx.x * kActEnvs + l15;
     const bool valid = m < n;
-    auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
-    // ---- every operand request goes out before the first MFMA
-    const float4 xq = valid ? ld4(obs + m * IN + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);   // X[m][4 kk + s]
-    float4 w1q[4], b1q[4], b2q[4], w3q[4], w4q[4], w2q[4][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        w1q[t] = ld4(params + OFF_W1 + (16 * t + l15) * IN + 4 * kk);   // W1[16 t + l15][4 kk + s]
-        b1q[t] = ld4(params + OFF_B1 + 16 * t + 4 * kk);                 // rows 16 t + 4 kk + r of the accumulator
-        b2q[t] = ld4(params + OFF_B2 + 16 * t + 4 * kk);
-        w3q[t] = ld4(params + OFF_W3 + 16 * t + 4 * kk);
-        {   // layer4.weight starts one float after layer3.bias: not 16-byte aligned, so four dword loads
-            const float* w4p = params + OFF_W4 + 16 * t + 4 * kk;
-            w4q[t] = make_float4(w4p[0], w4p[1], w4p[2], w4p[3]);
-        }
-#pragma unroll
-        for (int t1 = 0; t1 < 4; ++t1) w2q[t][t1] = ld4(params + OFF_W2 + (16 * t + l15) * H + 16 * t1 + 4 * kk);
-    }
-    const float var = *var_ptr;
+    const float4 xq = valid ? *reinterpret_cast<const float4*>(obs + m * IN + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t step = (step_base ? *step_base : 0u) + step_offset;
-    const float b3 = params[OFF_B3], b4 = params[OFF_B4];
-
-    const float xs[4] = {xq.x, xq.y, xq.z, xq.w};
-    f32x4 c1[4], c2[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        c1[t] = f32x4{b1q[t].x, b1q[t].y, b1q[t].z, b1q[t].w};
-        c2[t] = f32x4{b2q[t].x, b2q[t].y, b2q[t].z, b2q[t].w};
-    }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {   // four independent accumulators back to back
-            const float a = s4 == 0 ? w1q[t].x : s4 == 1 ? w1q[t].y : s4 == 2 ? w1q[t].z : w1q[t].w;
-            c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xs[s4], c1[t], 0, 0, 0);
-        }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c1[t][r] = relu_bits(c1[t][r]);
-#pragma unroll
-    for (int t1 = 0; t1 < 4; ++t1)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int t2 = 0; t2 < 4; ++t2) {
-                const float4 w = w2q[t2][t1];   // W2[16 t2 + l15][16 t1 + 4 kk + r]
-                const float a = r == 0 ? w.x : r == 1 ? w.y : r == 2 ? w.z : w.w;
-                c2[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, c1[t1][r], c2[t2], 0, 0, 0);
-            }
-    float z3 = 0.f, z4 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float w3v[4] = {w3q[t].x, w3q[t].y, w3q[t].z, w3q[t].w}, w4v[4] = {w4q[t].x, w4q[t].y, w4q[t].z, w4q[t].w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float h = relu_bits(c2[t][r]);
-            z3 = fmaf(h, w3v[r], z3);
-            z4 = fmaf(h, w4v[r], z4);
-        }
-    }
-    z3 += __shfl_xor(z3, 16, 64);
-    z4 += __shfl_xor(z4, 16, 64);
-    z3 += __shfl_xor(z3, 32, 64);
-    z4 += __shfl_xor(z4, 32, 64);
-    z3 += b3;
-    z4 += b4;
+    const PolicyOut o = policy_wave16(params, xq, lane, *var_ptr, (noise && valid) ? noise + 2 * m : nullptr, step, seed,
+                                      env_id_base + (uint64_t)m);
     if (kk == 0 && valid) {
-        const float mu0 = 1.0f / (1.0f + expf(-z3)), mu1 = tanhf(z4);
-        float e0, e1;
-        if (noise) {
-            e0 = noise[2 * m];
-            e1 = noise[2 * m + 1];
-        } else {
-            const uint64_t gid = env_id_base + (uint64_t)m;
-            uint32_t r[4];
-            philox10((uint32_t)gid, (uint32_t)(gid >> 32), step, 0x61637473u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-            const float u1 = ((float)(r[0] >> 8) + 1.0f) * 0x1.0p-24f;  // (0, 1]
-            const float u2 = (float)(r[1] >> 8) * 0x1.0p-24f;           // [0, 1)
-            const float rad = sqrtf(-2.0f * logf(u1));
-            e0 = rad * cosf(6.283185307179586f * u2);
-            e1 = rad * sinf(6.283185307179586f * u2);
-        }
-        const float sd = sqrtf(var);
-        const float a0 = fminf(fmaxf(fmaf(sd, e0, mu0), 0.f), 1.f);    // ppo.py:698-703
-        const float a1 = fminf(fmaxf(fmaf(sd, e1, mu1), -1.f), 1.f);
-        const float d0 = a0 - mu0, d1 = a1 - mu1;
-        act[2 * m] = a0;
-        act[2 * m + 1] = a1;
-        logp[m] = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);  // ppo.py:704
+        act[2 * m] = o.a0;
+        act[2 * m + 1] = o.a1;
+        logp[m] = o.logp;
         if (mean_out) {
-            mean_out[2 * m] = mu0;
-            mean_out[2 * m + 1] = mu1;
+            mean_out[2 * m] = o.mu0;
+            mean_out[2 * m + 1] = o.mu1;
         }
     }
 }

@@ -46,6 +46,7 @@ class PPOConfig:
     save_freq: int = 2                     # ppo.py:774
     seed: int = 0
     use_graph: bool = True                 # capture the T-step rollout in one hipGraph
+    persistent_rollout: bool = True        # mlp64x2 on GPU: all T steps in ONE launch (navsim_rollout_mlp64)
     fused_update: bool = True              # mlp64x2 on GPU: fused HIP loss+gradient kernel (csrc/ppo_mlp64.hip)
     output_dir: str = ""                   # "" = no checkpoints / logs
     episode_csv_rows: int = 2000           # per-iteration cap on rows appended to <method>_train_episodes.csv (0 = off)
@@ -285,6 +286,7 @@ class PPOTrainer:
         self.ended_buf = torch.zeros((T, N), dtype=u8, device=dev)
         self.epret_buf = torch.zeros((T, N), dtype=f32, device=dev)
         self.eplen_buf = torch.zeros((T, N), dtype=torch.int32, device=dev)
+        self.eppath_buf = torch.zeros((T, N), dtype=f32, device=dev)
         self.rtg_buf = torch.zeros((T, N), dtype=f32, device=dev)
         self.var = torch.full((), cfg.init_var, dtype=f32, device=dev)  # ppo.py:123-124 (0.8 * I)
         self._lo = torch.tensor([0.0, -1.0], device=dev)
@@ -316,7 +318,7 @@ class PPOTrainer:
         if self.updater.fused_mlp64:
             self._fused_act(t)
             self.env.sim.step(self.act_buf[t], self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.arrive_buf[t],
-                              self.ended_buf[t], self.epret_buf[t], self.eplen_buf[t])
+                              self.ended_buf[t], self.epret_buf[t], self.eplen_buf[t], ep_path=self.eppath_buf[t])
             return
         obs = self.obs_buf[t]
         mean = self.actor(obs)
@@ -326,7 +328,22 @@ class PPOTrainer:
         torch.clamp(raw, self._lo, self._hi, out=act)                   # ppo.py:700-703
         self.logp_buf[t] = gaussian_log_prob(mean, act, self.var)       # log-prob of the clamped action, :704
         self.env.sim.step(act, self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.arrive_buf[t],
-                          self.ended_buf[t], self.epret_buf[t], self.eplen_buf[t])
+                          self.ended_buf[t], self.epret_buf[t], self.eplen_buf[t], ep_path=self.eppath_buf[t])
+
+    def _persistent_rollout(self):
+        """ppo.py:505-594 in ONE launch (csrc/navsim.hip: rollout_kernel): policy step and env step alternate inside the
+        kernel; same device functions and Philox keys as the per-step path, so the buffers come out bit-identical."""
+        import ctypes as C
+        from ._native import check, lib
+        ptr = lambda x: C.c_void_p(x.data_ptr())
+        sim = self.env.sim
+        with torch.cuda.device(self.device):
+            check(lib().navsim_rollout_mlp64(sim._h, ptr(self.updater.fp.flat), ptr(self.obs_buf), ptr(self.act_buf),
+                                             ptr(self.logp_buf), ptr(self.rew_buf), ptr(self.done_buf), ptr(self.arrive_buf),
+                                             ptr(self.ended_buf), ptr(self.epret_buf), ptr(self.eplen_buf), ptr(self.eppath_buf),
+                                             ptr(self.var), self._act_seed, ptr(self._step_base), self.cfg.rollout_len,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "navsim_rollout_mlp64")
+        self._step_base += self.cfg.rollout_len
 
     def _rollout_body(self):
         for t in range(self.cfg.rollout_len):
@@ -340,7 +357,10 @@ class PPOTrainer:
         self.epret_buf.zero_()
         self.eplen_buf.zero_()
         self.env.sim.reset(self.obs_buf[0])  # ppo.py:486: every batch starts from a reset
-        if cfg.use_graph and self.device.type == "cuda":
+        if (cfg.persistent_rollout and self.updater.fused_mlp64 and self.env.B == 10
+                and self.env.sim.obs_dtype == torch.float32):
+            self._persistent_rollout()
+        elif cfg.use_graph and self.device.type == "cuda":
             if self._graph is None:
                 s = torch.cuda.Stream(self.device)
                 s.wait_stream(torch.cuda.current_stream())

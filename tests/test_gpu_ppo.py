@@ -222,3 +222,34 @@ def test_cli_train_resume_eval(tmp_path):
                    "--use_external_sampler"]) == 0
     assert M.main(["--eval", "--eval_episodes", "12", "--timesteps_per_episode", "15", "--method_name", "dbg", "--output_dir", out]) == 0
     assert os.path.exists(os.path.join(out, "dbg", "logs", "dbg_eval_episodes.csv"))
+
+
+@pytest.mark.parametrize("N,T,per_env", [(4096, 64, False), (200, 90, False), (96, 40, True)])
+def test_persistent_rollout_equals_per_step_rollout(N, T, per_env):
+    """navsim_rollout_mlp64 (all T steps in one launch) against T pairs of navppo_mlp64_act / navsim_step: same device
+    functions and Philox keys, so every rollout buffer and the simulator state must come out bit-identical -- over two
+    consecutive rollouts (the noise counter and the cached next-episode records carry over)."""
+    from navbot_ppo_amd import ppo
+    from navbot_ppo_amd.env import VecEnv
+    outs = []
+    for persistent in (True, False):
+        env = VecEnv(N, map="stage_2" if per_env else "stage_1", max_episode_steps=30, seed=3, per_env_map=per_env)
+        cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=30, n_updates_per_iteration=1, policy="mlp64x2", seed=5,
+                            persistent_rollout=persistent, use_graph=False)
+        tr = ppo.PPOTrainer(env, cfg)
+        bufs = []
+        for _ in range(2):
+            tr.rollout()
+            torch.cuda.synchronize()
+            bufs.append([b.clone() for b in (tr.obs_buf, tr.act_buf, tr.logp_buf, tr.rew_buf, tr.done_buf, tr.arrive_buf,
+                                             tr.ended_buf, tr.rtg_buf)] +
+                        [torch.where(tr.ended_buf.bool(), b, torch.zeros_like(b)) for b in (tr.epret_buf, tr.eplen_buf, tr.eppath_buf)])
+        outs.append((bufs, env.sim.get_state()))
+        env.close()
+    (a, sa), (b, sb) = outs
+    assert int(a[0][6].sum()) > N // 4          # episodes ended
+    for ra, rb in zip(a, b):
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k])

@@ -8,6 +8,28 @@ CFG2 = "--cfg2" in sys.argv
 _args = [a for a in sys.argv[1:] if not a.startswith("--")]
 _native.LIB_PATH = os.path.abspath(_args[0] if _args else "build/libnavsim_timing.so")
 from navbot_ppo_amd.env import NavSim
+names = ["start", "pre-A", "post-A", "pre-B", "post-B", "pre-C", "post-C", "end"]
+if "--rollout" in sys.argv:   # the persistent rollout kernel: stamps of its LAST step + the whole launch
+    from navbot_ppo_amd import ppo
+    from navbot_ppo_amd.env import VecEnv
+    T = 256
+    env = VecEnv(4096, map="stage_1", max_episode_steps=500, seed=0)
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=T, policy="mlp64x2", n_updates_per_iteration=1))
+    tr.rollout(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); tr._persistent_rollout(); e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / T
+    buf = np.zeros(512, dtype=np.int64)
+    L = _native.lib(); L.navsim_dbg_read.argtypes = [C.c_void_p]; L.navsim_dbg_read(buf.ctypes.data_as(C.c_void_p))
+    b = buf.reshape(8, 8, 8)
+    print(f"persistent rollout: {us:.2f} us per step ({T} steps)")
+    for blk in range(3):
+        t0 = b[blk, :4, 0].min()
+        print(f"block sample {blk}: last step")
+        for w in range(4):
+            print("  wave", w, " ".join(f"{names[s]}={(b[blk, w, s] - t0) * 10:6d}ns" for s in range(8)))
+        print(f"  step body {(b[blk, :4, 7].max() - t0) * 10} ns -> policy phase + barrier ~ {us * 1e3 - (b[blk, :4, 7].max() - t0) * 10:.0f} ns")
+    sys.exit(0)
 N = 4096 if CFG2 else 16384
 sim = NavSim(N, max_episode_steps=500, auto_reset=True, seed=0)
 if CFG2:
@@ -23,7 +45,6 @@ buf = np.zeros(512, dtype=np.int64)
 L = _native.lib(); L.navsim_dbg_read.argtypes = [C.c_void_p]; L.navsim_dbg_read(buf.ctypes.data_as(C.c_void_p))
 b = buf.reshape(8, 8, 8)  # [sampled block][wave][slot]
 t0 = b[:, :4, 0].min()
-names = ["start", "pre-A", "post-A", "pre-B", "post-B", "pre-C", "post-C", "end"]
 for blk in range(4):
     print(f"block sample {blk}")
     for w in range(4):
