@@ -14,10 +14,13 @@ gradient per epoch when N > 1).  value = K * T * n_envs_total / wall, the refere
 policy, seeded goals).  Weak scaling: every GPU owns its own 4096-env shard.
 
 Besides the contract fields, rank 0 adds
-  roofline      step kernel on BASELINE configs[2] (16384 envs, per-env stage_2 segment buffers): algorithmic
-                bytes (134 + 16*S per env-step) / mean launch duration from HIP events
-  roofline_timed_region   the same kernel at the timed workload (4096 envs, shared map: launch-latency bound)
-  cpu_baseline  the CPU oracle (scalar C port, 1 core) stepping the same 4096-env workload for ~10 s
+  roofline            step kernel on BASELINE configs[2] (16384 envs, per-env stage_2 segment buffers, S=128): algorithmic
+                      bytes (134 + 16*S per env-step) / mean launch duration from HIP events
+  roofline_beyond_l3  the same kernel with S=1024 per env (268 MB working set: past the 256 MiB Infinity Cache)
+  roofline_timed_region   the persistent rollout kernel of the timed workload
+  time_to_reward_s    PPO wall-clock until mean episode return >= +100 (ppo.py:833) from a fresh policy
+  resmlp512           the same iteration with the reference's active 512-wide residual nets (PyTorch-ROCm path)
+  cpu_baseline / _all_cores / _n1   the CPU oracle (scalar C port) on 1 core, on every host core, and one env per call
 """
 import argparse
 import json
@@ -59,11 +62,11 @@ def _event_time_ms(fn, iters, warm=20, per_graph=64):
     return e0.elapsed_time(e1) / (reps * per_graph)
 
 
-def step_kernel_roofline(n_envs, map_name, per_env, iters=640, seed=0):
+def step_kernel_roofline(n_envs, map_name, per_env, iters=640, seed=0, sides=None, detail=""):
     """HIP-event timing of navsim_step alone (random actions resident in HBM)."""
     from navbot_ppo_amd import maps
     from navbot_ppo_amd.env import NavSim
-    seg = maps.by_name(map_name)
+    seg = maps.stage_2(sides=sides) if sides else maps.by_name(map_name)
     S = int(seg.shape[0])
     sim = NavSim(n_envs, max_episode_steps=500, auto_reset=True, seed=seed)
     rr, rs = maps.goal_rects(map_name)
@@ -86,32 +89,102 @@ def step_kernel_roofline(n_envs, map_name, per_env, iters=640, seed=0):
     alg_bytes = n_envs * bytes_per_env_step + (0 if per_env else 16 * S)
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     sim.close()
-    return dict(bound="hbm", kernel="step_kernel<10,%s>" % ("per_env" if per_env else "shared"),
+    return dict(bound="hbm", bound_detail=detail, kernel="step_kernel<10,%s>" % ("per_env" if per_env else "shared"),
                 workload=f"{n_envs} envs, {map_name} ({S} segments, {'per-env' if per_env else 'shared'} map), 10 beams",
                 achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
                 traffic=None, launch_us=round(ms * 1e3, 3), algorithmic_bytes_per_launch=int(alg_bytes),
                 bytes_per_env_step=bytes_per_env_step, env_steps_per_sec=round(n_envs / (ms * 1e-3), 1))
 
 
-def cpu_baseline(n_envs, budget_s=10.0):
-    """The oracle (oracle/navsim_oracle.c, scalar C, one thread) on the same workload, bounded in time."""
-    from navbot_ppo_amd import maps
-    from oracle import navsim_oracle as O
-    sim = O.OracleSim(n_envs, max_episode_steps=500, auto_reset=True, seed=0)
-    sim.set_map(maps.stage_1())
-    sim.reset()
-    rng = np.random.default_rng(0)
-    a = np.stack([rng.uniform(0, 1, n_envs), rng.uniform(-1, 1, n_envs)], 1).astype(np.float32)
-    sim.step(a)
+def cpu_baseline(n_envs, procs, budget_s):
+    """The oracle (oracle/navsim_oracle.c, scalar C) on the configs[1] env workload, bounded in time, in its own process
+    (oracle/cpu_bench.py forks its worker pool from an interpreter that never touched HIP)."""
+    import subprocess
+    out = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--procs", str(procs), "--envs", str(n_envs),
+                          "--budget", str(budget_s)], cwd=REPO, capture_output=True, text=True, timeout=60 + 4 * budget_s)
+    if out.returncode != 0:
+        return {"error": out.stderr[-400:]}
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def rollout_kernel_leg(trainer, reps=6):
+    """The persistent rollout kernel of the timed workload alone (HIP events on its stream)."""
+    T, N = trainer.cfg.rollout_len, trainer.env.N
+    trainer.env.sim.reset(trainer.obs_buf[0])
+    trainer._persistent_rollout()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        trainer._persistent_rollout()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg = T * N * 134 + 16 * 32           # SURVEY 8(d): 134 B per env-step with a shared map (+ the map once)
+    ach = alg / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", bound_detail="latency chain: one workgroup per CU runs T dependent steps (policy MFMA -> f64 motion -> "
+                "cast -> rules); bytes are irrelevant at this size", kernel="rollout_kernel<16,8 waves>",
+                workload=f"{N} envs x {T} steps, stage_1 (32 segments, shared map), 10 beams, 16-64-64 policy in-kernel",
+                achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                launch_us=round(ms * 1e3, 1), us_per_step=round(ms * 1e3 / T, 3), algorithmic_bytes_per_launch=int(alg),
+                env_steps_per_sec=round(T * N / (ms * 1e-3), 1))
+
+
+def time_to_reward(n_envs, target=100.0, max_iters=40):
+    """BASELINE metric part (ii): PPO wall-clock until the iteration's mean episode return (avg_ep_rews, ppo.py:833) reaches
+    +100, from a fresh policy (seed 0) on the configs[1] workload; the clock includes every launch from the first reset."""
+    from navbot_ppo_amd import ppo
+    from navbot_ppo_amd.env import VecEnv
+    env = VecEnv(n_envs, map="stage_1", max_episode_steps=500, seed=0)
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(policy="mlp64x2", seed=0))
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < budget_s:
-        sim.step(a)
-        steps += 1
+    trace = []
+    for it in range(max_iters):
+        lg = tr.iteration()
+        torch.cuda.synchronize()
+        trace.append([round(time.perf_counter() - t0, 3), round(lg["avg_ep_rews"], 2), round(lg["success_rate"], 4)])
+        if lg["avg_ep_rews"] >= target and it >= 1:
+            break
+    env.close()
+    return dict(seconds=trace[-1][0], reached=bool(trace[-1][1] >= target), target=target, iterations=len(trace),
+                env_steps=tr.env_steps, trace_sec_meanreward_success=trace)
+
+
+def resmlp512_leg(n_envs, rollout, epochs, steps=2):
+    """SURVEY 8(d) cfg 2 "reported alongside": the reference's ACTIVE nets (net_actor.py:56-144, net_critic.py:50-130) on the
+    same workload; PyTorch-ROCm forward/backward, hipGraph rollout."""
+    from navbot_ppo_amd import ppo
+    from navbot_ppo_amd.env import VecEnv
+    env = VecEnv(n_envs, map="stage_1", max_episode_steps=500, seed=0)
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=rollout, n_updates_per_iteration=epochs, policy="resmlp512", seed=0))
+    tr.iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = u = 0.0
+    for _ in range(steps):
+        lg = tr.iteration()
+        r += lg["rollout_time"]
+        u += lg["update_time"]
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return dict(value=round(steps * n_envs / dt, 1), unit="env-steps/s", cores=1, kind="port",
-                sample=f"{steps} steps of {n_envs} envs (stage_1, 10 beams, random actions), env step only, {dt:.1f} s",
-                host_cpus=os.cpu_count())
+    env.close()
+    return dict(policy="resmlp512", value=round(steps * rollout * n_envs / dt, 1), unit="env-steps/s", steps=steps,
+                ms_per_step=round(dt / steps * 1e3, 2), rollout_ms=round(r / steps * 1e3, 2), update_ms=round(u / steps * 1e3, 2))
+
+
+def profiled_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh -> profiles/pmc_traffic.json),
+    used only while the file was recorded from THIS kernel source (sha256 of csrc/navsim.hip), else None."""
+    import hashlib
+    f = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    src = os.path.join(REPO, "navbot_ppo_amd", "csrc", "navsim.hip")
+    if not (os.path.exists(f) and os.path.exists(src)):
+        return None
+    d = json.load(open(f))
+    if d.get("navsim_hip_sha256") != hashlib.sha256(open(src, "rb").read()).hexdigest():
+        return None
+    return d.get(key)
 
 
 def main():
@@ -173,23 +246,34 @@ def main():
                                    f"PPO {args.policy}, rollout={args.rollout}, {args.epochs} full-batch epochs, episode cap 500",
                        "n_envs_total": n_total, "n_envs_per_gpu": n_local, "rollout_len": args.rollout,
                        "epochs": args.epochs, "policy": args.policy, "parallelism": f"env-shard dp{ctx.world}",
-                       "hip_graph_rollout": not args.no_graph},
+                       "rollout": "persistent kernel (navsim_rollout_mlp64)" if trainer.updater.fused_mlp64 and cfg.persistent_rollout
+                       else ("hipGraph of per-step launches" if not args.no_graph else "per-step launches")},
             "rollout_only_env_steps_per_sec": round(K * args.rollout * n_total / roll_t, 1),
             "rollout_ms": round(roll_t / K * 1e3, 3), "update_ms": round(upd_t / K * 1e3, 3),
             "last_iter": {k: lg[k] for k in ("avg_ep_rews", "success_rate", "episodes", "actor_loss", "critic_loss", "approx_kl")},
         }
     if not args.no_extras and ctx.rank == 0:   # rank 0 only (the other ranks wait at the barrier below)
+        # GPU legs first and long enough (several seconds in total) for an outside utilisation sampler to see them
+        out["roofline_timed_region"] = rollout_kernel_leg(trainer) if trainer.updater.fused_mlp64 else None
         del trainer
         torch.cuda.empty_cache()
-        out["roofline"] = step_kernel_roofline(16384, "stage_2", per_env=True)
-        out["roofline_timed_region"] = step_kernel_roofline(n_local, "stage_1", per_env=False)
-        pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            t = json.load(open(pmc))
-            out["roofline"]["traffic"] = t.get("cfg3_step_bytes_per_launch")
-            out["roofline_timed_region"]["traffic"] = t.get("cfg2_step_bytes_per_launch")
+        out["roofline"] = step_kernel_roofline(
+            16384, "stage_2", per_env=True, iters=64 * 1500,
+            detail="working set 35.7 MB sits in the 256 MiB Infinity Cache: L3-fed, VALU / phase-latency bound at this size")
+        out["roofline"]["traffic"] = profiled_traffic("cfg3_step_bytes_per_launch")
+        out["roofline_beyond_l3"] = step_kernel_roofline(
+            16384, "stage_2", per_env=True, iters=64 * 400, sides=248,
+            detail="working set 268 MB > Infinity Cache: the segment stream comes from HBM")
+        out["roofline_beyond_l3"]["traffic"] = profiled_traffic("s1024_step_bytes_per_launch")
         if ctx.world == 1:
-            out["cpu_baseline"] = cpu_baseline(n_local)
+            ttr = time_to_reward(n_local)
+            out["time_to_reward_s"] = ttr["seconds"]
+            out["time_to_reward"] = ttr
+            out["resmlp512"] = resmlp512_leg(n_local, args.rollout, args.epochs)
+            cores = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(n_local, 1, 8.0)
+            out["cpu_baseline_all_cores"] = cpu_baseline(n_local, cores, 6.0)
+            out["cpu_baseline_n1"] = cpu_baseline(1, 1, 3.0)
     if ctx.rank == 0:
         print(json.dumps(out), flush=True)
     ctx.barrier()

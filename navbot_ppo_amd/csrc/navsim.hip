@@ -1110,9 +1110,69 @@ __global__ void spawn_obs_kernel(const float* __restrict__ best, int n, int belo
 }
 
 // ---------------------------------------------------------------- return scan (PPO.compute_rtgs)
-// thread = env column, reverse over T; loads are independent of the recurrence so they pipeline.
-__global__ void rtg_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ ended, int T, int N,
-                           double gamma, float* __restrict__ out) {
+// R[t] = r[t] + gamma R[t+1], restarting at 0 behind every episode end and at the batch end (ppo.py:658-666), float64
+// accumulate, float32 store: per env column a strictly serial recurrence (any re-association would change bits), so the
+// parallelism is across columns only and the job of the kernel is to keep the memory system busy meanwhile.  A workgroup
+// owns kRtgCols adjacent columns and walks from the last row to the first in chunks of kRtgRows rows through a three-stage
+// pipeline over LDS buffers:   waves 1-3 stream chunk s in (16-byte loads, all in flight at once)
+//                            | wave 0, lane = column, runs the recurrence on chunk s - 1 (the carry stays in a register)
+//                            | waves 1-3 stream the returns of chunk s - 2 out
+// with one workgroup barrier per stage.  N = 4096 gives 256 workgroups (round 1: one thread per column with 8 loads in
+// flight = 64 latency-bound waves, 40 us for 18.9 MB; now 18.6 us).  The floor is the recurrence itself: 512 dependent
+// float64 multiply -> add pairs per column, ~35 cycles each = 7.5 us.  "if ended: disc = 0" is folded into the factor:
+// disc * 0 is (+-)0 and r + (+-)0 == r, so the value is that of ppo.py:660-665 while the select leaves the dependent chain.
+// (Tried: chunk s + 1 requested into registers one stage ahead behind an LDS-only barrier -- 35 us, slower.)
+constexpr int kRtgCols = 16, kRtgRows = 128;
+
+__global__ __launch_bounds__(256) void rtg_kernel_vec(const float* __restrict__ rew, const uint8_t* __restrict__ ended, int T, int N,
+                                                      double gamma, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_r[3][kRtgRows * kRtgCols];
+    __shared__ __attribute__((aligned(16))) float s_o[3][kRtgRows * kRtgCols];   // separate from s_r: the recurrence's reads of
+    __shared__ __attribute__((aligned(16))) uint8_t s_e[3][kRtgRows * kRtgCols]; // row t - 1 must not wait for its write of row t
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int col0 = blockIdx.x * kRtgCols;   // N % 16 == 0: all 16 columns exist
+    const int C = (T + kRtgRows - 1) / kRtgRows;   // chunk j covers rows [T - (j + 1) kRtgRows, T - j kRtgRows) clipped at 0
+    const int wt = tid - 64;                       // thread index among the 192 streaming threads
+    double disc = 0;  // ppo.py:660
+    for (int s = 0; s < C + 2; ++s) {
+        if (wave > 0) {
+            if (s < C) {   // ---- stream chunk s in
+                const int t_hi = T - s * kRtgRows, t_lo = max(0, t_hi - kRtgRows), nt = t_hi - t_lo;
+                for (int k = wt; k < nt * 4; k += 192)
+                    reinterpret_cast<float4*>(s_r[s % 3])[k] =
+                        *reinterpret_cast<const float4*>(rew + (size_t)(t_lo + (k >> 2)) * N + col0 + 4 * (k & 3));
+                for (int k = wt; k < nt; k += 192)
+                    reinterpret_cast<uint4*>(s_e[s % 3])[k] = *reinterpret_cast<const uint4*>(ended + (size_t)(t_lo + k) * N + col0);
+            }
+            if (s >= 2) {   // ---- stream the returns of chunk s - 2 out
+                const int j = s - 2;
+                const int t_hi = T - j * kRtgRows, t_lo = max(0, t_hi - kRtgRows), nt = t_hi - t_lo;
+                for (int k = wt; k < nt * 4; k += 192)
+                    *reinterpret_cast<float4*>(out + (size_t)(t_lo + (k >> 2)) * N + col0 + 4 * (k & 3)) =
+                        reinterpret_cast<const float4*>(s_o[j % 3])[k];
+            }
+        } else if (s >= 1 && s <= C && tid < kRtgCols) {   // ---- the recurrence on chunk s - 1
+            const int j = s - 1;
+            const int t_hi = T - j * kRtgRows, nt = t_hi - max(0, t_hi - kRtgRows);
+            const float* __restrict__ br = s_r[j % 3];
+            const uint8_t* __restrict__ be = s_e[j % 3];
+            float* __restrict__ bo = s_o[j % 3];
+#pragma unroll 8
+            for (int tt = nt - 1; tt >= 0; --tt) {
+                const int k = tt * kRtgCols + tid;
+                const float r = br[k];
+                const double g = be[k] ? 0.0 : gamma;
+                disc = (double)r + disc * g;      // ppo.py:665
+                bo[k] = (float)disc;              // ppo.py:669
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// any N / alignment: thread = env column, reverse over T
+__global__ void rtg_kernel_generic(const float* __restrict__ rew, const uint8_t* __restrict__ ended, int T, int N, double gamma,
+                                   float* __restrict__ out) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     double disc = 0;  // ppo.py:660
@@ -1548,8 +1608,12 @@ int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, i
     if (T < 0 || N < 0) return fail(NAVSIM_E_ARG, "navsim_rtg_scan: negative size");
     if (T == 0 || N == 0) return NAVSIM_OK;  // empty batch: nothing to scan (pointers may be null)
     if (!rew_dev || !ended_dev || !out_dev) return fail(NAVSIM_E_ARG, "navsim_rtg_scan: null buffer");
-    hipLaunchKernelGGL(rtg_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N,
-                       gamma, out_dev);
+    if ((N % 16 == 0) && (((uintptr_t)rew_dev | (uintptr_t)out_dev | (uintptr_t)ended_dev) % 16 == 0))
+        hipLaunchKernelGGL(rtg_kernel_vec, dim3(N / kRtgCols), dim3(256), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N, gamma,
+                           out_dev);
+    else
+        hipLaunchKernelGGL(rtg_kernel_generic, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N,
+                           gamma, out_dev);
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;
 }

@@ -53,6 +53,7 @@ class NavSim:
         with torch.cuda.device(self.device):
             check(lib().navsim_create(C.byref(self.cfg), C.byref(self._h)), "navsim_create")
         self._seg = None  # keeps the map tensor alive: the handle only borrows the pointer
+        self.generation = 0  # bumped whenever device pointers / scalars a captured hipGraph would have frozen change
 
     def close(self):
         if getattr(self, "_h", None):
@@ -78,11 +79,13 @@ class NavSim:
             check(lib().navsim_set_map(self._h, _ptr(seg), int(seg.shape[-2]), int(bool(per_env)), _stream()), "navsim_set_map")
         self._seg = seg
         self.S, self.per_env = int(seg.shape[-2]), bool(per_env)
+        self.generation += 1
 
     def set_goal_rects(self, which, rects):
         r = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
         with torch.cuda.device(self.device):   # the call synchronises the CURRENT device before touching the rectangles
             check(lib().navsim_set_goal_rects(self._h, int(which), _np_ptr(r), r.shape[0]), "navsim_set_goal_rects")
+        self.generation += 1
 
     def set_spawn_sampler(self, starts, goals=None, min_dist=1.5, max_dist=6.0):
         """GoalSpawnSampler tables (spawn_goal_sampler.py:37-62): start poses [K,3], goal points [G,2] or None."""
@@ -91,6 +94,7 @@ class NavSim:
         with torch.cuda.device(self.device):
             check(lib().navsim_set_spawn_sampler(self._h, _np_ptr(st), st.shape[0], _np_ptr(g), 0 if g is None else g.shape[0],
                                                  float(min_dist), float(max_dist), _stream()), "navsim_set_spawn_sampler")
+        self.generation += 1
 
     # -- buffers
     def alloc_io(self):

@@ -90,8 +90,11 @@ def main(argv=None):
     if args.use_external_sampler:
         world_type = "stage1" if args.map.startswith("stage") else "small_house"
         st, g, dmin, dmax = maps.spawn_tables(world_type)
-        if world_type == "small_house":
-            st, g = maps.open_tables(maps.by_name(args.map), st, g)
+        n_st, n_g = len(st), len(g)
+        st, g = maps.open_tables(maps.by_name(args.map), st, g)   # drop table points inside / against walls (stage tables too:
+        if ctx.rank == 0 and (len(st) < n_st or len(g) < n_g):    # the reference's stage-1 goals at +-4.0 sit inside the outer wall)
+            print(f"external sampler: dropped {n_st - len(st)} start poses and {n_g - len(g)} goals that are not in open space",
+                  flush=True)
         sampler = (st, g, dmin, dmax)
     env = VecEnv(hi - lo, map=args.map, max_episode_steps=args.timesteps_per_episode, auto_reset=True, is_training=True,
                  seed=args.seed, env_id_base=lo, device=ctx.device, sampler=sampler)

@@ -213,6 +213,8 @@ class PPOUpdater:
             V0 = self.critic(obs).squeeze(-1)
             adv = normalise_advantages(rtg - V0, ctx)          # ppo.py:275-284
         n_ep = cfg.n_updates_per_iteration
+        a_loss = c_loss = torch.zeros((), device=obs.device)   # n_updates_per_iteration == 0: nothing to report
+        gn_sum = torch.zeros((), device=obs.device)            # fused path: grad norm summed over the epochs, like the other path
         acc = torch.zeros(6, device=obs.device)                # sums over epochs of diagnostics
         self.loss_history = torch.zeros((n_ep, 2), device=obs.device)  # per-epoch (actor, critic) loss, ppo.py:396-397
         var_f = float(var) if self.fused_mlp64 else None
@@ -227,12 +229,13 @@ class PPOUpdater:
                 if world > 1:
                     ctx.all_reduce_sum(self.fp.grad)
                     self.fp.grad.div_(world)
+                gn_sum += self.fp.grad.norm()
                 self.opt.step()
                 if ep == n_ep - 1:
                     h = self._fhist[:n_ep]
                     self.loss_history = h[:, [0, 4]].clone()
                     acc = torch.stack([h[:, 0].sum(), h[:, 4].sum(), h[:, 1].sum(), h[:, 2].sum(),
-                                       self.fp.grad.norm() * n_ep, V0.mean() * n_ep])
+                                       gn_sum, V0.mean() * n_ep])
                     a_loss, c_loss = h[-1, 0].clone(), h[-1, 4].clone()
                 continue
             a_loss, c_loss, ratios, logp, _ = ppo_losses(self.actor, self.critic, obs, acts, logp_old, rtg, adv, var, cfg.clip)
@@ -361,7 +364,10 @@ class PPOTrainer:
                 and self.env.sim.obs_dtype == torch.float32):
             self._persistent_rollout()
         elif cfg.use_graph and self.device.type == "cuda":
+            if self._graph is not None and self._graph_gen != self.env.sim.generation:
+                self._graph = None   # set_map / set_spawn_sampler / set_goal_rects re-allocated what the capture froze
             if self._graph is None:
+                self._graph_gen = self.env.sim.generation
                 s = torch.cuda.Stream(self.device)
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):  # warm-up outside capture (allocator, hipBLASLt workspaces)
@@ -450,8 +456,10 @@ class PPOTrainer:
         return os.path.join(self.cfg.output_dir, self.cfg.method_name, "logs")
 
     def write_episode_csv(self, max_rows=None):
-        """Appends the episodes finished in the last rollout, in (step, env) order.  path_length is not tracked by the
-        batched simulator (0.0); time is the iteration's wall time share."""
+        """Appends the episodes finished in the last rollout, in (step, env) order (ppo.py:739-746).  path_length is the
+        simulator's per-episode accumulator (ppo.py:533-537 semantics: the final step's displacement is not part of it);
+        time is the episode's share of the rollout wall clock, length x (rollout_time / T): the envs advance in lock
+        step, so an episode of L steps occupied L / T of the rollout."""
         import csv
         os.makedirs(self.log_dir(), exist_ok=True)
         path = os.path.join(self.log_dir(), f"{self.cfg.method_name}_train_episodes.csv")
@@ -464,7 +472,9 @@ class PPOTrainer:
         a = self.arrive_buf[t_idx, n_idx].cpu().numpy()
         ln = self.eplen_buf[t_idx, n_idx].cpu().numpy()
         rt = self.epret_buf[t_idx, n_idx].cpu().numpy()
+        pl = self.eppath_buf[t_idx, n_idx].cpu().numpy()
         tt = t_idx.cpu().numpy()
+        sec_per_step = float(self.logger.get("rollout_time", 0.0)) / max(self.cfg.rollout_len, 1)
         base = getattr(self, "_episode_count", 0)
         with open(path, "a", newline="") as f:
             w = csv.writer(f)
@@ -473,7 +483,7 @@ class PPOTrainer:
             for k in range(len(tt)):
                 succ = int(a[k]); coll = int(d[k] and not a[k]); tmo = int(not d[k] and not a[k])  # ppo.py:558-560
                 w.writerow([base + k, self.env_steps - (self.cfg.rollout_len - int(tt[k]) - 1) * self.env.N, succ, coll, tmo,
-                            int(ln[k]), float(rt[k]), 0.0, 0.0])
+                            int(ln[k]), float(rt[k]), float(pl[k]), float(ln[k]) * sec_per_step])
         self._episode_count = base + len(tt)
         return path
 
