@@ -248,6 +248,8 @@ def main():
                        "epochs": args.epochs, "policy": args.policy, "parallelism": f"env-shard dp{ctx.world}",
                        "rollout": "persistent kernel (navsim_rollout_mlp64)" if trainer.updater.fused_mlp64 and cfg.persistent_rollout
                        else ("hipGraph of per-step launches" if not args.no_graph else "per-step launches")},
+            "dist_backend": ctx.backend, "rccl_version": ctx.rccl_version,
+            "rccl_ranks": (torch.distributed.get_world_size() if ctx.backend == "nccl" else 0),
             "rollout_only_env_steps_per_sec": round(K * args.rollout * n_total / roll_t, 1),
             "rollout_ms": round(roll_t / K * 1e3, 3), "update_ms": round(upd_t / K * 1e3, 3),
             "last_iter": {k: lg[k] for k in ("avg_ep_rews", "success_rate", "episodes", "actor_loss", "critic_loss", "approx_kl")},

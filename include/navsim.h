@@ -92,6 +92,11 @@ int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_
  * which=0: used by reset (environment_new.py:340-343); which=1: used by the arrival
  * re-spawn (environment_new.py:248-251).  Defaults are the reference's stage_1 values.
  * n_rects <= 16.  Synchronous.
+ * Bound: the reference redraws until a goal is accepted (environment_new.py:340-345 loops forever on rectangles that
+ * cover the goal box); the kernels draw at most 64 times and then keep the last draw.  With the stock rectangles
+ * (18 % / 25 % of the box rejected) the chance of exhausting 64 draws is < 1e-38; rectangles covering more than ~70 %
+ * of [goal_lo, goal_hi]^2 make accepted-after-64 goals inside a rectangle plausible (0.7^64 = 1e-10 per reset) -- keep
+ * the rejected share below that or enlarge the goal box.
  */
 int navsim_set_goal_rects(navsim_t* h, int32_t which, const double* rects_host, int32_t n_rects);
 

@@ -70,6 +70,7 @@ class DistCtx:
         self.device = torch.device(device)
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
+        self.backend, self.rccl_version = None, None
         if self.enabled and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
@@ -78,6 +79,18 @@ class DistCtx:
             backend = os.environ.get("NAVBOT_DIST_BACKEND") or ("nccl" if self.device.type == "cuda" else "gloo")
             kw = {"device_id": self.device} if backend == "nccl" else {}
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+        if self.enabled:
+            self.backend = dist.get_backend()
+            if self.device.type == "cuda" and not os.environ.get("NAVBOT_DIST_BACKEND"):
+                assert self.backend == "nccl", f"GPU ranks must talk RCCL (torch backend 'nccl'), got {self.backend!r}"
+            if self.backend == "nccl":
+                try:
+                    self.rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception:
+                    self.rccl_version = "unknown"
+                if self.rank == 0:   # one line per job: a scaling run shows how many ranks RCCL really connected
+                    print(f"[navbot_ppo_amd] RCCL {self.rccl_version}: {dist.get_world_size()} ranks, one per GPU, "
+                          f"flat-gradient all-reduce per epoch", flush=True)
 
     def all_reduce_sum(self, t):
         if self.enabled:

@@ -145,7 +145,7 @@ def _free_port():
 def _dp_worker(rank, world, port, path):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
-    torch.set_num_threads(2)
+    torch.set_num_threads(1 if world > 2 else 2)
     ctx = ppo.DistCtx(device="cpu")
     d = np.load(os.path.join(G, "g7_update.npz"))
     torch.manual_seed(100 + rank)  # different initial weights per rank: the broadcast must fix that
@@ -161,13 +161,19 @@ def _dp_worker(rank, world, port, path):
     torch.distributed.destroy_process_group()
 
 
-def test_data_parallel_gloo_world2_equals_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_data_parallel_gloo_equals_single_process(tmp_path, world):
+    """world_size 2 and 8 (the node size of BASELINE configs[3]/[4]): contiguous shards of the G7 batch, flat-gradient
+    all-reduce per epoch, all-reduced advantage moments == the single-process update on the whole batch."""
     import torch.multiprocessing as mp
     path = str(tmp_path / "dp")
-    mp.spawn(_dp_worker, args=(2, _free_port(), path), nprocs=2, join=True)
-    r0, r1 = torch.load(path + ".0"), torch.load(path + ".1")
-    assert r0["shard"] == (0, 256) and r1["shard"] == (256, 512)
-    assert torch.equal(r0["flat"], r1["flat"])  # replicas stay bit-identical
+    mp.spawn(_dp_worker, args=(world, _free_port(), path), nprocs=world, join=True)
+    rs = [torch.load(f"{path}.{k}") for k in range(world)]
+    r0, r1 = rs[0], rs[1]
+    per = 512 // world
+    assert [r["shard"] for r in rs] == [(k * per, (k + 1) * per) for k in range(world)]
+    for r in rs[1:]:
+        assert torch.equal(r0["flat"], r["flat"])  # replicas stay bit-identical
     # single process on the full batch, starting from rank 0's initial weights
     d = np.load(os.path.join(G, "g7_update.npz"))
     torch.manual_seed(100)
@@ -177,7 +183,7 @@ def test_data_parallel_gloo_world2_equals_single_process(tmp_path):
               torch.from_numpy(d["rtgs"]), torch.tensor(0.8))
     np.testing.assert_allclose(r0["flat"].numpy(), up.fp.flat.numpy(), rtol=0, atol=2e-6)
     # global losses = mean of the shard losses (equal shard sizes)
-    np.testing.assert_allclose(((r0["hist"] + r1["hist"]) / 2).numpy(), up.loss_history.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose((sum(r["hist"] for r in rs) / world).numpy(), up.loss_history.numpy(), rtol=1e-4, atol=1e-5)
 
 
 def test_shard_partition():
