@@ -323,6 +323,10 @@ struct StepSmem {
     float4 r4[NW][128];          // ... and of those whose angular extent holds at least one beam
     unsigned re[NW][128];
     float2 act_l[EPB];           // persistent rollout: the action the policy phase chose for this step
+    // persistent rollout: the envs' state lives here between the steps (HBM sees it before the first and after the last)
+    double st_d[8][EPB];         // x, y, th, gx, gy, past_dist, ep_ret, ep_path
+    float2 st_pact[EPB];
+    uint32_t st_step[EPB], st_ctr[EPB];
 };
 
 // Correctly rounded K / Dn for positive, normal-range operands (Dn in [2^-60, 2^20], K in {0} U [2^-60, 2^20]):
@@ -418,7 +422,8 @@ __device__ __forceinline__ float write_lidar(float* row, const float* best, int 
 //   barrier C
 //   all:     the EPB x (B+6) observation tile leaves LDS as one contiguous, fully coalesced store.
 // SENS = false compiles the sensor-fidelity options (range noise, -inf below range_min) out.
-// PERSIST: called once per step by the persistent rollout kernel; the action comes from the policy phase through LDS.
+// PERSIST: called once per step by the persistent rollout kernel; the action comes from the policy phase through LDS and
+// the env state stays in LDS (sm.st_*) from step to step; `last_step` also writes it back to HBM.
 // NW: waves per workgroup (4; the persistent rollout kernel, one workgroup per CU, runs 8 for a shorter cast).
 template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4>
 __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>& sm, int& next_env,
@@ -426,7 +431,8 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
                                           void* __restrict__ obs_out, float* __restrict__ reward,
                                           uint8_t* __restrict__ done, uint8_t* __restrict__ arrive,
                                           uint8_t* __restrict__ ended, float* __restrict__ ep_return,
-                                          int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out) {
+                                          int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out,
+                                          const bool last_step = true) {
     static_assert(EPB <= 64 && EPB >= 4 && NB % 2 == 0, "EPB / NB");
     constexpr int kThreads = 64 * NW;
 
@@ -494,18 +500,33 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
         if (pose_lane) {
             double delta_s = 0, delta_theta = 0, arg = 0, x_old = 0, y_old = 0;
             if (el_pose < nloc) {
-                th = P.th[i];
-                act = PERSIST ? sm.act_l[el_pose] : action[i];
-                ctr = P.rng_ctr[i];
-                stepw = (uint32_t)P.ep_step[i];
-                if (rr == 0) {
-                    x = P.x[i]; y = P.y[i];
-                    gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
-                    pact = past_override ? past_override[i] : P.past_action[i];
-                    ret0 = P.ep_ret[i];
-                    path0 = P.ep_path[i];
-                    x_old = x; y_old = y;
+                if (PERSIST) {
+                    const int e = el_pose;
+                    th = sm.st_d[2][e];
+                    act = sm.act_l[e];
+                    ctr = sm.st_ctr[e];
+                    stepw = sm.st_step[e];
+                    if (rr == 0) {
+                        x = sm.st_d[0][e]; y = sm.st_d[1][e];
+                        gx = sm.st_d[3][e]; gy = sm.st_d[4][e]; pdist = sm.st_d[5][e];
+                        pact = sm.st_pact[e];
+                        ret0 = sm.st_d[6][e];
+                        path0 = sm.st_d[7][e];
+                    }
+                } else {
+                    th = P.th[i];
+                    act = action[i];
+                    ctr = P.rng_ctr[i];
+                    stepw = (uint32_t)P.ep_step[i];
+                    if (rr == 0) {
+                        x = P.x[i]; y = P.y[i];
+                        gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
+                        pact = past_override ? past_override[i] : P.past_action[i];
+                        ret0 = P.ep_ret[i];
+                        path0 = P.ep_path[i];
+                    }
                 }
+                x_old = x; y_old = y;
                 // environment_new.py:273-278
                 const double v = (double)act.x / 4;
                 const double w = (double)act.y;
@@ -895,15 +916,25 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             row[B + 0] = 0.f; row[B + 1] = 0.f;        // :372-373
             row[B + 2] = tl.x; row[B + 3] = tl.y; row[B + 4] = tl.z; row[B + 5] = tl.w;
         }
-        P.x[i] = x; P.y[i] = y; P.th[i] = th;
-        P.gx[i] = gx; P.gy[i] = gy; P.past_dist[i] = pdist;
-        P.past_action[i] = next_pact;
         // the records written or read in part 2 stay current until the env's goal stream moves
         const bool rec_ok = (P.auto_reset || P.respawn) && !moved_stream;
-        P.ep_step[i] = (int32_t)(step | (rec_ok ? kRecValid : 0u));
-        P.ep_ret[i] = ret;
-        P.ep_path[i] = path;
-        P.rng_ctr[i] = ctr;
+        const uint32_t stepw_out = step | (rec_ok ? kRecValid : 0u);
+        if (PERSIST) {
+            sm.st_d[0][e] = x; sm.st_d[1][e] = y; sm.st_d[2][e] = th; sm.st_d[3][e] = gx; sm.st_d[4][e] = gy;
+            sm.st_d[5][e] = pdist; sm.st_d[6][e] = ret; sm.st_d[7][e] = path;
+            sm.st_pact[e] = next_pact;
+            sm.st_step[e] = stepw_out;
+            sm.st_ctr[e] = ctr;
+        }
+        if (!PERSIST || last_step) {
+            P.x[i] = x; P.y[i] = y; P.th[i] = th;
+            P.gx[i] = gx; P.gy[i] = gy; P.past_dist[i] = pdist;
+            P.past_action[i] = next_pact;
+            P.ep_step[i] = (int32_t)stepw_out;
+            P.ep_ret[i] = ret;
+            P.ep_path[i] = path;
+            P.rng_ctr[i] = ctr;
+        }
     }
     __syncthreads();  // barrier C: observation tile complete in LDS
 
@@ -969,6 +1000,14 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
     const int nloc = min(EPB, P.N - base);
     const size_t N = (size_t)P.N;
     for (int k = tid; k < mlp64::P_ACTOR; k += kThreads) wts[k] = R.params[k];
+    if (tid < nloc) {   // the envs' state: HBM -> LDS for the whole rollout
+        const int e = tid, i = base + e;
+        sm.st_d[0][e] = P.x[i]; sm.st_d[1][e] = P.y[i]; sm.st_d[2][e] = P.th[i]; sm.st_d[3][e] = P.gx[i]; sm.st_d[4][e] = P.gy[i];
+        sm.st_d[5][e] = P.past_dist[i]; sm.st_d[6][e] = P.ep_ret[i]; sm.st_d[7][e] = P.ep_path[i];
+        sm.st_pact[e] = P.past_action[i];
+        sm.st_step[e] = (uint32_t)P.ep_step[i];
+        sm.st_ctr[e] = P.rng_ctr[i];
+    }
     for (int k = tid; k < nloc * D; k += kThreads) sm.obs[(k / D) * DP + (k % D)] = R.obs_buf[(size_t)base * D + k];
     const uint32_t step0 = R.step_base ? *R.step_base : 0u;
     const float var = *R.var_ptr;
@@ -1007,7 +1046,8 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
         __syncthreads();
         step_body<NB, EPB, SENS, true, NW>(P, sm, next_env, nullptr, nullptr, R.obs_buf + (tn + N) * D, R.reward + tn, R.done + tn,
                                        R.arrive + tn, R.ended + tn, R.ep_return ? R.ep_return + tn : nullptr,
-                                       R.ep_length ? R.ep_length + tn : nullptr, R.ep_path ? R.ep_path + tn : nullptr);
+                                       R.ep_length ? R.ep_length + tn : nullptr, R.ep_path ? R.ep_path + tn : nullptr,
+                                       t == R.T - 1);
         // the observation tile of step t + 1 is in sm.obs; its store only reads it, like the next policy phase
     }
 }
