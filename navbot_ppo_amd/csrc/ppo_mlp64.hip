@@ -419,39 +419,73 @@ __global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restric
         }
     }
 
-    // ---- workgroup reduction of the 8 waves' partial gradients in LDS, then one coalesced row of `partial`
+    // ---- workgroup reduction of the 8 waves' partial gradients in LDS, then one coalesced row of `partial`.
+    // No atomics (round 1 added all 8 waves' 5.4 k accumulators into one LDS row with ds_add_f32: 8-way same-address
+    // conflicts, ~60 us per launch = 10 % of the epoch): waves 0-3 STORE their accumulators into four private rows, waves 4-7
+    // then ADD theirs on top (wave w + 4 onto row w: every index of a row has exactly one owner lane per wave), then all
+    // threads sum the four rows.  Accumulators that two or four lanes of a wave share (the bias / output-weight sums of the
+    // two sample halves, the loss statistics) are combined with shuffles first.
     __syncthreads();
-    float* red = sm.wv;
-    for (int k = tid; k < P + 4; k += NT) red[k] = 0.f;
-    __syncthreads();
+    constexpr int RP = (P + 3 + 3) & ~3;   // row pitch (floats): P parameters + 3 statistics, a multiple of 4
+    static_assert(4 * RP <= kWWaves * WAVE_F, "reduction rows fit the wave tiles");
+    float s3 = adb3, s4 = adb4, sA = ACTOR ? st0 : st1, sB = st2, sC = st3;   // held per lane (lhi == 0 lanes non-zero)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s3 += __shfl_xor(s3, o, 64); s4 += __shfl_xor(s4, o, 64);
+        sA += __shfl_xor(sA, o, 64); sB += __shfl_xor(sB, o, 64); sC += __shfl_xor(sC, o, 64);
+    }
+    float hb2[2], hw3[2], hw4[2], qb1[4];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
-#pragma unroll
-        for (int t1 = 0; t1 < 2; ++t1)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                atomicAdd(&red[OFF_W2 + (32 * t2 + c_row(r, lane)) * H + 32 * t1 + l31], aW2[t2][t1][r]);
-        atomicAdd(&red[OFF_B2 + 32 * t2 + l31], adb2[t2]);
-        atomicAdd(&red[OFF_W3 + 32 * t2 + l31], adw3[t2]);
-        if (ACTOR) atomicAdd(&red[OFF_W4 + 32 * t2 + l31], adw4[t2]);
+        hb2[t2] = adb2[t2] + __shfl_xor(adb2[t2], 32, 64);
+        hw3[t2] = adw3[t2] + __shfl_xor(adw3[t2], 32, 64);
+        hw4[t2] = adw4[t2] + __shfl_xor(adw4[t2], 32, 64);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+        float v = adb1[u];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        qb1[u] = v;
+    }
+    float* const row = sm.wv + (wave & 3) * RP;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&red[OFF_W1 + (16 * u + 4 * kk + r) * IN + l15], aW1[u][r]);
-        atomicAdd(&red[OFF_B1 + 16 * u + l15], adb1[u]);
+    for (int pass = 0; pass < 2; ++pass) {
+        if ((wave >> 2) == pass) {
+            const bool add = pass == 1;
+            auto put = [&](int idx, float v) { row[idx] = add ? row[idx] + v : v; };
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+                for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) put(OFF_W2 + (32 * t2 + c_row(r, lane)) * H + 32 * t1 + l31, aW2[t2][t1][r]);
+                if (lhi == 0) {
+                    put(OFF_B2 + 32 * t2 + l31, hb2[t2]);
+                    put(OFF_W3 + 32 * t2 + l31, hw3[t2]);
+                    if (ACTOR) put(OFF_W4 + 32 * t2 + l31, hw4[t2]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) put(OFF_W1 + (16 * u + 4 * kk + r) * IN + l15, aW1[u][r]);
+                if (kk == 0) put(OFF_B1 + 16 * u + l15, qb1[u]);
+            }
+            if (lane == 0) {
+                put(OFF_B3, s3);
+                if (ACTOR) put(OFF_B4, s4);
+                put(P + 0, sA);
+                put(P + 1, sB);
+                put(P + 2, sC);
+            }
+        }
+        __syncthreads();
     }
-    if (lhi == 0) {
-        atomicAdd(&red[OFF_B3], adb3);
-        if (ACTOR) atomicAdd(&red[OFF_B4], adb4);
-        atomicAdd(&red[P + 0], ACTOR ? st0 : st1);
-        atomicAdd(&red[P + 1], st2);
-        atomicAdd(&red[P + 2], st3);
-    }
-    __syncthreads();
     float* out = partial + (size_t)blockIdx.x * P;
-    for (int k = tid; k < P; k += NT) out[k] = red[k];
-    if (tid < 3) stats_partial[blockIdx.x * 4 + tid] = red[P + tid];
+    const float* red = sm.wv;
+    for (int k = tid; k < P; k += NT) out[k] = (red[k] + red[RP + k]) + (red[2 * RP + k] + red[3 * RP + k]);
+    if (tid < 3) stats_partial[blockIdx.x * 4 + tid] = (red[P + tid] + red[RP + P + tid]) + (red[2 * RP + P + tid] + red[3 * RP + P + tid]);
 }
 
 // grad[p] += sum over a slice of the workgroups' partial rows ; stats += slice sums * inv_n.  grid = (P/64, kRedSlices):

@@ -264,42 +264,60 @@ class Env:
         self._sim.set_map(seg)
         self._io = self._sim.alloc_io()
         dev = self._sim.device
-        self._act = torch.zeros((1, 2), dtype=torch.float32, device=dev)
-        self._past = torch.zeros((1, 2), dtype=torch.float32, device=dev)
-        self.position = _XY()
-        self.goal_position = _Pose()
-        self.past_distance = 0.0
-        self._sync_attrs()
+        self._ap = torch.zeros((2, 1, 2), dtype=torch.float32, device=dev)     # action | past_action: one H2D copy per step
+        self._ap_host = torch.zeros((2, 1, 2), dtype=torch.float32).pin_memory()
+        self._out = torch.zeros(16 + 3, dtype=torch.float32, device=dev)         # obs | reward | done | arrive: one D2H copy
+        self._state = None   # host copy of pose / goal / past_distance, fetched when an attribute is read
 
-    def _sync_attrs(self):
-        st = self._sim.get_state()
-        self.position = _XY(float(st["pose"][0, 0]), float(st["pose"][0, 1]))
-        self.yaw_rad = float(st["pose"][0, 2])
-        self.goal_position.position.x = float(st["goal"][0, 0])
-        self.goal_position.position.y = float(st["goal"][0, 1])
-        self.past_distance = float(st["past_dist"][0])
+    # -- attributes the reference's callers read (ppo.py:535, main.py:202; environment_new.py:29-41): fetched lazily, one
+    #    navsim_get_state per step at most, and none at all for callers that never look
+    def _st(self):
+        if self._state is None:
+            self._state = self._sim.get_state()
+        return self._state
+
+    @property
+    def position(self):
+        p = self._st()["pose"][0]
+        return _XY(float(p[0]), float(p[1]))
+
+    @property
+    def yaw_rad(self):
+        return float(self._st()["pose"][0, 2])
+
+    @property
+    def goal_position(self):
+        g = self._st()["goal"][0]
+        pose = _Pose()
+        pose.position.x, pose.position.y = float(g[0]), float(g[1])
+        return pose
+
+    @property
+    def past_distance(self):
+        return float(self._st()["past_dist"][0])
 
     def reset(self):
         self._sim.reset(self._io.obs)
-        obs = self._io.obs[0].double().cpu().numpy()
-        self._sync_attrs()
-        return obs
+        self._state = None
+        return self._io.obs[0].double().cpu().numpy()
 
     def step(self, action, past_action):
         a = np.asarray(action, dtype=np.float32).reshape(-1)
         p = np.asarray(past_action, dtype=np.float32).reshape(-1)
         if a.shape[0] < 2 or p.shape[0] < 2:
             raise IndexError("action and past_action need two components")  # as action[1] would in the reference
-        self._act.copy_(torch.from_numpy(a[:2]).view(1, 2))
-        self._past.copy_(torch.from_numpy(p[:2]).view(1, 2))
+        self._ap_host[0, 0, 0], self._ap_host[0, 0, 1] = float(a[0]), float(a[1])
+        self._ap_host[1, 0, 0], self._ap_host[1, 0, 1] = float(p[0]), float(p[1])
+        self._ap.copy_(self._ap_host, non_blocking=True)
         io = self._io
-        self._sim.step(self._act, io.obs, io.reward, io.done, io.arrive, io.ended, None, None, past_action=self._past)
-        obs = io.obs[0].double().cpu().numpy()
-        reward = float(io.reward[0].item())
-        done = bool(io.done[0].item())
-        arrive = bool(io.arrive[0].item())
-        self._sync_attrs()
-        return obs, reward, done, arrive
+        self._sim.step(self._ap[0], io.obs, io.reward, io.done, io.arrive, io.ended, None, None, past_action=self._ap[1])
+        self._out[:16] = io.obs[0]
+        self._out[16] = io.reward[0]
+        self._out[17] = io.done[0]
+        self._out[18] = io.arrive[0]
+        out = self._out.cpu().numpy()          # the step's only synchronisation
+        self._state = None
+        return out[:16].astype(np.float64), float(out[16]), bool(out[17]), bool(out[18])
 
     def getLatestImage(self):
         return None
