@@ -46,6 +46,21 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
                            const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples,
                            float var, float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
 
+/* V = critic(obs).squeeze() (ppo.py:275, :724) for n rows: the forward half of the critic's fused pass.  value_dev [n] f32. */
+int navppo_mlp64_value(const float* critic_params_dev, const float* obs_dev, int64_t n_samples, float* value_dev, void* stream);
+
+/*
+ * One whole update epoch of ppo.py:305-392 on one GPU: navppo_mlp64_loss_grad followed by the two Adam steps of
+ * ppo.py:381,392 (torch.optim.Adam defaults: no weight decay, no amsgrad) applied in place by the kernel that sums the
+ * workgroups' partial gradients.  step = 1, 2, ... (Adam's bias correction); adam_m_dev / adam_v_dev [5378 + 5313] f32 are
+ * the optimiser's moments (zero before the first step).  grad_dev and stats_dev are filled as by navppo_mlp64_loss_grad.
+ * Multi-GPU runs use navppo_mlp64_loss_grad + an all-reduce + their own optimiser step instead.
+ */
+int navppo_mlp64_update_epoch(float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
+                              const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
+                              float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
+                              float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
+
 /*
  * PPO.get_action() (ppo.py:673-706) for all envs of a shard in one launch: mean = actor(obs) (net_actor forward),
  * sample MVN(mean, var*I), clamp a0 to [0,1] and a1 to [-1,1] (ppo.py:700-703), log-prob of the CLAMPED action (:704).

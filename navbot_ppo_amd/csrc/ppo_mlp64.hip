@@ -28,6 +28,7 @@
 // At the end every workgroup writes its partial gradient (one row of `partial`), and `reduce_partials` sums rows.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <string>
 
@@ -92,20 +93,23 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool ACTOR>
+// FWD: forward only (critic): V[m] = critic(obs[m]) is written to v_out and everything behind the output unit is skipped.
+template <bool ACTOR, bool FWD = false>
 __global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restrict__ params, const float* __restrict__ obs,
                                                           const float* __restrict__ act, const float* __restrict__ logp_old,
                                                           const float* __restrict__ rtg, const float* __restrict__ adv,
                                                           long long M, float var, float clip, float inv_n,
                                                           float* __restrict__ partial, float* __restrict__ stats_partial,
-                                                          float* __restrict__ grad_zero, float* __restrict__ stats_zero) {
+                                                          float* __restrict__ grad_zero, float* __restrict__ stats_zero,
+                                                          float* __restrict__ v_out = nullptr) {
+    static_assert(!(FWD && ACTOR), "forward-only pass is the critic's");
     constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
     constexpr int NT = kWThreads;
     __shared__ __attribute__((aligned(16))) SmemW sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15, kk = lane >> 4;
 
-    if (blockIdx.x == 0) {  // the reduction that follows this launch accumulates with atomics: clear its targets here
+    if (!FWD && blockIdx.x == 0) {  // the reduction that follows this launch accumulates with atomics: clear its targets here
         for (int k = tid; k < P; k += NT) grad_zero[k] = 0.f;
         if (tid < 3) stats_zero[tid] = 0.f;
     }
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restric
                 pre_a1 = a.y;
                 pre_lp = logp_old[m];
                 pre_t = adv[m];
-            } else {
+            } else if (!FWD) {
                 pre_t = rtg[m];
             }
         }
@@ -262,6 +266,10 @@ __global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restric
                 }
             z3 += __shfl_xor(z3, 32, 64);
             if (ACTOR) z4 += __shfl_xor(z4, 32, 64);
+            if (FWD) {
+                if (valid && lhi == 0) v_out[tile * 32 + l31] = z3 + b3;   // critic(obs).squeeze(), ppo.py:275,724
+                continue;
+            }
             const float own = (lhi == 0) ? 1.f : 0.f;   // statistics are counted once per sample
             if (valid) {
                 z3 += b3;
@@ -419,6 +427,7 @@ __global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restric
         }
     }
 
+    if (FWD) return;
     // ---- workgroup reduction of the 8 waves' partial gradients in LDS, then one coalesced row of `partial`.
     // No atomics (round 1 added all 8 waves' 5.4 k accumulators into one LDS row with ds_add_f32: 8-way same-address
     // conflicts, ~60 us per launch = 10 % of the epoch): waves 0-3 STORE their accumulators into four private rows, waves 4-7
@@ -520,6 +529,44 @@ __global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__
     }
 }
 
+// Single-GPU epoch: the same row sum, then torch.optim.Adam's update (ppo.py:116-117,381,392; defaults betas (0.9, 0.999),
+// eps 1e-8, no weight decay) applied in place -- one launch instead of reduce + a separate optimiser launch.  One block owns
+// 64 parameters and ALL rows (no atomics): grad[p] is stored, not accumulated.
+__global__ __launch_bounds__(256) void reduce_adam(const float* __restrict__ partial, const float* __restrict__ stats_partial,
+                                                   int n_blocks, int P, float inv_n, float* __restrict__ grad,
+                                                   float* __restrict__ stats, float* __restrict__ params, float* __restrict__ m,
+                                                   float* __restrict__ v, float lr, float beta1, float beta2, float eps,
+                                                   float bc1, float bc2_sqrt) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, p = blockIdx.x * 64 + lane, g = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (p < P) {
+        int b = g;
+        for (; b + 4 < n_blocks; b += 8) {
+            s0 += partial[(size_t)b * P + p];
+            s1 += partial[(size_t)(b + 4) * P + p];
+        }
+        if (b < n_blocks) s0 += partial[(size_t)b * P + p];
+    }
+    part[g][lane] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && p < P) {
+        const float gr = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        grad[p] = gr;
+        const float mm = m[p] + (gr - m[p]) * (1.0f - beta1);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vv = beta2 * v[p] + (1.0f - beta2) * (gr * gr);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        m[p] = mm;
+        v[p] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        params[p] -= (lr / bc1) * (mm / denom);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3) {
+        float s = 0.f;
+        for (int b = 0; b < n_blocks; ++b) s += stats_partial[b * 4 + threadIdx.x];
+        stats[threadIdx.x] = s * inv_n;
+    }
+}
+
 // ---------------------------------------------------------------- rollout-time policy step (PPO.get_action, ppo.py:673-706)
 // PPO.get_action for all envs, one launch: one wave = 16 envs, the policy step itself is mlp64_policy.h (shared with the
 // persistent rollout kernel of navsim.hip so that both produce the same bits)
@@ -591,6 +638,65 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_loss_grad: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+int navppo_mlp64_value(const float* critic_params_dev, const float* obs_dev, int64_t n_samples, float* value_dev, void* stream) {
+    if (!critic_params_dev || !obs_dev || !value_dev || n_samples < 1 || ((uintptr_t)obs_dev & 15)) {
+        g_err = "navppo_mlp64_value: bad argument (obs must be 16-byte aligned)";
+        return -1;
+    }
+    const long long wtiles = (n_samples + 31) / 32;
+    const long long want = (wtiles + kWWaves - 1) / kWWaves;
+    const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
+    hipLaunchKernelGGL((mlp64_pass_w<false, true>), dim3(blocks), dim3(kWThreads), 0, (hipStream_t)stream, critic_params_dev, obs_dev,
+                       nullptr, nullptr, nullptr, nullptr, (long long)n_samples, 1.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr,
+                       value_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_err = std::string("navppo_mlp64_value: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+int navppo_mlp64_update_epoch(float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
+                              const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
+                              float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
+                              float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
+    if (!params_dev || !obs_dev || !act_dev || !logp_old_dev || !rtg_dev || !adv_dev || !grad_dev || !stats_dev ||
+        !workspace_dev || !adam_m_dev || !adam_v_dev || n_samples < 1 || !(var > 0.f) || step < 1) {
+        g_err = "navppo_mlp64_update_epoch: bad argument";
+        return -1;
+    }
+    if (((uintptr_t)obs_dev & 15) || ((uintptr_t)act_dev & 7)) {
+        g_err = "navppo_mlp64_update_epoch: obs must be 16-byte and act 8-byte aligned";
+        return -1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = reinterpret_cast<float*>(workspace_dev);
+    float* stats_partial = partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * NAVPPO_MLP64_ACTOR_PARAMS;
+    const float inv_n = 1.0f / (float)n_samples;
+    const long long wtiles = (n_samples + 31) / 32;
+    const long long want = (wtiles + kWWaves - 1) / kWWaves;
+    const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
+    const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
+    hipLaunchKernelGGL((mlp64_pass_w<true>), dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
+                       rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, grad_dev, stats_dev);
+    hipLaunchKernelGGL(reduce_adam, dim3((P_ACTOR + 63) / 64), dim3(256), 0, st, partial, stats_partial, blocks, P_ACTOR, inv_n,
+                       grad_dev, stats_dev, params_dev, adam_m_dev, adam_v_dev, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+    hipLaunchKernelGGL((mlp64_pass_w<false>), dim3(blocks), dim3(kWThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
+                       logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial,
+                       grad_dev + P_ACTOR, stats_dev + 4);
+    hipLaunchKernelGGL(reduce_adam, dim3((P_CRITIC + 63) / 64), dim3(256), 0, st, partial, stats_partial, blocks, P_CRITIC, inv_n,
+                       grad_dev + P_ACTOR, stats_dev + 4, params_dev + P_ACTOR, adam_m_dev + P_ACTOR, adam_v_dev + P_ACTOR, lr,
+                       beta1, beta2, eps, bc1, bc2_sqrt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_err = std::string("navppo_mlp64_update_epoch: ") + hipGetErrorString(e);
         return -2;
     }
     return 0;

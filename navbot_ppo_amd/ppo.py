@@ -202,6 +202,10 @@ class PPOUpdater:
             self._ws = torch.empty(lib().navppo_mlp64_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
             self._fstats = torch.zeros(8, dtype=torch.float32, device=self.device)
             self._fhist = torch.zeros((max(cfg.n_updates_per_iteration, 1), 8), dtype=torch.float32, device=self.device)
+            # single GPU: Adam runs inside the kernel that sums the partial gradients (navppo_mlp64_update_epoch)
+            self._adam_m = torch.zeros_like(self.fp.flat)
+            self._adam_v = torch.zeros_like(self.fp.flat)
+            self._adam_t = 0
 
     def _fused_loss_grad(self, obs, acts, logp_old, rtg, adv, var, stats=None):
         """evaluate + losses + backward of ppo.py:307-386 in the HIP kernels of csrc/ppo_mlp64.hip; gradients land
@@ -219,11 +223,40 @@ class PPOUpdater:
         if rc != 0:
             raise RuntimeError(f"navppo_mlp64_loss_grad failed: {L.navppo_last_error().decode()}")
 
+    def _fused_value(self, obs):
+        """V = critic(obs).squeeze() (ppo.py:275) by the forward half of the critic's fused pass."""
+        import ctypes as C
+        from ._native import lib
+        L = lib()
+        out = torch.empty(obs.shape[0], dtype=torch.float32, device=obs.device)
+        rc = L.navppo_mlp64_value(C.c_void_p(self.fp.flat.data_ptr() + 4 * 5378), C.c_void_p(obs.data_ptr()), int(obs.shape[0]),
+                                  C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"navppo_mlp64_value failed: {L.navppo_last_error().decode()}")
+        return out
+
+    def _fused_epoch(self, obs, acts, logp_old, rtg, adv, var, stats):
+        """One epoch of ppo.py:305-392 on one GPU: losses, gradients and both Adam steps in four launches."""
+        import ctypes as C
+        from ._native import lib
+        L = lib()
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        self._adam_t += 1
+        rc = L.navppo_mlp64_update_epoch(ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+                                         int(obs.shape[0]), float(var), float(self.cfg.clip), float(self.cfg.lr), 0.9, 0.999, 1e-8,
+                                         int(self._adam_t), ptr(self._adam_m), ptr(self._adam_v), ptr(self.fp.grad), ptr(stats),
+                                         ptr(self._ws), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"navppo_mlp64_update_epoch failed: {L.navppo_last_error().decode()}")
+
     def update(self, obs, acts, logp_old, rtg, var):
         cfg, ctx = self.cfg, self.ctx
         world = ctx.world if ctx is not None else 1
         with torch.no_grad():
-            V0 = self.critic(obs).squeeze(-1)
+            if self.fused_mlp64 and obs.is_contiguous() and obs.data_ptr() % 16 == 0:
+                V0 = self._fused_value(obs)
+            else:
+                V0 = self.critic(obs).squeeze(-1)
             adv = normalise_advantages(rtg - V0, ctx)          # ppo.py:275-284
         n_ep = cfg.n_updates_per_iteration
         a_loss = c_loss = torch.zeros((), device=obs.device)   # n_updates_per_iteration == 0: nothing to report
@@ -237,11 +270,13 @@ class PPOUpdater:
         for ep in range(n_ep):                                 # ppo.py:305
             if self.fused_mlp64:
                 # per-epoch diagnostics land in row ep of a device buffer: no extra launches inside the epoch loop
-                self._fused_loss_grad(obs, acts, logp_old, rtg, adv, var_f, stats=self._fhist[ep])
                 if world > 1:
+                    self._fused_loss_grad(obs, acts, logp_old, rtg, adv, var_f, stats=self._fhist[ep])
                     ctx.all_reduce_sum(self.fp.grad)
                     self.fp.grad.div_(world)
-                self.opt.step()
+                    self.opt.step()
+                else:
+                    self._fused_epoch(obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
                 if ep == n_ep - 1:
                     h = self._fhist[:n_ep]
                     self.loss_history = h[:, [0, 4]].clone()

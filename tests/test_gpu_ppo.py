@@ -253,3 +253,18 @@ def test_persistent_rollout_equals_per_step_rollout(N, T, per_env):
             assert torch.equal(x, y)
     for k in sa:
         np.testing.assert_array_equal(sa[k], sb[k])
+
+
+def test_fused_value_matches_pytorch_critic():
+    from navbot_ppo_amd import nets, ppo
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    a, c = nets.make_policy("mlp64x2")
+    a.to(dev), c.to(dev)
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(policy="mlp64x2"), None, dev)
+    for n in (1, 31, 1000, 128 * 300 + 7):
+        obs = torch.rand((n, 16), device=dev) * 2 - 0.5
+        with torch.no_grad():
+            want = c(obs).squeeze(-1)
+        got = up._fused_value(obs)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
