@@ -84,6 +84,7 @@ struct SmemW {
     float wv[kWWaves * WAVE_F];
 };
 static_assert(sizeof(SmemW) <= 160 * 1024, "LDS");
+static_assert(2 * kWMaxBlocks <= NAVPPO_MLP64_MAX_BLOCKS, "workspace rows for both nets");
 static_assert(kWWaves * WAVE_F >= P_ACTOR + 4, "reduction buffer");
 
 __device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -95,17 +96,16 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // FWD: forward only (critic): V[m] = critic(obs[m]) is written to v_out and everything behind the output unit is skipped.
 template <bool ACTOR, bool FWD = false>
-__global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restrict__ params, const float* __restrict__ obs,
-                                                          const float* __restrict__ act, const float* __restrict__ logp_old,
-                                                          const float* __restrict__ rtg, const float* __restrict__ adv,
-                                                          long long M, float var, float clip, float inv_n,
-                                                          float* __restrict__ partial, float* __restrict__ stats_partial,
-                                                          float* __restrict__ grad_zero, float* __restrict__ stats_zero,
-                                                          float* __restrict__ v_out = nullptr) {
+__device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ params, const float* __restrict__ obs,
+                                          const float* __restrict__ act, const float* __restrict__ logp_old,
+                                          const float* __restrict__ rtg, const float* __restrict__ adv,
+                                          long long M, float var, float clip, float inv_n,
+                                          float* __restrict__ partial, float* __restrict__ stats_partial,
+                                          float* __restrict__ grad_zero, float* __restrict__ stats_zero,
+                                          float* __restrict__ v_out = nullptr) {
     static_assert(!(FWD && ACTOR), "forward-only pass is the critic's");
     constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
     constexpr int NT = kWThreads;
-    __shared__ __attribute__((aligned(16))) SmemW sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15, kk = lane >> 4;
 
@@ -497,6 +497,34 @@ __global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restric
     if (tid < 3) stats_partial[blockIdx.x * 4 + tid] = (red[P + tid] + red[RP + P + tid]) + (red[2 * RP + P + tid] + red[3 * RP + P + tid]);
 }
 
+template <bool ACTOR, bool FWD = false>
+__global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restrict__ params, const float* __restrict__ obs,
+                                                          const float* __restrict__ act, const float* __restrict__ logp_old,
+                                                          const float* __restrict__ rtg, const float* __restrict__ adv,
+                                                          long long M, float var, float clip, float inv_n,
+                                                          float* __restrict__ partial, float* __restrict__ stats_partial,
+                                                          float* __restrict__ grad_zero, float* __restrict__ stats_zero,
+                                                          float* __restrict__ v_out = nullptr) {
+    __shared__ __attribute__((aligned(16))) SmemW sm;
+    pass_body<ACTOR, FWD>(sm, params, obs, act, logp_old, rtg, adv, M, var, clip, inv_n, partial, stats_partial, grad_zero,
+                          stats_zero, v_out);
+}
+
+// both nets of one epoch in one launch (single-GPU path): the actor's tiles, then the critic's, by the same workgroups
+__global__ __launch_bounds__(kWThreads) void mlp64_pass_both(const float* __restrict__ params, const float* __restrict__ obs,
+                                                             const float* __restrict__ act, const float* __restrict__ logp_old,
+                                                             const float* __restrict__ rtg, const float* __restrict__ adv,
+                                                             long long M, float var, float clip, float inv_n,
+                                                             float* __restrict__ partial_a, float* __restrict__ stats_partial_a,
+                                                             float* __restrict__ partial_c, float* __restrict__ stats_partial_c,
+                                                             float* __restrict__ grad, float* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) SmemW sm;
+    pass_body<true>(sm, params, obs, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_a, stats_partial_a, grad, stats);
+    __syncthreads();
+    pass_body<false>(sm, params + P_ACTOR, obs, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_c, stats_partial_c,
+                     grad + P_ACTOR, stats + 4);
+}
+
 // grad[p] += sum over a slice of the workgroups' partial rows ; stats += slice sums * inv_n.  grid = (P/64, kRedSlices):
 // block = 64 parameters x 4 row groups of one slice; rows are read 256 B per wave; one atomicAdd per parameter per slice
 // (grad / stats were zeroed by workgroup 0 of the pass kernel that produced the partials).
@@ -529,18 +557,21 @@ __global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__
     }
 }
 
-// Single-GPU epoch: the same row sum, then torch.optim.Adam's update (ppo.py:116-117,381,392; defaults betas (0.9, 0.999),
-// eps 1e-8, no weight decay) applied in place -- one launch instead of reduce + a separate optimiser launch.  One block owns
-// 64 parameters and ALL rows (no atomics): grad[p] is stored, not accumulated.
-__global__ __launch_bounds__(256) void reduce_adam(const float* __restrict__ partial, const float* __restrict__ stats_partial,
-                                                   int n_blocks, int P, float inv_n, float* __restrict__ grad,
-                                                   float* __restrict__ stats, float* __restrict__ params, float* __restrict__ m,
-                                                   float* __restrict__ v, float lr, float beta1, float beta2, float eps,
-                                                   float bc1, float bc2_sqrt) {
+// Single-GPU epoch: the same row sum for BOTH nets, then torch.optim.Adam's update (ppo.py:116-117,381,392; defaults betas
+// (0.9, 0.999), eps 1e-8, no weight decay) applied in place -- one launch instead of two reductions + an optimiser launch.
+// One block owns 64 parameters and ALL rows (no atomics): grad[p] is stored, not accumulated.
+__global__ __launch_bounds__(256) void reduce_adam(const float* __restrict__ partial_a, const float* __restrict__ stats_partial_a,
+                                                   const float* __restrict__ partial_c, const float* __restrict__ stats_partial_c,
+                                                   int n_blocks, float inv_n, float* __restrict__ grad, float* __restrict__ stats,
+                                                   float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
+                                                   float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
     __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, p = blockIdx.x * 64 + lane, g = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, q = blockIdx.x * 64 + lane, g = threadIdx.x >> 6;   // q: index into actor | critic
+    const bool actor = q < P_ACTOR;
+    const float* __restrict__ partial = actor ? partial_a : partial_c;
+    const int P = actor ? P_ACTOR : P_CRITIC, p = actor ? q : q - P_ACTOR;
     float s0 = 0.f, s1 = 0.f;
-    if (p < P) {
+    if (q < P_ACTOR + P_CRITIC) {
         int b = g;
         for (; b + 4 < n_blocks; b += 8) {
             s0 += partial[(size_t)b * P + p];
@@ -550,19 +581,20 @@ __global__ __launch_bounds__(256) void reduce_adam(const float* __restrict__ par
     }
     part[g][lane] = s0 + s1;
     __syncthreads();
-    if (g == 0 && p < P) {
+    if (g == 0 && q < P_ACTOR + P_CRITIC) {
         const float gr = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-        grad[p] = gr;
-        const float mm = m[p] + (gr - m[p]) * (1.0f - beta1);          // exp_avg.lerp_(grad, 1 - beta1)
-        const float vv = beta2 * v[p] + (1.0f - beta2) * (gr * gr);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        m[p] = mm;
-        v[p] = vv;
+        grad[q] = gr;
+        const float mm = m[q] + (gr - m[q]) * (1.0f - beta1);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vv = beta2 * v[q] + (1.0f - beta2) * (gr * gr);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        m[q] = mm;
+        v[q] = vv;
         const float denom = sqrtf(vv) / bc2_sqrt + eps;
-        params[p] -= (lr / bc1) * (mm / denom);
+        params[q] -= (lr / bc1) * (mm / denom);
     }
-    if (blockIdx.x == 0 && threadIdx.x < 3) {
+    if (blockIdx.x == 0 && threadIdx.x < 8 && (threadIdx.x & 3) < 3) {   // stats[0..2] actor, stats[4..6] critic
+        const float* sp = (threadIdx.x < 4) ? stats_partial_a : stats_partial_c;
         float s = 0.f;
-        for (int b = 0; b < n_blocks; ++b) s += stats_partial[b * 4 + threadIdx.x];
+        for (int b = 0; b < n_blocks; ++b) s += sp[b * 4 + (threadIdx.x & 3)];
         stats[threadIdx.x] = s * inv_n;
     }
 }
@@ -684,16 +716,14 @@ int navppo_mlp64_update_epoch(float* params_dev, const float* obs_dev, const flo
     const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
     const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
     const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
-    hipLaunchKernelGGL((mlp64_pass_w<true>), dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
-                       rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, grad_dev, stats_dev);
-    hipLaunchKernelGGL(reduce_adam, dim3((P_ACTOR + 63) / 64), dim3(256), 0, st, partial, stats_partial, blocks, P_ACTOR, inv_n,
-                       grad_dev, stats_dev, params_dev, adam_m_dev, adam_v_dev, lr, beta1, beta2, eps, bc1, bc2_sqrt);
-    hipLaunchKernelGGL((mlp64_pass_w<false>), dim3(blocks), dim3(kWThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
-                       logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial,
-                       grad_dev + P_ACTOR, stats_dev + 4);
-    hipLaunchKernelGGL(reduce_adam, dim3((P_CRITIC + 63) / 64), dim3(256), 0, st, partial, stats_partial, blocks, P_CRITIC, inv_n,
-                       grad_dev + P_ACTOR, stats_dev + 4, params_dev + P_ACTOR, adam_m_dev + P_ACTOR, adam_v_dev + P_ACTOR, lr,
-                       beta1, beta2, eps, bc1, bc2_sqrt);
+    float* partial_c = partial + (size_t)kWMaxBlocks * P_ACTOR;        // the workspace has NAVPPO_MLP64_MAX_BLOCKS = 2 kWMaxBlocks rows
+    float* stats_partial_c = stats_partial + (size_t)kWMaxBlocks * 4;
+    hipLaunchKernelGGL(mlp64_pass_both, dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev,
+                       adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, partial_c, stats_partial_c, grad_dev,
+                       stats_dev);
+    hipLaunchKernelGGL(reduce_adam, dim3((P_ACTOR + P_CRITIC + 63) / 64), dim3(256), 0, st, partial, stats_partial, partial_c,
+                       stats_partial_c, blocks, inv_n, grad_dev, stats_dev, params_dev, adam_m_dev, adam_v_dev, lr, beta1, beta2, eps,
+                       bc1, bc2_sqrt);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_update_epoch: ") + hipGetErrorString(e);
