@@ -46,6 +46,13 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
                            const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples,
                            float var, float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
 
+/*
+ * torch.optim.Adam's step (defaults: no weight decay, no amsgrad) on a flat buffer with the gradient scaled first: the
+ * multi-GPU epoch is navppo_mlp64_loss_grad -> all-reduce(sum) of grad_dev over RCCL -> navppo_adam_step(grad_scale = 1 / world).
+ */
+int navppo_adam_step(float* params_dev, const float* grad_dev, float* adam_m_dev, float* adam_v_dev, int64_t n, float grad_scale,
+                     float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
 /* V = critic(obs).squeeze() (ppo.py:275, :724) for n rows: the forward half of the critic's fused pass.  value_dev [n] f32. */
 int navppo_mlp64_value(const float* critic_params_dev, const float* obs_dev, int64_t n_samples, float* value_dev, void* stream);
 

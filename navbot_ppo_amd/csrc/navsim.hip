@@ -48,7 +48,6 @@ constexpr float kRangeMin = 0.12f, kRangeMax = 3.5f;             // gazebo.xacro
 constexpr int kSubsteps = 6;     // 30 Hz drive updates per 5 Hz scan (gazebo.xacro:62,107)
 constexpr int kMaxRects = 16;
 constexpr int kMaxGoalTries = 64;
-constexpr int kSegTile = 2048;   // shared-map LDS tile: 2048 segments = 32 KiB
 
 thread_local std::string g_err;
 

@@ -25,7 +25,7 @@
 //   B2  dH1 = (dH2 W2) . [H1 > 0]   [32x64]x[64x64]     ; db1
 //   G2  dW2 += dH2^T H1             [64x32]x[32x64]     accumulators persist over the wave's tiles
 //   G1  dW1 += dH1^T X              [64x32]x[32x16]
-// At the end every workgroup writes its partial gradient (one row of `partial`), and `reduce_partials` sums rows.
+// At the end every workgroup writes its partial gradient (one row of `partial`), and `reduce_adam` sums rows.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -109,10 +109,8 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15, kk = lane >> 4;
 
-    if (!FWD && blockIdx.x == 0) {  // the reduction that follows this launch accumulates with atomics: clear its targets here
-        for (int k = tid; k < P; k += NT) grad_zero[k] = 0.f;
-        if (tid < 3) stats_zero[tid] = 0.f;
-    }
+    (void)grad_zero;
+    (void)stats_zero;
     for (int k = tid; k < H * IN; k += NT) sm.W1s[(k / IN) * LW1 + (k % IN)] = params[OFF_W1 + k];
     for (int k = tid; k < H * H; k += NT) {
         const float w = params[OFF_W2 + k];
@@ -525,41 +523,10 @@ __global__ __launch_bounds__(kWThreads) void mlp64_pass_both(const float* __rest
                      grad + P_ACTOR, stats + 4);
 }
 
-// grad[p] += sum over a slice of the workgroups' partial rows ; stats += slice sums * inv_n.  grid = (P/64, kRedSlices):
-// block = 64 parameters x 4 row groups of one slice; rows are read 256 B per wave; one atomicAdd per parameter per slice
-// (grad / stats were zeroed by workgroup 0 of the pass kernel that produced the partials).
-constexpr int kRedSlices = 8;
-
-__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ partial, const float* __restrict__ stats_partial,
-                                                       int n_blocks, int P, float inv_n, float* __restrict__ grad,
-                                                       float* __restrict__ stats) {
-    __shared__ float part[4][64];
-    const int p = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    const int per = (n_blocks + kRedSlices - 1) / kRedSlices;
-    const int b_lo = blockIdx.y * per, b_hi = min(n_blocks, b_lo + per);
-    float s0 = 0.f, s1 = 0.f;
-    if (p < P) {
-        int b = b_lo + g;
-        for (; b + 4 < b_hi; b += 8) {
-            s0 += partial[(size_t)b * P + p];
-            s1 += partial[(size_t)(b + 4) * P + p];
-        }
-        if (b < b_hi) s0 += partial[(size_t)b * P + p];
-    }
-    part[g][threadIdx.x & 63] = s0 + s1;
-    __syncthreads();
-    if (g == 0 && p < P)
-        atomicAdd(&grad[p], (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
-    if (blockIdx.x == 0 && threadIdx.x < 3) {
-        float s = 0.f;
-        for (int b = b_lo; b < b_hi; ++b) s += stats_partial[b * 4 + threadIdx.x];
-        atomicAdd(&stats[threadIdx.x], s * inv_n);
-    }
-}
-
-// Single-GPU epoch: the same row sum for BOTH nets, then torch.optim.Adam's update (ppo.py:116-117,381,392; defaults betas
+// grad[p] = sum over the workgroups' partial rows, for BOTH nets; ADAM (single-GPU epoch): then torch.optim.Adam's update (ppo.py:116-117,381,392; defaults betas
 // (0.9, 0.999), eps 1e-8, no weight decay) applied in place -- one launch instead of two reductions + an optimiser launch.
 // One block owns 64 parameters and ALL rows (no atomics): grad[p] is stored, not accumulated.
+template <bool ADAM>
 __global__ __launch_bounds__(256) void reduce_adam(const float* __restrict__ partial_a, const float* __restrict__ stats_partial_a,
                                                    const float* __restrict__ partial_c, const float* __restrict__ stats_partial_c,
                                                    int n_blocks, float inv_n, float* __restrict__ grad, float* __restrict__ stats,
@@ -584,12 +551,14 @@ __global__ __launch_bounds__(256) void reduce_adam(const float* __restrict__ par
     if (g == 0 && q < P_ACTOR + P_CRITIC) {
         const float gr = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
         grad[q] = gr;
-        const float mm = m[q] + (gr - m[q]) * (1.0f - beta1);          // exp_avg.lerp_(grad, 1 - beta1)
-        const float vv = beta2 * v[q] + (1.0f - beta2) * (gr * gr);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        m[q] = mm;
-        v[q] = vv;
-        const float denom = sqrtf(vv) / bc2_sqrt + eps;
-        params[q] -= (lr / bc1) * (mm / denom);
+        if (ADAM) {
+            const float mm = m[q] + (gr - m[q]) * (1.0f - beta1);          // exp_avg.lerp_(grad, 1 - beta1)
+            const float vv = beta2 * v[q] + (1.0f - beta2) * (gr * gr);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+            m[q] = mm;
+            v[q] = vv;
+            const float denom = sqrtf(vv) / bc2_sqrt + eps;
+            params[q] -= (lr / bc1) * (mm / denom);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < 8 && (threadIdx.x & 3) < 3) {   // stats[0..2] actor, stats[4..6] critic
         const float* sp = (threadIdx.x < 4) ? stats_partial_a : stats_partial_c;
@@ -597,6 +566,20 @@ __global__ __launch_bounds__(256) void reduce_adam(const float* __restrict__ par
         for (int b = 0; b < n_blocks; ++b) s += sp[b * 4 + (threadIdx.x & 3)];
         stats[threadIdx.x] = s * inv_n;
     }
+}
+
+// torch.optim.Adam's update on a flat buffer, gradient pre-scaled (multi-GPU: grad = all-reduced sum x 1 / world)
+__global__ void adam_step_kernel(float* __restrict__ params, const float* __restrict__ grad, float* __restrict__ m,
+                                 float* __restrict__ v, int n, float grad_scale, float lr, float beta1, float beta2, float eps,
+                                 float bc1, float bc2_sqrt) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const float gr = grad[q] * grad_scale;
+    const float mm = m[q] + (gr - m[q]) * (1.0f - beta1);
+    const float vv = beta2 * v[q] + (1.0f - beta2) * (gr * gr);
+    m[q] = mm;
+    v[q] = vv;
+    params[q] -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
 }
 
 // ---------------------------------------------------------------- rollout-time policy step (PPO.get_action, ppo.py:673-706)
@@ -658,18 +641,34 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
     const long long wtiles = (n_samples + 31) / 32;
     const long long want = (wtiles + kWWaves - 1) / kWWaves;
     const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
-    hipLaunchKernelGGL((mlp64_pass_w<true>), dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev,
-                       rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, grad_dev, stats_dev);
-    hipLaunchKernelGGL(reduce_partials, dim3((P_ACTOR + 63) / 64, kRedSlices), dim3(256), 0, st, partial, stats_partial, blocks,
-                       P_ACTOR, inv_n, grad_dev, stats_dev);
-    hipLaunchKernelGGL((mlp64_pass_w<false>), dim3(blocks), dim3(kWThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev,
-                       logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial,
-                       grad_dev + P_ACTOR, stats_dev + 4);
-    hipLaunchKernelGGL(reduce_partials, dim3((P_CRITIC + 63) / 64, kRedSlices), dim3(256), 0, st, partial, stats_partial, blocks,
-                       P_CRITIC, inv_n, grad_dev + P_ACTOR, stats_dev + 4);
+    float* partial_c = partial + (size_t)kWMaxBlocks * P_ACTOR;        // the workspace has NAVPPO_MLP64_MAX_BLOCKS = 2 kWMaxBlocks rows
+    float* stats_partial_c = stats_partial + (size_t)kWMaxBlocks * 4;
+    hipLaunchKernelGGL(mlp64_pass_both, dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev,
+                       adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, partial_c, stats_partial_c, grad_dev,
+                       stats_dev);
+    hipLaunchKernelGGL(reduce_adam<false>, dim3((P_ACTOR + P_CRITIC + 63) / 64), dim3(256), 0, st, partial, stats_partial, partial_c,
+                       stats_partial_c, blocks, inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_loss_grad: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+int navppo_adam_step(float* params_dev, const float* grad_dev, float* adam_m_dev, float* adam_v_dev, int64_t n, float grad_scale,
+                     float lr, float beta1, float beta2, float eps, int32_t step, void* stream) {
+    if (!params_dev || !grad_dev || !adam_m_dev || !adam_v_dev || n < 1 || step < 1) {
+        g_err = "navppo_adam_step: bad argument";
+        return -1;
+    }
+    const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params_dev, grad_dev,
+                       adam_m_dev, adam_v_dev, (int)n, grad_scale, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_err = std::string("navppo_adam_step: ") + hipGetErrorString(e);
         return -2;
     }
     return 0;
@@ -721,7 +720,7 @@ int navppo_mlp64_update_epoch(float* params_dev, const float* obs_dev, const flo
     hipLaunchKernelGGL(mlp64_pass_both, dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev,
                        adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, partial_c, stats_partial_c, grad_dev,
                        stats_dev);
-    hipLaunchKernelGGL(reduce_adam, dim3((P_ACTOR + P_CRITIC + 63) / 64), dim3(256), 0, st, partial, stats_partial, partial_c,
+    hipLaunchKernelGGL(reduce_adam<true>, dim3((P_ACTOR + P_CRITIC + 63) / 64), dim3(256), 0, st, partial, stats_partial, partial_c,
                        stats_partial_c, blocks, inv_n, grad_dev, stats_dev, params_dev, adam_m_dev, adam_v_dev, lr, beta1, beta2, eps,
                        bc1, bc2_sqrt);
     hipError_t e = hipGetLastError();

@@ -223,6 +223,18 @@ class PPOUpdater:
         if rc != 0:
             raise RuntimeError(f"navppo_mlp64_loss_grad failed: {L.navppo_last_error().decode()}")
 
+    def _fused_adam(self, grad_scale):
+        import ctypes as C
+        from ._native import lib
+        L = lib()
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        self._adam_t += 1
+        rc = L.navppo_adam_step(ptr(self.fp.flat), ptr(self.fp.grad), ptr(self._adam_m), ptr(self._adam_v), int(self.fp.numel),
+                                float(grad_scale), float(self.cfg.lr), 0.9, 0.999, 1e-8, int(self._adam_t),
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"navppo_adam_step failed: {L.navppo_last_error().decode()}")
+
     def _fused_value(self, obs):
         """V = critic(obs).squeeze() (ppo.py:275) by the forward half of the critic's fused pass."""
         import ctypes as C
@@ -270,11 +282,10 @@ class PPOUpdater:
         for ep in range(n_ep):                                 # ppo.py:305
             if self.fused_mlp64:
                 # per-epoch diagnostics land in row ep of a device buffer: no extra launches inside the epoch loop
-                if world > 1:
+                if world > 1:   # fused passes -> ONE all-reduce of the flat gradient (RCCL) -> scale + Adam in one launch
                     self._fused_loss_grad(obs, acts, logp_old, rtg, adv, var_f, stats=self._fhist[ep])
                     ctx.all_reduce_sum(self.fp.grad)
-                    self.fp.grad.div_(world)
-                    self.opt.step()
+                    self._fused_adam(1.0 / world)
                 else:
                     self._fused_epoch(obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
                 if ep == n_ep - 1:

@@ -268,3 +268,47 @@ def test_fused_value_matches_pytorch_critic():
             want = c(obs).squeeze(-1)
         got = up._fused_value(obs)
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def _dp_gpu_worker(rank, world, port, path):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      NAVBOT_DIST_BACKEND="gloo")   # RCCL refuses two ranks on one device: gloo carries the all-reduce here
+    from navbot_ppo_amd import nets, ppo
+    ctx = ppo.DistCtx(device="cuda:0")
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_update.npz"))
+    torch.manual_seed(100 + rank)
+    a, c = nets.make_policy("mlp64x2")
+    a.cuda(), c.cuda()
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(n_updates_per_iteration=5, policy="mlp64x2"), ctx, torch.device("cuda:0"))
+    assert up.fused_mlp64
+    lo, hi = ctx.shard(512)
+    cu = lambda k: torch.from_numpy(d[k][lo:hi]).cuda()
+    up.update(cu("obs"), cu("acts"), cu("logp"), cu("rtgs"), torch.tensor(0.8, device="cuda"))
+    torch.save({"flat": up.fp.flat.cpu()}, f"{path}.{rank}")
+    ctx.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_fused_multi_rank_epoch_equals_single_rank(tmp_path):
+    """The N > 1 update path on the GPU (fused passes -> one all-reduce of the flat gradient -> scale + Adam kernel) with two
+    ranks on shards of the G7 batch == the single-rank path (fused passes + in-kernel Adam) on the whole batch."""
+    import socket
+    import torch.multiprocessing as mp
+    from navbot_ppo_amd import nets, ppo
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    path = str(tmp_path / "dpg")
+    mp.spawn(_dp_gpu_worker, args=(2, port, path), nprocs=2, join=True)
+    r0, r1 = torch.load(path + ".0"), torch.load(path + ".1")
+    assert torch.equal(r0["flat"], r1["flat"])
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_update.npz"))
+    torch.manual_seed(100)
+    a, c = nets.make_policy("mlp64x2")
+    a.cuda(), c.cuda()
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(n_updates_per_iteration=5, policy="mlp64x2"), None, torch.device("cuda:0"))
+    cu = lambda k: torch.from_numpy(d[k]).cuda()
+    up.update(cu("obs"), cu("acts"), cu("logp"), cu("rtgs"), torch.tensor(0.8, device="cuda"))
+    np.testing.assert_allclose(r0["flat"].numpy(), up.fp.flat.cpu().numpy(), rtol=0, atol=3e-6)
