@@ -453,7 +453,7 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     // headings and the final heading), so the pose phase costs one sincos latency instead of seven.
     // Lane r == 0 of each group owns the env's float64 state across the phases.  EPB envs -> EPB/8 waves (0, 1).
     constexpr int PW = (EPB + 7) / 8;          // pose waves
-    static_assert(PW <= 2, "pose lanes live in waves 0 and 1");
+    static_assert(PW < NW, "pose waves + at least one ray wave");
     double x = 0, y = 0, th = 0, gx = 0, gy = 0, pdist = 0, dist = 0, yaw = 0, rel_theta = 0, diff = 0, ret0 = 0, path0 = 0;
     float2 act = make_float2(0.f, 0.f), pact = make_float2(0.f, 0.f);
     uint32_t ctr = 0, stepw = 0;
@@ -469,8 +469,15 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     constexpr int kSpecWave = PW - 1;
     constexpr int kSpecLane0 = (PW == 1) ? EPB : 0;
     const int n_rec = P.respawn ? 2 : 1;
-    const int sl = lane - kSpecLane0;                         // spec lane index: record (sl / EPB), env (sl % EPB)
-    const bool spec_lane = (wave == kSpecWave) && (sl >= 0) && (sl < n_rec * EPB) && ((sl % EPB) < nloc);
+    // spec lanes: record spec_c of env spec_e.  Both records of every env share the last pose wave when they fit (2 EPB lanes),
+    // else (EPB = 64) record c takes pose wave PW - 2 + c
+    constexpr bool kSpecTwoWaves = (kSpecLane0 + 2 * EPB > 64);
+    static_assert(!kSpecTwoWaves || PW >= 2, "two spec waves");
+    const int sl = lane - kSpecLane0;
+    const int spec_c = kSpecTwoWaves ? wave - (PW - 2) : sl / EPB;
+    const int spec_e = kSpecTwoWaves ? lane : sl % EPB;
+    const bool spec_lane = (kSpecTwoWaves ? (wave == PW - 2 || wave == PW - 1) : (wave == kSpecWave && sl >= 0)) &&
+                           (spec_c >= 0) && (spec_c < n_rec) && (spec_e < EPB) && (spec_e < nloc);
 
     // ---- cast geometry: lane -> (env of the pass, segment of the tile)
     const int spl = P.seg_pack_log2;            // log2(lanes per env in one pass): 6, smaller when the map has <= 32 segments
@@ -617,9 +624,9 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     // timeout (and by arrival when respawn_on_arrive is off), record 1 for an end by arrival after the arrival re-spawn
     // draw of :245-253.  Records live in HBM; kRecValid in the env's ep_step word says they match its draw counter.
     // A spec lane of an env whose flag is clear (it was reset, or its goal stream moved) recomputes and stores them.
-    const bool spec = spec_lane && (P.auto_reset || (sl >= EPB));
+    const bool spec = spec_lane && (P.auto_reset || (spec_c == 1));
     if (own || spec) {
-        const int e = own ? lane : sl % EPB;
+        const int e = own ? lane : spec_e;
         const int ie = base + e;
         if (own) {
             const double px = sm.sv_d[0][e], py = sm.sv_d[1][e], tgx = sm.sv_d[3][e], tgy = sm.sv_d[4][e];
@@ -632,7 +639,7 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             dist = hypot(tgx - px, tgy - py);  // environment_new.py:203 ; getGoalDistace, :116-120
             sm.sv_d[6][e] = dist; sm.sv_d[7][e] = yaw; sm.sv_d[8][e] = rel_theta; sm.sv_d[9][e] = diff;
         } else {
-            const int c = sl / EPB;
+            const int c = spec_c;
             const size_t N = (size_t)P.N;
             double px = 0, py = 0, pth = 0, tgx = 0, tgy = 0, rgx = 0, rgy = 0, rdist = 0;
             float4 tl = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -948,16 +955,16 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     }
 }
 
-template <int NB, int EPB, bool SENS>
-__global__ __launch_bounds__(kThreads4) void step_kernel(Params P, const float2* __restrict__ action,
+template <int NB, int EPB, bool SENS, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void step_kernel(Params P, const float2* __restrict__ action,
                                                         const float2* __restrict__ past_override,
                                                         void* __restrict__ obs_out, float* __restrict__ reward,
                                                         uint8_t* __restrict__ done, uint8_t* __restrict__ arrive,
                                                         uint8_t* __restrict__ ended, float* __restrict__ ep_return,
                                                         int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out) {
-    __shared__ StepSmem<NB, EPB> sm;
+    __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
-    step_body<NB, EPB, SENS, false>(P, sm, next_env, action, past_override, obs_out, reward, done, arrive, ended, ep_return,
+    step_body<NB, EPB, SENS, false, NW>(P, sm, next_env, action, past_override, obs_out, reward, done, arrive, ended, ep_return,
                                     ep_length, ep_path_out);
 }
 
@@ -1244,20 +1251,35 @@ struct navsim {
     bool has_map = false;
 };
 
-int g_epb = 16;  // envs per workgroup (NAVSIM_EPB = 8 | 16; tuning knob)
+int g_epb = 0;   // envs per workgroup: 0 = by shard size (below); NAVSIM_EPB = 8 | 16 | 32 | 64 forces one (tuning knob)
+
+// Envs per workgroup.  Bigger workgroups make the float64 lanes of the geometry / rules phases denser (a wave instruction
+// costs the same with 16 or 64 active lanes) and start fewer workgroups, but need N / EPB >= the number of CUs to fill the
+// chip: measured (tools/time_step.py) 16384 envs: 18.5 / 16.7 / 15.9 us with 16 / 32 / 64; 8192: 69.8 / 64.8 / 73.9; 4096: 8.9 / 8.6 / 9.8.
+static int pick_epb(int n_envs) {
+    if (g_epb) return g_epb;
+    return n_envs >= 16384 ? 64 : (n_envs >= 4096 ? 32 : 16);
+}
 
 template <int NB>
 static void launch_step(const navsim* h, const float* action, const float* past, void* obs, float* reward, uint8_t* done,
                         uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len, float* ep_path, hipStream_t st) {
     const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
-    auto go = [&](auto kernel, int epb) {
-        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(kThreads4), 0, st, h->P, (const float2*)action,
+    auto go = [&](auto kernel, int epb, int nw) {
+        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, h->P, (const float2*)action,
                            (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len, ep_path);
     };
-    if (g_epb == 8) {
-        if (sens) go(step_kernel<NB, 8, true>, 8); else go(step_kernel<NB, 8, false>, 8);
+    const int epb = pick_epb(h->P.N);
+    if (epb == 8) {
+        if (sens) go(step_kernel<NB, 8, true>, 8, 4); else go(step_kernel<NB, 8, false>, 8, 4);
+    } else if (epb == 32 || (epb == 64 && NB > 10)) {   // 8-wave workgroups of 32 envs: float64 geometry / rules lanes twice as dense
+        if (sens) go(step_kernel<NB, 32, true, 8>, 32, 8); else go(step_kernel<NB, 32, false, 8>, 32, 8);
+    } else if (epb == 64) {   // 16-wave workgroups of 64 envs (10 beams: the 36-beam tile does not fit the LDS)
+        if constexpr (NB == 10) {
+            if (sens) go(step_kernel<NB, 64, true, 16>, 64, 16); else go(step_kernel<NB, 64, false, 16>, 64, 16);
+        }
     } else {
-        if (sens) go(step_kernel<NB, 16, true>, 16); else go(step_kernel<NB, 16, false>, 16);
+        if (sens) go(step_kernel<NB, 16, true>, 16, 4); else go(step_kernel<NB, 16, false>, 16, 4);
     }
 }
 
@@ -1388,7 +1410,7 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
 
     if (const char* e = std::getenv("NAVSIM_EPB")) {
         const int v = std::atoi(e);
-        if (v == 8 || v == 16) g_epb = v;
+        if (v == 8 || v == 16 || v == 32 || v == 64) g_epb = v;
     }
     navsim* h = new navsim();
     const int rc = init_handle(h, cfg);

@@ -650,3 +650,29 @@ def test_g10_reference_rollout_through_the_kernel():
                    float(d["gamma"])).cpu().numpy()[:, 0]
     check_against_g10(d, obs, rew, ended, flags, eplen, epret, eppath, rtg)
     assert int(sim.get_state()["rng_ctr"][0]) == int(d["rng_ctr_final"])
+
+
+@pytest.mark.parametrize("epb", [8, 32, 64])
+def test_workgroup_shapes_keep_parity(epb, monkeypatch):
+    """The step kernel picks 16 / 32 / 64 envs per workgroup (4 / 8 / 16 waves) by shard size; NAVSIM_EPB forces one.  Every
+    shape must reproduce the oracle: auto-reset with the cached next-episode records, per-env maps, and the
+    respawn-on-arrive mode (two records per env: with 64 envs per workgroup they live on two spec waves)."""
+    monkeypatch.setenv("NAVSIM_EPB", str(epb))
+    rng = np.random.default_rng(50 + epb)
+    N = 200   # ragged against every shape
+    gpu, cpu = _mk(N, maps.stage_1(), max_episode_steps=30, auto_reset=True, seed=4)
+    st = _lockstep(gpu, cpu, _actions(rng, 80, N))
+    assert st["ended"] > N
+    seg = maps.replicate_per_env(maps.stage_2(), N, seed=5)
+    gpu, cpu = _mk(N, seg, per_env=True, max_episode_steps=25, auto_reset=True, seed=6)
+    _lockstep(gpu, cpu, _actions(rng, 60, N))
+    for auto in (False, True):
+        gpu, cpu = _mk(N, maps.stage_1(), max_episode_steps=0 if not auto else 40, auto_reset=auto, respawn_on_arrive=True,
+                       seed=7, goal_box=(-0.6, 0.6))
+        for s in (gpu, cpu):
+            s.set_goal_rects(0, np.zeros((0, 4)))
+            s.set_goal_rects(1, np.zeros((0, 4)))
+        a = _actions(rng, 90, N)
+        a[..., 0] = np.maximum(a[..., 0], 0.5)
+        st = _lockstep(gpu, cpu, a)
+        assert st["arrive"] > 20
