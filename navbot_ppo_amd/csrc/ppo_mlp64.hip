@@ -526,30 +526,35 @@ __global__ __launch_bounds__(kWThreads) void mlp64_pass_both(const float* __rest
 // grad[p] = sum over the workgroups' partial rows, for BOTH nets; ADAM (single-GPU epoch): then torch.optim.Adam's update (ppo.py:116-117,381,392; defaults betas
 // (0.9, 0.999), eps 1e-8, no weight decay) applied in place -- one launch instead of two reductions + an optimiser launch.
 // One block owns 64 parameters and ALL rows (no atomics): grad[p] is stored, not accumulated.
+constexpr int kRedGroups = 16;   // row groups per block: 1024 threads, every thread sums n_blocks / 16 rows, 4 loads in flight
 template <bool ADAM>
-__global__ __launch_bounds__(256) void reduce_adam(const float* __restrict__ partial_a, const float* __restrict__ stats_partial_a,
+__global__ __launch_bounds__(64 * kRedGroups) void reduce_adam(const float* __restrict__ partial_a, const float* __restrict__ stats_partial_a,
                                                    const float* __restrict__ partial_c, const float* __restrict__ stats_partial_c,
                                                    int n_blocks, float inv_n, float* __restrict__ grad, float* __restrict__ stats,
                                                    float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
                                                    float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
-    __shared__ float part[4][64];
+    __shared__ float part[kRedGroups][64];
     const int lane = threadIdx.x & 63, q = blockIdx.x * 64 + lane, g = threadIdx.x >> 6;   // q: index into actor | critic
     const bool actor = q < P_ACTOR;
     const float* __restrict__ partial = actor ? partial_a : partial_c;
     const int P = actor ? P_ACTOR : P_CRITIC, p = actor ? q : q - P_ACTOR;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (q < P_ACTOR + P_CRITIC) {
         int b = g;
-        for (; b + 4 < n_blocks; b += 8) {
+        for (; b + 3 * kRedGroups < n_blocks; b += 4 * kRedGroups) {   // the row reads of a (b, lane) pair are 256 B per wave
             s0 += partial[(size_t)b * P + p];
-            s1 += partial[(size_t)(b + 4) * P + p];
+            s1 += partial[(size_t)(b + kRedGroups) * P + p];
+            s2 += partial[(size_t)(b + 2 * kRedGroups) * P + p];
+            s3 += partial[(size_t)(b + 3 * kRedGroups) * P + p];
         }
-        if (b < n_blocks) s0 += partial[(size_t)b * P + p];
+        for (; b < n_blocks; b += kRedGroups) s0 += partial[(size_t)b * P + p];
     }
-    part[g][lane] = s0 + s1;
+    part[g][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && q < P_ACTOR + P_CRITIC) {
-        const float gr = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        float gr = 0.f;
+#pragma unroll
+        for (int k = 0; k < kRedGroups; ++k) gr += part[k][lane];
         grad[q] = gr;
         if (ADAM) {
             const float mm = m[q] + (gr - m[q]) * (1.0f - beta1);          // exp_avg.lerp_(grad, 1 - beta1)
@@ -560,11 +565,13 @@ __global__ __launch_bounds__(256) void reduce_adam(const float* __restrict__ par
             params[q] -= (lr / bc1) * (mm / denom);
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < 8 && (threadIdx.x & 3) < 3) {   // stats[0..2] actor, stats[4..6] critic
-        const float* sp = (threadIdx.x < 4) ? stats_partial_a : stats_partial_c;
+    if (blockIdx.x == 0 && g < 8 && (g & 3) < 3) {   // stats[0..2] actor, stats[4..6] critic: wave g sums statistic g over the rows
+        const float* sp = (g < 4) ? stats_partial_a : stats_partial_c;
         float s = 0.f;
-        for (int b = 0; b < n_blocks; ++b) s += sp[b * 4 + (threadIdx.x & 3)];
-        stats[threadIdx.x] = s * inv_n;
+        for (int b = lane; b < n_blocks; b += 64) s += sp[b * 4 + (g & 3)];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) stats[g] = s * inv_n;
     }
 }
 
@@ -646,7 +653,7 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
     hipLaunchKernelGGL(mlp64_pass_both, dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev,
                        adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, partial_c, stats_partial_c, grad_dev,
                        stats_dev);
-    hipLaunchKernelGGL(reduce_adam<false>, dim3((P_ACTOR + P_CRITIC + 63) / 64), dim3(256), 0, st, partial, stats_partial, partial_c,
+    hipLaunchKernelGGL(reduce_adam<false>, dim3((P_ACTOR + P_CRITIC + 63) / 64), dim3(64 * kRedGroups), 0, st, partial, stats_partial, partial_c,
                        stats_partial_c, blocks, inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -720,7 +727,7 @@ int navppo_mlp64_update_epoch(float* params_dev, const float* obs_dev, const flo
     hipLaunchKernelGGL(mlp64_pass_both, dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev,
                        adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, partial_c, stats_partial_c, grad_dev,
                        stats_dev);
-    hipLaunchKernelGGL(reduce_adam<true>, dim3((P_ACTOR + P_CRITIC + 63) / 64), dim3(256), 0, st, partial, stats_partial, partial_c,
+    hipLaunchKernelGGL(reduce_adam<true>, dim3((P_ACTOR + P_CRITIC + 63) / 64), dim3(64 * kRedGroups), 0, st, partial, stats_partial, partial_c,
                        stats_partial_c, blocks, inv_n, grad_dev, stats_dev, params_dev, adam_m_dev, adam_v_dev, lr, beta1, beta2, eps,
                        bc1, bc2_sqrt);
     hipError_t e = hipGetLastError();

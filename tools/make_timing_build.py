@@ -11,7 +11,7 @@ def rep(a, b, n=1):
     t = t.replace(a, b, n)
 rep("template <int NB, int EPB, int NW = 4>\nstruct StepSmem {",
     "__device__ long long g_dbg[64 * 8];\n__device__ long long g_blk[8192 * 3];\n"
-    "#define STAMP(slot) do { if (blockIdx.x % 97 == 0 && (threadIdx.x & 63) == 0) g_dbg[((blockIdx.x / 97) % 8) * 64 + (threadIdx.x >> 6) * 8 + (slot)] = wall_clock64(); } while (0)\n"
+    "#define STAMP(slot) do { if (blockIdx.x % 97 == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) g_dbg[((blockIdx.x / 97) % 8) * 64 + (threadIdx.x >> 6) * 8 + (slot)] = wall_clock64(); } while (0)\n"
     "template <int NB, int EPB, int NW = 4>\nstruct StepSmem {")
 rep("    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motion + sensor frame",
     "    STAMP(0);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) { g_blk[blockIdx.x * 3] = wall_clock64(); unsigned hw; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw)); unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc)); g_blk[blockIdx.x * 3 + 2] = ((long long)xcc << 32) | hw; }\n"
@@ -19,7 +19,7 @@ rep("    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motio
 rep("    __syncthreads();  // barrier A:", "    STAMP(1);\n    __syncthreads();  STAMP(2); // barrier A:")
 rep("    __syncthreads();  // barrier B:", "    STAMP(3);\n    __syncthreads();  STAMP(4); // barrier B:")
 rep("    __syncthreads();  // barrier C:", "    STAMP(5);\n    __syncthreads();  STAMP(6); // barrier C:")
-idx = t.index("template <int NB, int EPB, bool SENS>\n__global__ __launch_bounds__(kThreads4) void step_kernel(")
+idx = t.index("template <int NB, int EPB, bool SENS, int NW = 4>\n__global__ __launch_bounds__(64 * NW) void step_kernel(")
 j = t.rfind("}\n\n", 0, idx)
 t = t[:j] + "    STAMP(7);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk[blockIdx.x * 3 + 1] = wall_clock64();\n" + t[j:]
 rep("int navsim_version(void) { return NAVSIM_ABI_VERSION; }",

@@ -31,6 +31,7 @@ if "--rollout" in sys.argv:   # the persistent rollout kernel: stamps of its LAS
         print(f"  step body {(b[blk, :4, 7].max() - t0) * 10} ns -> policy phase + barrier ~ {us * 1e3 - (b[blk, :4, 7].max() - t0) * 10:.0f} ns")
     sys.exit(0)
 N = 4096 if CFG2 else 16384
+EPBv = int(os.environ.get('NAVSIM_EPB', '16'))
 sim = NavSim(N, max_episode_steps=500, auto_reset=True, seed=0)
 if CFG2:
     sim.set_map(maps.stage_1(), per_env=False)
@@ -44,10 +45,11 @@ sim.step(acts, io.obs, io.reward, io.done, io.arrive, io.ended); torch.cuda.sync
 buf = np.zeros(512, dtype=np.int64)
 L = _native.lib(); L.navsim_dbg_read.argtypes = [C.c_void_p]; L.navsim_dbg_read(buf.ctypes.data_as(C.c_void_p))
 b = buf.reshape(8, 8, 8)  # [sampled block][wave][slot]
-t0 = b[:, :4, 0].min()
-for blk in range(4):
+NWV = 8 if EPBv >= 32 else 4
+t0 = b[:, :NWV, 0][b[:, :NWV, 0] > 0].min()
+for blk in range(2):
     print(f"block sample {blk}")
-    for w in range(4):
+    for w in range(NWV):
         print("  wave", w, " ".join(f"{names[s]}={(b[blk, w, s] - t0) * 10:6d}ns" for s in range(8)))
 
 EPB = int(os.environ.get('NAVSIM_EPB', '16'))
