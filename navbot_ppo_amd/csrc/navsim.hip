@@ -830,6 +830,18 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             p2 = advance(p1);
             ld(p2, g2, v2);
         }
+        // The tail.  Stage A2 only filters, so when everything that is left fits one stage-B pass it is skipped: the stage-A
+        // survivors join the stage-B queue directly (one pass of 206 VALU instead of 75 + 206; a small map never needs A2).
+        if (qtail - qhead + rtail - rhead <= 64) {
+            const int n = qtail - qhead;
+            if (lane < n) {
+                const int s1 = (qhead + lane) & 127, s2 = (rtail + lane) & 127;
+                r4[s2] = q4[s1];
+                re[s2] = qe[s1];
+            }
+            rtail += n;
+            qhead += n;
+        }
         if (qtail > qhead) flushA2(qtail - qhead);
         if (rtail > rhead) flushB(rtail - rhead);
     }
