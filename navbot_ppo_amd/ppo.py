@@ -127,7 +127,9 @@ class FlatParams:
     stay ordinary tensors so state_dict keys are unchanged.)"""
 
     def __init__(self, modules, device):
-        self.params = [p for m in modules for n, p in m.named_parameters() if ".bn" not in "." + n and not n.startswith("bn")]
+        per_module = [[p for n, p in m.named_parameters() if ".bn" not in "." + n and not n.startswith("bn")] for m in modules]
+        self.params = [p for ps in per_module for p in ps]
+        self.module_numel = [sum(p.numel() for p in ps) for ps in per_module]   # [actor, critic] slices of the flat buffers
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(total, dtype=torch.float32, device=device)
@@ -271,6 +273,7 @@ class PPOUpdater:
                 V0 = self.critic(obs).squeeze(-1)
             adv = normalise_advantages(rtg - V0, ctx)          # ppo.py:275-284
         n_ep = cfg.n_updates_per_iteration
+        flat_before = self.fp.flat.clone()                     # for the parameter-delta diagnostics of ppo.py:402-403
         a_loss = c_loss = torch.zeros((), device=obs.device)   # n_updates_per_iteration == 0: nothing to report
         acc = torch.zeros(6, device=obs.device)                # sums over epochs of diagnostics
         self.loss_history = torch.zeros((n_ep, 2), device=obs.device)  # per-epoch (actor, critic) loss, ppo.py:396-397
@@ -314,8 +317,12 @@ class PPOUpdater:
         if ctx is not None and world > 1:
             ctx.all_reduce_sum(acc)
             acc = acc / world
-        self.stats = dict(zip(["actor_loss", "critic_loss", "approx_kl", "clip_frac", "grad_norm", "value_mean"],
-                              [float(v) for v in acc.tolist()]))
+        n_a = self.fp.module_numel[0]
+        d = self.fp.flat - flat_before
+        extra = torch.stack([self.fp.grad[:n_a].norm(), self.fp.grad[n_a:].norm(), d[:n_a].norm(), d[n_a:].norm()])
+        self.stats = dict(zip(["actor_loss", "critic_loss", "approx_kl", "clip_frac", "grad_norm", "value_mean",
+                               "actor_grad_norm", "critic_grad_norm", "actor_param_delta", "critic_param_delta"],
+                              [float(v) for v in torch.cat([acc, extra]).tolist()]))   # grad norms: the last epoch's
         self.last_losses = (a_loss.detach(), c_loss.detach())
         return self.stats
 
@@ -505,6 +512,7 @@ class PPOTrainer:
                 f.write(json.dumps(dict(self.tb_scalars(), iteration=self.i_so_far, t_so_far=self.t_so_far)) + "\n")
             if cfg.episode_csv_rows:
                 self.write_episode_csv(cfg.episode_csv_rows)
+            self.write_tensorboard()
         return self.logger
 
     # ---- logging surface of the reference: per-episode CSV (ppo.py:159-163,739-746) and the TensorBoard scalar names
@@ -547,16 +555,56 @@ class PPOTrainer:
         return path
 
     def tb_scalars(self):
-        """The reference's scalar names (ppo.py:892-939) for the last iteration."""
+        """The scalars the reference hands to SummaryWriter.add_scalar once per iteration, under its tag names
+        (ppo.py:892-918), for the last iteration."""
         lg = self.logger
         ep = max(lg.get("episodes", 0), 1)
-        return {"train/mean_return": lg.get("avg_ep_rews"), "train/mean_length": lg.get("avg_ep_lens"),
-                "train/success_rate": lg.get("success_rate"), "train/collision_rate": lg.get("collisions", 0) / ep,
-                "train/timeout_rate": lg.get("timeouts", 0) / ep, "loss/actor": lg.get("actor_loss"),
-                "loss/critic": lg.get("critic_loss"), "time/rollout_sec": lg.get("rollout_time"),
-                "time/update_sec": lg.get("update_time"), "time/iteration_sec": lg.get("iter_time"),
-                "perf/steps_per_sec": lg.get("steps_per_sec"), "ppo/approx_kl": lg.get("approx_kl"),
-                "ppo/clip_frac": lg.get("clip_frac"), "ppo/grad_norm": lg.get("grad_norm"), "ppo/exploration_var": lg.get("var")}
+        n_ep = self.cfg.n_updates_per_iteration
+        var = float(lg.get("var", self.cfg.init_var))
+        sec_per_step = float(lg.get("rollout_time", 0.0)) / max(self.cfg.rollout_len, 1)
+        return {"train/success_rate": lg.get("success_rate"), "train/collision_rate": lg.get("collisions", 0) / ep,
+                "train/timeout_rate": lg.get("timeouts", 0) / ep, "train/mean_return": lg.get("avg_ep_rews"),
+                "train/mean_ep_length": lg.get("avg_ep_lens"), "train/mean_ep_time": lg.get("avg_ep_lens", 0.0) * sec_per_step,
+                "loss/actor": lg.get("actor_loss"), "loss/critic": lg.get("critic_loss"), "train/timesteps": lg.get("t_so_far"),
+                "time/rollout": lg.get("rollout_time"), "time/update": lg.get("update_time"), "time/iteration": lg.get("iter_time"),
+                "perf/steps_per_sec": lg.get("steps_per_sec"), "perf/actor_grad_steps": n_ep, "perf/critic_grad_steps": n_ep,
+                "ppo/approx_kl": lg.get("approx_kl"),
+                "ppo/entropy": 1.0 + LOG_2PI + math.log(max(var, 1e-30)),   # MultivariateNormal(mean, var I).entropy(), 2-D
+                "ppo/clip_frac": lg.get("clip_frac"), "ppo/actor_grad_norm": lg.get("actor_grad_norm"),
+                "ppo/critic_grad_norm": lg.get("critic_grad_norm"), "ppo/actor_param_delta": lg.get("actor_param_delta"),
+                "ppo/critic_param_delta": lg.get("critic_param_delta")}
+
+    def tb_dir(self):
+        return os.path.join(self.cfg.output_dir, self.cfg.method_name, "tb")   # ppo.py:66
+
+    def write_tensorboard(self):
+        """The reference's TensorBoard stream (ppo.py:892-939): per-iteration scalars at step i_so_far, the per-epoch
+        Actor_loss/train and Critic_loss/train series, Episode_Rewards/train (return / length of every finished episode,
+        ppo.py:586, capped per iteration like the CSV) and avg_ep_rews/train."""
+        from .tb_writer import SummaryWriter
+        if getattr(self, "_tb", None) is None:
+            self._tb = SummaryWriter(self.tb_dir())
+            self._tb_loss_steps = self._tb_ep_steps = 0
+        w, it = self._tb, self.i_so_far
+        for k, v in self.tb_scalars().items():
+            if v is not None:
+                w.add_scalar(k, float(v), it)
+        hist = self.updater.loss_history.detach().cpu().numpy()
+        for k in range(hist.shape[0]):
+            w.add_scalar("Actor_loss/train", float(hist[k, 0]), self._tb_loss_steps + k)
+            w.add_scalar("Critic_loss/train", float(hist[k, 1]), self._tb_loss_steps + k)
+        self._tb_loss_steps += hist.shape[0]
+        ended = self.ended_buf.bool()
+        t_idx, n_idx = torch.nonzero(ended, as_tuple=True)
+        cap = self.cfg.episode_csv_rows or 0
+        if cap:
+            t_idx, n_idx = t_idx[:cap], n_idx[:cap]
+        per_step = (self.epret_buf[t_idx, n_idx] / self.eplen_buf[t_idx, n_idx].clamp(min=1)).cpu().numpy()
+        for k, r in enumerate(per_step):
+            w.add_scalar("Episode_Rewards/train", float(r), self._tb_ep_steps + k)
+        self._tb_ep_steps += len(per_step)
+        w.add_scalar("avg_ep_rews/train", float(self.logger.get("avg_ep_rews", 0.0)), it)
+        w.flush()
 
     def learn(self, total_timesteps, log=print):
         # The reference counts only COMPLETED episodes toward the budget (ppo.py:258); if a configuration never completes

@@ -202,6 +202,22 @@ def test_train_checkpoint_then_evaluate_like_main(tmp_path):
     import json
     sc = [json.loads(l) for l in open(os.path.join(logs, "scalars.jsonl"))]
     assert len(sc) == 2 and {"train/mean_return", "loss/actor", "loss/critic", "perf/steps_per_sec", "ppo/approx_kl"} <= set(sc[0])
+    # TensorBoard event file under <run>/tb (ppo.py:66,149) with the reference's tags (ppo.py:892-939), CRC-checked on read
+    import glob
+    from navbot_ppo_amd import tb_writer
+    ev_files = glob.glob(os.path.join(str(tmp_path), "m1", "tb", "events.out.tfevents.*"))
+    assert len(ev_files) == 1
+    recs = tb_writer.read_scalars(ev_files[0])
+    tags = {r[0] for r in recs}
+    assert {"train/success_rate", "train/collision_rate", "train/timeout_rate", "train/mean_return", "train/mean_ep_length",
+            "train/mean_ep_time", "loss/actor", "loss/critic", "train/timesteps", "time/rollout", "time/update", "time/iteration",
+            "perf/steps_per_sec", "perf/actor_grad_steps", "perf/critic_grad_steps", "ppo/approx_kl", "ppo/entropy",
+            "ppo/clip_frac", "ppo/actor_grad_norm", "ppo/critic_grad_norm", "ppo/actor_param_delta", "ppo/critic_param_delta",
+            "Actor_loss/train", "Critic_loss/train", "Episode_Rewards/train", "avg_ep_rews/train"} <= tags
+    assert sorted(s for tg, s, _ in recs if tg == "train/mean_return") == [1, 2]
+    assert len([1 for tg, _, _ in recs if tg == "Actor_loss/train"]) == 4          # 2 iterations x 2 epochs
+    path_col = [float(r.split(",")[7]) for r in open(os.path.join(logs, "m1_train_episodes.csv")).read().strip().split("\n")[1:]]
+    assert max(path_col) > 0.0
     actor, policy = ev.load_actor(ck, "cuda")
     assert policy == "resmlp512"
     s = ev.evaluate(actor, num_episodes=40, max_timesteps_per_episode=25, n_parallel=16, output_dir=str(tmp_path), method_name="m1", log=None)

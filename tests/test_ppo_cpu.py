@@ -248,3 +248,18 @@ def test_cli_flags_match_reference_arguments():
     assert M.schedule(t) == (2, 20) and M.schedule(M.get_args([])) == (10, 500)
     with pytest.raises(SystemExit):
         M.get_args(["--method_name", "vision_mobilenet"])
+
+
+def test_tensorboard_event_writer_roundtrip(tmp_path):
+    """navbot_ppo_amd.tb_writer writes the TFRecord / tensorflow.Event format tensorboardX would (ppo.py:13,149,892)."""
+    from navbot_ppo_amd import tb_writer as T
+    assert T.crc32c(b"123456789") == 0xE3069283          # CRC-32C check value
+    w = T.SummaryWriter(str(tmp_path))
+    w.add_scalar("train/mean_return", 12.5, 3)
+    w.add_scalar("loss/actor", -0.25, 300)
+    w.add_scalar("perf/steps_per_sec", 3.5e7, 1 << 40)
+    w.close()
+    assert os.path.basename(w.path).startswith("events.out.tfevents.")
+    assert T.read_scalars(w.path) == [("train/mean_return", 3, 12.5), ("loss/actor", 300, -0.25), ("perf/steps_per_sec", 1 << 40, 3.5e7)]
+    raw = open(w.path, "rb").read()
+    assert b"brain.Event:2" in raw[:64]
