@@ -82,7 +82,9 @@ void navsim_destroy(navsim_t* h);
  * The static world the reference gets from Gazebo (worlds/train_world_new.world:85-416):
  * S line segments (ax,ay,bx,by) float32.  per_env=0: seg_dev is [S,4], shared by all envs;
  * per_env=1: seg_dev is [N,S,4], env i reads its own S segments.  The buffer is NOT copied:
- * it must stay alive and unchanged while the handle uses it.  Also ray-casts the spawn pose
+ * it must stay alive and unchanged while the handle uses it.  (Exception: a shared map of 65..4096 segments is copied,
+ * synchronously, into a handle-owned buffer in Morton order of the segment midpoints together with the bounding box of
+ * every 64-segment tile, which lets the step kernel skip whole tiles; the order of segments does not affect any result.)  Also ray-casts the spawn pose
  * (the scan every reset observes) on `stream`.
  */
 int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_t per_env, void* stream);

@@ -33,7 +33,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "navsim.h"
 #include "mlp64_policy.h"
@@ -86,6 +89,8 @@ struct Params {
     uint32_t* rsp_ctr;        // [N] draw counter after the re-spawn draw
     int seg_pack_log2;        // cast: log2(lanes per env in one 64-lane pass) = 6, or log2(pow2ceil(S)) when S <= 32
     const float4* seg;        // [S] or [N][S]
+    const float4* tile_box;   // shared maps of 65..4096 segments (kept in Morton order by navsim_set_map): per 64-segment tile
+                              // the bounding box (xmin, ymin, xmax, ymax) of its segments; else null
     const float* spawn_scan;  // [K][B] or [N][K][B] nearest hits (+inf = none) at the K start poses (K = 1: the cfg spawn pose)
     const float* spawn_obs;   // same shape: the noise-free lidar entries of the reset observation (sanitised scan / 3.5)
     const double* starts;     // [K][3] start poses (x, y, yaw)
@@ -321,6 +326,7 @@ struct StepSmem {
     unsigned qe[NW][128];
     float4 r4[NW][128];          // ... and of those whose angular extent holds at least one beam
     unsigned re[NW][128];
+    float4 tbox[64];             // Params::tile_box, staged once per launch (BOXES)
     float2 act_l[EPB];           // persistent rollout: the action the policy phase chose for this step
     // persistent rollout: the envs' state lives here between the steps (HBM sees it before the first and after the last)
     double st_d[8][EPB];         // x, y, th, gx, gy, past_dist, ep_ret, ep_path
@@ -424,7 +430,9 @@ __device__ __forceinline__ float write_lidar(float* row, const float* best, int 
 // PERSIST: called once per step by the persistent rollout kernel; the action comes from the policy phase through LDS and
 // the env state stays in LDS (sm.st_*) from step to step; `last_step` also writes it back to HBM.
 // NW: waves per workgroup (4; the persistent rollout kernel, one workgroup per CU, runs 8 for a shorter cast).
-template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4>
+// BOXES: shared map with tile bounding boxes (Params::tile_box): whole 64-segment tiles that lie behind the beam fan or out of
+// range are skipped without being loaded (the house map: 32 tiles, ~5 of them near any one pose).
+template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4, bool BOXES = false>
 __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>& sm, int& next_env,
                                           const float2* __restrict__ action, const float2* __restrict__ past_override,
                                           void* __restrict__ obs_out, float* __restrict__ reward,
@@ -600,6 +608,7 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             sm.mn_bits[tid - 64 * PW] = kInfBits;
             sm.neg[tid - 64 * PW] = 0u;
         }
+        if (BOXES && tid - 64 * PW < ntiles) sm.tbox[tid - 64 * PW] = P.tile_box[tid - 64 * PW];
         // static positions k = 0, 1, 2 of ray wave r: item r + RW (k / ntiles), tile k % ntiles
         constexpr int RW = NW - PW;
         const int r = wave - PW;
@@ -802,18 +811,50 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
                 if (qtail - qhead >= 64) flushA2(64);
             }
         };
+        // BOXES: bit t of item_live(env) = tile t can matter for this env's pose: lane = tile, the same conservative range /
+        // behind-the-fan tests as stage A applied to the tile's bounding box (all four corners inside the behind cone)
+        auto item_live = [&](const int it) __attribute__((always_inline)) -> unsigned long long {
+            const int el = min(it, nloc - 1);
+            const float2 o = sm.org[el], h = sm.hd[el];
+            const float4 bx = sm.tbox[lane];
+            const float dx = fmaxf(fmaxf(bx.x - o.x, o.x - bx.z), 0.f), dy = fmaxf(fmaxf(bx.y - o.y, o.y - bx.w), 0.f);
+            const bool far = fmaf(dx, dx, dy * dy) > 12.3f;
+            const float x0 = bx.x - o.x, x1 = bx.z - o.x, y0 = bx.y - o.y, y1 = bx.w - o.y;
+            auto behind = [&](float cx, float cy) {
+                const float X = fmaf(cx, h.x, cy * h.y), Y = fmaf(cy, h.x, -(cx * h.y));
+                return fmaf(1e-3f, fabsf(Y), X) < 0.f;
+            };
+            const bool back = behind(x0, y0) && behind(x1, y0) && behind(x0, y1) && behind(x1, y1);
+            return __ballot((lane < ntiles) && !(far || back));
+        };
+        unsigned long long cur_live = 0ull;   // BOXES: live tiles of the item the last assigned position belongs to
+        auto next_item = [&]() __attribute__((always_inline)) -> Pos {   // BOXES: first live tile of the next item that has one
+            for (;;) {
+                const int it = grab();
+                if (it >= n_items) return Pos{it, 0};
+                cur_live = item_live(it);
+                if (cur_live) return Pos{it, (int)__builtin_ctzll(cur_live)};
+            }
+        };
         auto advance = [&](const Pos p) __attribute__((always_inline)) -> Pos {
             if (p.it >= n_items) return p;
+            if (BOXES) {
+                const unsigned long long rest = (p.t >= 63) ? 0ull : (cur_live & (~0ull << (p.t + 1)));
+                if (rest) return Pos{p.it, (int)__builtin_ctzll(rest)};
+                return next_item();
+            }
             if (p.t + 1 < ntiles) return Pos{p.it, p.t + 1};
             return Pos{grab(), 0};
         };
         if (wave < PW) {   // pose waves join when part 2 is done
-            p0 = Pos{grab(), 0};
+            p0 = BOXES ? next_item() : Pos{grab(), 0};
             ld(p0, g0, v0);
             p1 = advance(p0);
             ld(p1, g1, v1);
             p2 = advance(p1);
             ld(p2, g2, v2);
+        } else if (BOXES) {   // ray waves: the live tiles of the item their last pre-assigned tile belongs to
+            cur_live = (p2.it < n_items) ? item_live(p2.it) : 0ull;
         }
         // three tiles in flight; the slots take turns (a register rotation would have to wait for the load it moves)
         for (;;) {   // wave-uniform
@@ -967,7 +1008,7 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     }
 }
 
-template <int NB, int EPB, bool SENS, int NW = 4>
+template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false>
 __global__ __launch_bounds__(64 * NW) void step_kernel(Params P, const float2* __restrict__ action,
                                                         const float2* __restrict__ past_override,
                                                         void* __restrict__ obs_out, float* __restrict__ reward,
@@ -976,7 +1017,7 @@ __global__ __launch_bounds__(64 * NW) void step_kernel(Params P, const float2* _
                                                         int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out) {
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
-    step_body<NB, EPB, SENS, false, NW>(P, sm, next_env, action, past_override, obs_out, reward, done, arrive, ended, ep_return,
+    step_body<NB, EPB, SENS, false, NW, BOXES>(P, sm, next_env, action, past_override, obs_out, reward, done, arrive, ended, ep_return,
                                     ep_length, ep_path_out);
 }
 
@@ -1254,6 +1295,8 @@ struct navsim {
     double* beam_cs_dev = nullptr;
     Rects* rects_dev = nullptr;
     Rects rects_host;
+    float4* seg_sorted_dev = nullptr;   // shared maps of 65..4096 segments: the handle's own Morton-ordered copy
+    float4* tile_box_dev = nullptr;
     float* spawn_scan_dev = nullptr;
     float* spawn_obs_dev = nullptr;
     double* starts_dev = nullptr;   // [K][3]
@@ -1282,17 +1325,27 @@ static void launch_step(const navsim* h, const float* action, const float* past,
                            (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len, ep_path);
     };
     const int epb = pick_epb(h->P.N);
+    const bool boxes = h->P.tile_box != nullptr;   // shared map with tile bounding boxes (navsim_set_map)
+#define NAVSIM_GO(EPB_, NW_)                                                                         \
+    do {                                                                                             \
+        if (boxes) {                                                                                 \
+            if (sens) go(step_kernel<NB, EPB_, true, NW_, true>, EPB_, NW_);                         \
+            else go(step_kernel<NB, EPB_, false, NW_, true>, EPB_, NW_);                             \
+        } else {                                                                                     \
+            if (sens) go(step_kernel<NB, EPB_, true, NW_, false>, EPB_, NW_);                        \
+            else go(step_kernel<NB, EPB_, false, NW_, false>, EPB_, NW_);                            \
+        }                                                                                            \
+    } while (0)
     if (epb == 8) {
-        if (sens) go(step_kernel<NB, 8, true>, 8, 4); else go(step_kernel<NB, 8, false>, 8, 4);
+        NAVSIM_GO(8, 4);
     } else if (epb == 32 || (epb == 64 && NB > 10)) {   // 8-wave workgroups of 32 envs: float64 geometry / rules lanes twice as dense
-        if (sens) go(step_kernel<NB, 32, true, 8>, 32, 8); else go(step_kernel<NB, 32, false, 8>, 32, 8);
+        NAVSIM_GO(32, 8);
     } else if (epb == 64) {   // 16-wave workgroups of 64 envs (10 beams: the 36-beam tile does not fit the LDS)
-        if constexpr (NB == 10) {
-            if (sens) go(step_kernel<NB, 64, true, 16>, 64, 16); else go(step_kernel<NB, 64, false, 16>, 64, 16);
-        }
+        if constexpr (NB == 10) NAVSIM_GO(64, 16);
     } else {
-        if (sens) go(step_kernel<NB, 16, true>, 16, 4); else go(step_kernel<NB, 16, false>, 16, 4);
+        NAVSIM_GO(16, 4);
     }
+#undef NAVSIM_GO
 }
 
 static int invalidate_records(navsim* h, hipStream_t st) {
@@ -1441,6 +1494,8 @@ void navsim_destroy(navsim_t* h) {
     (void)hipFree(h->rects_dev);
     (void)hipFree(h->spawn_scan_dev);
     (void)hipFree(h->spawn_obs_dev);
+    (void)hipFree(h->seg_sorted_dev);
+    (void)hipFree(h->tile_box_dev);
     (void)hipFree(h->starts_dev);
     (void)hipFree(h->starts_sc_dev);
     (void)hipFree(h->goals_dev);
@@ -1488,6 +1543,66 @@ int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_
     P.S = n_segments;
     P.per_env = per_env ? 1 : 0;
     P.seg_pack_log2 = 6;
+    P.tile_box = nullptr;
+    if (h->seg_sorted_dev || h->tile_box_dev) {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        (void)hipFree(h->seg_sorted_dev);
+        (void)hipFree(h->tile_box_dev);
+        h->seg_sorted_dev = h->tile_box_dev = nullptr;
+    }
+    if (!per_env && n_segments > 64 && n_segments <= 4096) {
+        // A shared map big enough to tile: keep an own copy in Morton order of the segment midpoints, so that a 64-segment
+        // tile is a compact patch of the map, with the bounding box of every tile.  The order of the segments does not
+        // change the scan (the nearest hit is a min).
+        const int S = n_segments, nt = (S + 63) / 64;
+        std::vector<float4> seg((size_t)S);
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipMemcpy(seg.data(), seg_dev, sizeof(float4) * S, hipMemcpyDeviceToHost));
+        float lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+        for (const float4& g : seg) {
+            const float mx = 0.5f * (g.x + g.z), my = 0.5f * (g.y + g.w);
+            if (std::isfinite(mx) && std::isfinite(my)) {
+                lo[0] = std::fmin(lo[0], mx); hi[0] = std::fmax(hi[0], mx);
+                lo[1] = std::fmin(lo[1], my); hi[1] = std::fmax(hi[1], my);
+            }
+        }
+        auto spread = [](uint32_t v) {   // 16 bits -> every other bit
+            v &= 0xFFFFu;
+            v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu;
+            v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+            return v;
+        };
+        std::vector<std::pair<uint32_t, int>> key((size_t)S);
+        for (int j = 0; j < S; ++j) {
+            const float mx = 0.5f * (seg[j].x + seg[j].z), my = 0.5f * (seg[j].y + seg[j].w);
+            uint32_t code = 0xFFFFFFFFu;   // non-finite segments go last
+            if (std::isfinite(mx) && std::isfinite(my)) {
+                const float sx = (hi[0] > lo[0]) ? (mx - lo[0]) / (hi[0] - lo[0]) : 0.f;
+                const float sy = (hi[1] > lo[1]) ? (my - lo[1]) / (hi[1] - lo[1]) : 0.f;
+                code = spread((uint32_t)(sx * 65535.f)) | (spread((uint32_t)(sy * 65535.f)) << 1);
+            }
+            key[j] = {code, j};
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<float4> sorted((size_t)S), box((size_t)nt);
+        for (int j = 0; j < S; ++j) sorted[j] = seg[key[j].second];
+        for (int t = 0; t < nt; ++t) {
+            // NaN coordinates make the box NaN-free but that segment can never be hit either (every test on it fails)
+            float4 b = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+            for (int j = 64 * t; j < std::min(S, 64 * t + 64); ++j) {
+                const float4 g = sorted[j];
+                b.x = std::fmin(b.x, std::fmin(g.x, g.z)); b.y = std::fmin(b.y, std::fmin(g.y, g.w));
+                b.z = std::fmax(b.z, std::fmax(g.x, g.z)); b.w = std::fmax(b.w, std::fmax(g.y, g.w));
+            }
+            box[t] = b;
+        }
+        HIP_TRY(hipMalloc(&h->seg_sorted_dev, sizeof(float4) * S));
+        HIP_TRY(hipMalloc(&h->tile_box_dev, sizeof(float4) * nt));
+        HIP_TRY(hipMemcpy(h->seg_sorted_dev, sorted.data(), sizeof(float4) * S, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->tile_box_dev, box.data(), sizeof(float4) * nt, hipMemcpyHostToDevice));
+        P.seg = h->seg_sorted_dev;
+        P.tile_box = h->tile_box_dev;
+    }
     if (n_segments <= 32) {   // several envs share one 64-lane pass of the cast
         int lg = 0;
         while ((1 << lg) < n_segments) ++lg;

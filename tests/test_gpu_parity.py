@@ -666,6 +666,12 @@ def test_workgroup_shapes_keep_parity(epb, monkeypatch):
     seg = maps.replicate_per_env(maps.stage_2(), N, seed=5)
     gpu, cpu = _mk(N, seg, per_env=True, max_episode_steps=25, auto_reset=True, seed=6)
     _lockstep(gpu, cpu, _actions(rng, 60, N))
+    # shared map big enough for the Morton-ordered copy with tile bounding boxes (whole tiles are skipped)
+    gpu, cpu = _mk(N, maps.house(1000), max_episode_steps=25, auto_reset=True, seed=8)
+    st, g, lo, hi = maps.spawn_tables("small_house")
+    for s in (gpu, cpu):
+        s.set_spawn_sampler(*(maps.open_tables(maps.house(1000), st, g) + (lo, hi)))
+    _lockstep(gpu, cpu, _actions(rng, 50, N))
     for auto in (False, True):
         gpu, cpu = _mk(N, maps.stage_1(), max_episode_steps=0 if not auto else 40, auto_reset=auto, respawn_on_arrive=True,
                        seed=7, goal_box=(-0.6, 0.6))
