@@ -682,3 +682,17 @@ def test_workgroup_shapes_keep_parity(epb, monkeypatch):
         a[..., 0] = np.maximum(a[..., 0], 0.5)
         st = _lockstep(gpu, cpu, a)
         assert st["arrive"] > 20
+
+
+def test_actions_outside_the_policy_range():
+    """The simulator does not clamp: PPO clamps a0 to [0, 1] and a1 to [-1, 1] before Env.step (ppo.py:700-703), but the ABI
+    accepts any action (reverse driving, fast spins: up to 0.6 m and 0.6 rad per step here).  Same results as the oracle."""
+    rng = np.random.default_rng(91)
+    N = 160
+    gpu, cpu = _mk(N, maps.stage_1(), max_episode_steps=20, auto_reset=True, seed=12)
+    a = rng.uniform(-3.0, 3.0, (70, N, 2)).astype(np.float32)
+    st = _lockstep(gpu, cpu, a)
+    assert st["ended"] > N
+    seg = maps.replicate_per_env(maps.stage_2(), N, seed=2)
+    gpu, cpu = _mk(N, seg, per_env=True, max_episode_steps=20, auto_reset=True, seed=13)
+    _lockstep(gpu, cpu, a[:40])
