@@ -7,9 +7,9 @@
 
 Workload (BASELINE.json configs[1]): 4096 envs per GPU, stage_1 map (32 segments), 10 beams, PPO with the
 2x64 MLP heads, rollout T=512, episode cap 500, 50 full-batch update epochs, lr 3e-4, clip 0.2, gamma 0.99.
-One "step" = one PPO iteration = T env steps of all envs (policy forward + sampling + HIP step kernel,
-captured in one hipGraph) + the HIP return scan + the 50-epoch update (+ one RCCL all-reduce of the flat
-gradient per epoch when N > 1).  value = K * T * n_envs_total / wall, the reference's own
+One "step" = one PPO iteration = T env steps of all envs (policy forward + sampling + env step, all T of them in ONE
+persistent HIP launch) + the HIP return scan + the 50-epoch update (two launches per epoch; + one RCCL all-reduce of the
+flat gradient per epoch when N > 1).  value = K * T * n_envs_total / wall, the reference's own
 `perf/steps_per_sec` (project_ppo/src/ppo.py:855), all inputs resident in HBM, synthetic (random-init
 policy, seeded goals).  Weak scaling: every GPU owns its own 4096-env shard.
 
