@@ -1217,7 +1217,7 @@ __global__ void spawn_obs_kernel(const float* __restrict__ best, int n, int belo
 //                            | wave 0, lane = column, runs the recurrence on chunk s - 1 (the carry stays in a register)
 //                            | waves 1-3 stream the returns of chunk s - 2 out
 // with one workgroup barrier per stage.  N = 4096 gives 256 workgroups (round 1: one thread per column with 8 loads in
-// flight = 64 latency-bound waves, 40 us for 18.9 MB; now 18.6 us).  The floor is the recurrence itself: 512 dependent
+// flight = 64 latency-bound waves, 40 us for 18.9 MB; now 16.5 us).  The floor is the recurrence itself: 512 dependent
 // float64 multiply -> add pairs per column, ~35 cycles each = 7.5 us.  "if ended: disc = 0" is folded into the factor:
 // disc * 0 is (+-)0 and r + (+-)0 == r, so the value is that of ppo.py:660-665 while the select leaves the dependent chain.
 // (Tried: chunk s + 1 requested into registers one stage ahead behind an LDS-only barrier -- 35 us, slower.)
@@ -1256,13 +1256,33 @@ __global__ __launch_bounds__(256) void rtg_kernel_vec(const float* __restrict__ 
             const float* __restrict__ br = s_r[j % 3];
             const uint8_t* __restrict__ be = s_e[j % 3];
             float* __restrict__ bo = s_o[j % 3];
-#pragma unroll 8
-            for (int tt = nt - 1; tt >= 0; --tt) {
+            // blocks of 16 rows: all LDS reads of a block are requested at once, then the dependent multiply -> add chain runs
+            // from registers (one LDS latency per block instead of one per two rows)
+            constexpr int U = 16;
+            int tt = nt - 1;
+            for (; tt >= U - 1; tt -= U) {
+                float r[U];
+                uint8_t e[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    r[u] = br[(tt - u) * kRtgCols + tid];
+                    e[u] = be[(tt - u) * kRtgCols + tid];
+                }
+                float o[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double g = e[u] ? 0.0 : gamma;
+                    disc = (double)r[u] + disc * g;   // ppo.py:665
+                    o[u] = (float)disc;               // ppo.py:669
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) bo[(tt - u) * kRtgCols + tid] = o[u];
+            }
+            for (; tt >= 0; --tt) {
                 const int k = tt * kRtgCols + tid;
-                const float r = br[k];
                 const double g = be[k] ? 0.0 : gamma;
-                disc = (double)r + disc * g;      // ppo.py:665
-                bo[k] = (float)disc;              // ppo.py:669
+                disc = (double)br[k] + disc * g;
+                bo[k] = (float)disc;
             }
         }
         __syncthreads();
