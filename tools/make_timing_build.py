@@ -19,13 +19,23 @@ rep("    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motio
 rep("    __syncthreads();  // barrier A:", "    STAMP(1);\n    __syncthreads();  STAMP(2); // barrier A:")
 rep("    __syncthreads();  // barrier B:", "    STAMP(3);\n    __syncthreads();  STAMP(4); // barrier B:")
 rep("    __syncthreads();  // barrier C:", "    STAMP(5);\n    __syncthreads();  STAMP(6); // barrier C:")
-idx = t.index("template <int NB, int EPB, bool SENS, int NW = 4>\n__global__ __launch_bounds__(64 * NW) void step_kernel(")
+idx = t.index("template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false>\n__global__ __launch_bounds__(64 * NW) void step_kernel(")
 j = t.rfind("}\n\n", 0, idx)
 t = t[:j] + "    STAMP(7);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk[blockIdx.x * 3 + 1] = wall_clock64();\n" + t[j:]
 rep("int navsim_version(void) { return NAVSIM_ABI_VERSION; }",
     "int navsim_version(void) { return NAVSIM_ABI_VERSION; }\n"
     "int navsim_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 512); }\n"
     "int navsim_blk_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(long long) * 8192 * 3); }")
+# policy-phase stamps of the persistent rollout kernel (last step wins): loop top, MFMA part done, after barrier 1, finish done
+rep("__device__ long long g_dbg[64 * 8];", "__device__ long long g_dbg[64 * 8];\n__device__ long long g_pol[8 * 8 * 4];\n"
+    "#define PSTAMP(slot) do { if (blockIdx.x % 97 == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) g_pol[((blockIdx.x / 97) % 8) * 32 + (threadIdx.x >> 6) * 4 + (slot)] = wall_clock64(); } while (0)")
+rep("        if (wave < 4) {\n            const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]",
+    "        PSTAMP(0);\n        if (wave < 4) {\n            const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]")
+rep("            pol_eps[lane] = make_float2(e0, e1);\n        }\n        __syncthreads();",
+    "            pol_eps[lane] = make_float2(e0, e1);\n        }\n        PSTAMP(1);\n        __syncthreads();\n        PSTAMP(2);")
+rep("            R.logp_buf[tn + base + e] = o.logp;\n        }\n        __syncthreads();",
+    "            R.logp_buf[tn + base + e] = o.logp;\n        }\n        PSTAMP(3);\n        __syncthreads();")
+rep("int navsim_blk_read(long long* out)", "int navsim_pol_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pol), sizeof(long long) * 256); }\nint navsim_blk_read(long long* out)")
 if "--lb4" in extra_flags:
     rep("__global__ __launch_bounds__(kThreads) void step_kernel", "__global__ __launch_bounds__(kThreads, 4) void step_kernel")
 os.makedirs(os.path.join(R, "build"), exist_ok=True)

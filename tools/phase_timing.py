@@ -29,6 +29,14 @@ if "--rollout" in sys.argv:   # the persistent rollout kernel: stamps of its LAS
         for w in range(4):
             print("  wave", w, " ".join(f"{names[s]}={(b[blk, w, s] - t0) * 10:6d}ns" for s in range(8)))
         print(f"  step body {(b[blk, :4, 7].max() - t0) * 10} ns -> policy phase + barrier ~ {us * 1e3 - (b[blk, :4, 7].max() - t0) * 10:.0f} ns")
+    pol = np.zeros(256, dtype=np.int64)
+    L.navsim_pol_read.argtypes = [C.c_void_p]; L.navsim_pol_read(pol.ctypes.data_as(C.c_void_p))
+    pol = pol.reshape(8, 8, 4)
+    for blk in range(2):
+        p0 = pol[blk, :8, 0].min()
+        print(f"block sample {blk}: policy phase of the last step (ns after its first wave entered): top | MFMA+noise done | past barrier 1 | finish done")
+        for w in range(8):
+            print("  wave", w, " ".join(f"{(pol[blk, w, s] - p0) * 10:6d}" for s in range(4)), " step-body start", (b[blk, w, 0] - p0) * 10)
     sys.exit(0)
 N = 4096 if CFG2 else 16384
 EPBv = int(os.environ.get('NAVSIM_EPB', '16'))
