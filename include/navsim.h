@@ -166,6 +166,10 @@ int navsim_set_state(navsim_t* h, const double* pose_host, const double* goal_ho
  * ended_dev [T,N] u8 (last step of an episode), out_dev [T,N] f32:
  *   R[t,n] = rew[t,n] + gamma * (ended[t,n] ? 0 : R[t+1,n]),  R[T,n] = 0 (no bootstrap, ppo.py:601)
  * accumulated in float64 and stored as float32 like the reference (:665,:669).
+ * N % 16 == 0 runs the scan split over T (chunk-local scans composed through float64 carries): every stored float32 is
+ * within ONE ulp of the reference's serial recurrence (identical behind an episode end inside its 32-row chunk; elsewhere
+ * a store differs with probability ~2e-8).  Any other N, or NAVSIM_RTG_EXACT=1 in the environment, runs the serial
+ * recurrence: bit-identical, about 4x slower.
  */
 int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, int32_t N, double gamma,
                     float* out_dev, void* stream);

@@ -386,8 +386,8 @@ __device__ __forceinline__ float beam_coord(float x, float y, float two_inv_delt
     return fmaf(u * p, two_inv_delta, a_inv_delta);
 }
 
-constexpr int kThreads4 = 256;  // 4 waves.  (A workgroup reserves ceil(waves/4) slots on EVERY SIMD of its CU, so
-                                // a 5-wave block costs as much residency as an 8-wave one: measured 1 block/CU.)
+// (A workgroup reserves ceil(waves / 4) slots on EVERY SIMD of its CU, so a 5-wave block costs as much residency as an 8-wave
+// one: measured 1 block/CU.)
 
 // lidar part of an observation row (environment_new.py:289-294) from nearest hits `best` (stride `bstride`);
 // returns min(sanitised scan) for the collision rule (:200)
@@ -1210,86 +1210,87 @@ __global__ void spawn_obs_kernel(const float* __restrict__ best, int n, int belo
 
 // ---------------------------------------------------------------- return scan (PPO.compute_rtgs)
 // R[t] = r[t] + gamma R[t+1], restarting at 0 behind every episode end and at the batch end (ppo.py:658-666), float64
-// accumulate, float32 store: per env column a strictly serial recurrence (any re-association would change bits), so the
-// parallelism is across columns only and the job of the kernel is to keep the memory system busy meanwhile.  A workgroup
-// owns kRtgCols adjacent columns and walks from the last row to the first in chunks of kRtgRows rows through a three-stage
-// pipeline over LDS buffers:   waves 1-3 stream chunk s in (16-byte loads, all in flight at once)
-//                            | wave 0, lane = column, runs the recurrence on chunk s - 1 (the carry stays in a register)
-//                            | waves 1-3 stream the returns of chunk s - 2 out
-// with one workgroup barrier per stage.  N = 4096 gives 256 workgroups (round 1: one thread per column with 8 loads in
-// flight = 64 latency-bound waves, 40 us for 18.9 MB; now 16.5 us).  The floor is the recurrence itself: 512 dependent
-// float64 multiply -> add pairs per column, ~35 cycles each = 7.5 us.  "if ended: disc = 0" is folded into the factor:
-// disc * 0 is (+-)0 and r + (+-)0 == r, so the value is that of ppo.py:660-665 while the select leaves the dependent chain.
-// (Tried: chunk s + 1 requested into registers one stage ahead behind an LDS-only barrier -- 35 us, slower.)
-constexpr int kRtgCols = 16, kRtgRows = 128;
+// accumulate, float32 store.  Per env column that is a serial recurrence of T dependent float64 multiply -> add pairs
+// (~35 cycles each: 7.5 us for T = 512 however the memory is fed -- rounds 1-2: 40 us, then 16.5 us with an LDS pipeline).
+// This kernel splits the column over T instead: a workgroup owns kRtgCols adjacent columns and kRtgChunks chunks of
+// kRtgRows rows (thread = column x chunk, 1024 waves at N = 4096 with 64 loads in flight per lane):
+//   pass 1   every chunk scans its rows from registers with carry-in 0 -> B (the return at its first row) and
+//            A = gamma^kRtgRows, or 0 when an episode ends inside the chunk: R_first = B + A R_in
+//   carry    R_in of chunk c = R_first of chunk c + 1, composed serially from the (A, B) pairs in LDS (<= 15 steps)
+//   pass 2   the chunk re-runs the reference's recurrence from its true carry-in and stores
+// Every row behind (earlier than) an episode end inside its chunk carries the reference's bits by construction; the others see
+// a carry-in whose float64 rounding differs from the serial chain's (relative 1e-15), which moves the float32 store by one ulp
+// with probability ~2e-8 per element.  Contract: <= 1 float32 ulp from ppo.py:660-669, flags untouched (tests state it);
+// NAVSIM_RTG_EXACT=1 selects the serial kernel below, which is bit-identical.  "if ended: disc = 0" is folded into the
+// factor: disc * 0 is (+-)0 and r + (+-)0 == r, so the value is that of ppo.py:660-665 while the select leaves the chain.
+// T > 512: super-chunks of 512 rows from the batch end, the carry between them is the stored float64 of pass 2.
+constexpr int kRtgCols = 16, kRtgChunks = 16, kRtgRows = 32, kRtgSuper = kRtgChunks * kRtgRows;
 
-__global__ __launch_bounds__(256) void rtg_kernel_vec(const float* __restrict__ rew, const uint8_t* __restrict__ ended, int T, int N,
-                                                      double gamma, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float s_r[3][kRtgRows * kRtgCols];
-    __shared__ __attribute__((aligned(16))) float s_o[3][kRtgRows * kRtgCols];   // separate from s_r: the recurrence's reads of
-    __shared__ __attribute__((aligned(16))) uint8_t s_e[3][kRtgRows * kRtgCols]; // row t - 1 must not wait for its write of row t
-    const int tid = threadIdx.x, wave = tid >> 6;
-    const int col0 = blockIdx.x * kRtgCols;   // N % 16 == 0: all 16 columns exist
-    const int C = (T + kRtgRows - 1) / kRtgRows;   // chunk j covers rows [T - (j + 1) kRtgRows, T - j kRtgRows) clipped at 0
-    const int wt = tid - 64;                       // thread index among the 192 streaming threads
-    double disc = 0;  // ppo.py:660
-    for (int s = 0; s < C + 2; ++s) {
-        if (wave > 0) {
-            if (s < C) {   // ---- stream chunk s in
-                const int t_hi = T - s * kRtgRows, t_lo = max(0, t_hi - kRtgRows), nt = t_hi - t_lo;
-                for (int k = wt; k < nt * 4; k += 192)
-                    reinterpret_cast<float4*>(s_r[s % 3])[k] =
-                        *reinterpret_cast<const float4*>(rew + (size_t)(t_lo + (k >> 2)) * N + col0 + 4 * (k & 3));
-                for (int k = wt; k < nt; k += 192)
-                    reinterpret_cast<uint4*>(s_e[s % 3])[k] = *reinterpret_cast<const uint4*>(ended + (size_t)(t_lo + k) * N + col0);
-            }
-            if (s >= 2) {   // ---- stream the returns of chunk s - 2 out
-                const int j = s - 2;
-                const int t_hi = T - j * kRtgRows, t_lo = max(0, t_hi - kRtgRows), nt = t_hi - t_lo;
-                for (int k = wt; k < nt * 4; k += 192)
-                    *reinterpret_cast<float4*>(out + (size_t)(t_lo + (k >> 2)) * N + col0 + 4 * (k & 3)) =
-                        reinterpret_cast<const float4*>(s_o[j % 3])[k];
-            }
-        } else if (s >= 1 && s <= C && tid < kRtgCols) {   // ---- the recurrence on chunk s - 1
-            const int j = s - 1;
-            const int t_hi = T - j * kRtgRows, nt = t_hi - max(0, t_hi - kRtgRows);
-            const float* __restrict__ br = s_r[j % 3];
-            const uint8_t* __restrict__ be = s_e[j % 3];
-            float* __restrict__ bo = s_o[j % 3];
-            // blocks of 16 rows: all LDS reads of a block are requested at once, then the dependent multiply -> add chain runs
-            // from registers (one LDS latency per block instead of one per two rows)
-            constexpr int U = 16;
-            int tt = nt - 1;
-            for (; tt >= U - 1; tt -= U) {
-                float r[U];
-                uint8_t e[U];
+__global__ __launch_bounds__(256) void rtg_kernel_split(const float* __restrict__ rew, const uint8_t* __restrict__ ended, int T, int N,
+                                                        double gamma, float* __restrict__ out) {
+    __shared__ double s_b[kRtgChunks][kRtgCols], s_a[kRtgChunks][kRtgCols], s_sup[kRtgCols];
+    const int tid = threadIdx.x, col = tid & (kRtgCols - 1), c = tid >> 4;
+    // Workgroups go round-robin over the 8 XCDs (one L2 each) while a 128-byte line holds the rewards of 2 column blocks and
+    // the flags of 8: give each XCD runs of 8 adjacent column blocks so that a line is fetched into one L2, not into eight
+    // (measured 33.6 MB instead of 10.5 MB over the fabric otherwise).  Needs the block count to be a multiple of 64.
+    int q = blockIdx.x;
+    if ((gridDim.x & 63) == 0) {
+        const int x = q & 7, y = q >> 3;
+        q = ((y >> 3) * 8 + x) * 8 + (y & 7);
+    }
+    const size_t n = (size_t)q * kRtgCols + col;   // N % 16 == 0: all 16 columns exist
+    double gpow = 1.0;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    r[u] = br[(tt - u) * kRtgCols + tid];
-                    e[u] = be[(tt - u) * kRtgCols + tid];
-                }
-                float o[U];
+    for (int u = 0; u < kRtgRows; ++u) gpow *= gamma;
+    double rsup = 0;  // ppo.py:660
+    for (int t_hi = T; t_hi > 0; t_hi -= kRtgSuper) {
+        // rows t0 .. t0 + 31 of this chunk; t < 0 only below the first row of the batch (the lowest super-chunk): loaded from
+        // row 0 (any valid address), never stored, and nothing valid depends on them (the scan runs towards them)
+        const int t0 = t_hi - kRtgSuper + c * kRtgRows;
+        float r[kRtgRows];
+        uint8_t e[kRtgRows];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const double g = e[u] ? 0.0 : gamma;
-                    disc = (double)r[u] + disc * g;   // ppo.py:665
-                    o[u] = (float)disc;               // ppo.py:669
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) bo[(tt - u) * kRtgCols + tid] = o[u];
-            }
-            for (; tt >= 0; --tt) {
-                const int k = tt * kRtgCols + tid;
-                const double g = be[k] ? 0.0 : gamma;
-                disc = (double)br[k] + disc * g;
-                bo[k] = (float)disc;
-            }
+        for (int u = kRtgRows - 1; u >= 0; --u) {   // requested in the order pass 1 consumes them
+            const size_t k = (size_t)max(t0 + u, 0) * N + n;
+            r[u] = rew[k];
+            e[u] = ended[k];
         }
+        double b = 0;
+        bool any = false;
+#pragma unroll
+        for (int u = kRtgRows - 1; u >= 0; --u) {
+            const double g = e[u] ? 0.0 : gamma;
+            b = (double)r[u] + b * g;
+            any |= e[u] != 0;
+        }
+        s_b[c][col] = b;
+        s_a[c][col] = any ? 0.0 : gpow;
         __syncthreads();
+        double ak[kRtgChunks], bk[kRtgChunks];
+#pragma unroll
+        for (int k = 1; k < kRtgChunks; ++k) {
+            ak[k] = s_a[k][col];
+            bk[k] = s_b[k][col];
+        }
+        double R = rsup;
+#pragma unroll
+        for (int k = kRtgChunks - 1; k >= 1; --k)
+            if (k > c) R = bk[k] + ak[k] * R;
+#pragma unroll
+        for (int u = kRtgRows - 1; u >= 0; --u) {
+            const double g = e[u] ? 0.0 : gamma;
+            R = (double)r[u] + R * g;   // ppo.py:665
+            if (t0 + u >= 0) out[(size_t)(t0 + u) * N + n] = (float)R;   // ppo.py:669
+        }
+        if (t_hi > kRtgSuper) {   // uniform: another super-chunk follows
+            if (c == 0) s_sup[col] = R;
+            __syncthreads();
+            rsup = s_sup[col];
+        }
     }
 }
 
-// any N / alignment: thread = env column, reverse over T
+// any N / alignment, and the bit-exact mode: thread = env column, reverse over T
 __global__ void rtg_kernel_generic(const float* __restrict__ rew, const uint8_t* __restrict__ ended, int T, int N, double gamma,
                                    float* __restrict__ out) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1816,8 +1817,10 @@ int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, i
     if (T < 0 || N < 0) return fail(NAVSIM_E_ARG, "navsim_rtg_scan: negative size");
     if (T == 0 || N == 0) return NAVSIM_OK;  // empty batch: nothing to scan (pointers may be null)
     if (!rew_dev || !ended_dev || !out_dev) return fail(NAVSIM_E_ARG, "navsim_rtg_scan: null buffer");
-    if ((N % 16 == 0) && (((uintptr_t)rew_dev | (uintptr_t)out_dev | (uintptr_t)ended_dev) % 16 == 0))
-        hipLaunchKernelGGL(rtg_kernel_vec, dim3(N / kRtgCols), dim3(256), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N, gamma,
+    const char* ex = std::getenv("NAVSIM_RTG_EXACT");
+    const bool exact = ex && ex[0] == '1';
+    if (N % kRtgCols == 0 && !exact)
+        hipLaunchKernelGGL(rtg_kernel_split, dim3(N / kRtgCols), dim3(256), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N, gamma,
                            out_dev);
     else
         hipLaunchKernelGGL(rtg_kernel_generic, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N,

@@ -127,8 +127,9 @@ def test_trainer_iterations_run_and_learn_signal(policy):
     assert (tr.act_buf[..., 0] >= 0).all() and (tr.act_buf[..., 0] <= 1).all() and (tr.act_buf[..., 1].abs() <= 1).all()
     # return scan inside the trainer == oracle
     from oracle import navsim_oracle as O
-    np.testing.assert_array_equal(tr.rtg_buf.cpu().numpy(),
-                                  O.compute_rtgs_tn(tr.rew_buf.cpu().numpy(), tr.ended_buf.cpu().numpy(), cfg.gamma))
+    from test_gpu_parity import assert_rtg_close   # <= 1 float32 ulp (T-split scan), see there
+    assert_rtg_close(tr.rtg_buf.cpu().numpy(),
+                     O.compute_rtgs_tn(tr.rew_buf.cpu().numpy(), tr.ended_buf.cpu().numpy(), cfg.gamma))
     env.close()
 
 
