@@ -39,7 +39,7 @@ if "--rollout" in sys.argv:   # the persistent rollout kernel: stamps of its LAS
             print("  wave", w, " ".join(f"{(pol[blk, w, s] - p0) * 10:6d}" for s in range(4)), " step-body start", (b[blk, w, 0] - p0) * 10)
     sys.exit(0)
 N = 4096 if CFG2 else 16384
-EPBv = int(os.environ.get('NAVSIM_EPB', '16'))
+EPBv = int(os.environ.get('NAVSIM_EPB', '64' if N >= 16384 else '32' if N >= 4096 else '16'))   # pick_epb's rule
 sim = NavSim(N, max_episode_steps=500, auto_reset=True, seed=0)
 if CFG2:
     sim.set_map(maps.stage_1(), per_env=False)
@@ -60,18 +60,19 @@ for blk in range(2):
     for w in range(NWV):
         print("  wave", w, " ".join(f"{names[s]}={(b[blk, w, s] - t0) * 10:6d}ns" for s in range(8)))
 
-EPB = int(os.environ.get('NAVSIM_EPB', '16'))
+EPB = EPBv
 blk = np.zeros(8192 * 3, dtype=np.int64)
 L.navsim_blk_read.argtypes = [C.c_void_p]; L.navsim_blk_read(blk.ctypes.data_as(C.c_void_p))
 nb = (N + EPB - 1) // EPB
 blk = blk.reshape(8192, 3)[:nb]
+blk = blk[blk[:, 0] > 0]   # blocks that ran (a wrong EPB guess must not turn the time axis into hours)
 st, en, hw = blk[:, 0], blk[:, 1], blk[:, 2]
 t0 = st.min()
 st = (st - t0) * 10; en = (en - t0) * 10
 print("blocks", nb, "kernel span ns", en.max(), "mean block life ns", (en - st).mean())
 xcc = (hw >> 32) & 0xf; cu = (hw & 0xffffffff) >> 8 & 0xf; se = (hw & 0xffffffff) >> 13 & 0x7
 print("start time histogram (us):", np.histogram(st / 1000, bins=12)[0].tolist())
-for tq in range(0, int(en.max()), 5000):
+for tq in range(0, min(int(en.max()), 200000), 2500):
     print(f"  t={tq/1000:5.1f}us running blocks: {int(((st <= tq) & (en > tq)).sum())}")
 print("xcc counts", np.bincount(xcc.astype(int)).tolist())
 print("first 16 blocks xcc", xcc[:16].tolist(), "start", st[:16].tolist())
