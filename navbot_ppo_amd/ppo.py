@@ -293,12 +293,12 @@ class PPOUpdater:
                     self._fused_epoch(obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
                 if ep == n_ep - 1:
                     h = self._fhist[:n_ep]
-                    self.loss_history = h[:, [0, 4]].clone()
-                    acc = torch.stack([h[:, 0].sum(), h[:, 4].sum(), h[:, 1].sum(), h[:, 2].sum(),
-                                       self.fp.grad.norm() * n_ep, V0.mean() * n_ep])   # grad_norm: LAST epoch's
-                    # (the PyTorch path averages the norm over the epochs; a norm launch per epoch would cost 0.7 % of the
-                    # iteration for a diagnostic, so the fused path reports the final epoch's norm)
-                    a_loss, c_loss = h[-1, 0].clone(), h[-1, 4].clone()
+                    self.loss_history = h[:, 0:5:4].clone()   # columns 0 (actor loss) and 4 (critic loss)
+                    hs = h.sum(0)
+                    acc = torch.cat([hs[[0, 4, 1, 2]], torch.stack([self.fp.grad.norm(), V0.mean()]) * n_ep])
+                    # grad_norm: the LAST epoch's (the PyTorch path averages the norm over the epochs; a norm launch per epoch
+                    # would cost 0.7 % of the iteration for a diagnostic, so the fused path reports the final epoch's norm)
+                    a_loss, c_loss = self.loss_history[-1, 0], self.loss_history[-1, 1]
                 continue
             a_loss, c_loss, ratios, logp, _ = ppo_losses(self.actor, self.critic, obs, acts, logp_old, rtg, adv, var, cfg.clip)
             self.fp.grad.zero_()
@@ -319,7 +319,7 @@ class PPOUpdater:
             acc = acc / world
         n_a = self.fp.module_numel[0]
         d = self.fp.flat - flat_before
-        extra = torch.stack([self.fp.grad[:n_a].norm(), self.fp.grad[n_a:].norm(), d[:n_a].norm(), d[n_a:].norm()])
+        extra = torch.stack(torch._foreach_norm([self.fp.grad[:n_a], self.fp.grad[n_a:], d[:n_a], d[n_a:]]))
         self.stats = dict(zip(["actor_loss", "critic_loss", "approx_kl", "clip_frac", "grad_norm", "value_mean",
                                "actor_grad_norm", "critic_grad_norm", "actor_param_delta", "critic_param_delta"],
                               [float(v) for v in torch.cat([acc, extra]).tolist()]))   # grad norms: the last epoch's
@@ -358,6 +358,7 @@ class PPOTrainer:
         self.eppath_buf = torch.zeros((T, N), dtype=f32, device=dev)
         self.rtg_buf = torch.zeros((T, N), dtype=f32, device=dev)
         self.var = torch.full((), cfg.init_var, dtype=f32, device=dev)  # ppo.py:123-124 (0.8 * I)
+        self.var_host = float(cfg.init_var)   # host mirror, refreshed at every rollout start
         self._lo = torch.tensor([0.0, -1.0], device=dev)
         self._hi = torch.tensor([1.0, 1.0], device=dev)
         self._graph = None
@@ -459,16 +460,19 @@ class PPOTrainer:
         iteration, so the decay is applied once per N episode starts (per mean episode) -- identical for N=1
         up to being applied at the rollout boundary; documented deviation."""
         cfg = self.cfg
+        v = float(self.var)   # the one read-back of the iteration, at its start (the stream is idle here)
         if self.t_so_far > cfg.var_decay_after:
             k = int(round(self.episode_starts / max(self.env.N, 1)))
-            v = float(self.var)
             for _ in range(k):
                 if v >= cfg.var_floor:
                     v *= cfg.var_decay
             self.var.fill_(v)
+        self.var_host = v
         self.episode_starts = 0
 
-    def _rollout_metrics(self):
+    def _rollout_metrics_dev(self):
+        """The six sums behind the iteration's episode metrics as ONE device tensor (all-reduced over the ranks); nothing
+        here waits for the GPU, so the update can be queued behind it."""
         ended = self.ended_buf.bool()
         arrive = self.arrive_buf.bool() & ended
         done = self.done_buf.bool() & ended
@@ -477,32 +481,48 @@ class PPOTrainer:
         m = torch.cat([m, (self.epret_buf.double() * ended).sum().view(1)])
         if self.ctx is not None:
             self.ctx.all_reduce_sum(m)
-        ep, succ, coll, tmo, steps, ret = [float(x) for x in m.tolist()]
+        return m
+
+    def _rollout_metrics(self, m=None):
+        ep, succ, coll, tmo, steps, ret = [float(x) for x in (self._rollout_metrics_dev() if m is None else m).tolist()]
         self.episode_starts = ep / (self.ctx.world if self.ctx is not None else 1) + self.env.N
         return dict(episodes=int(ep), successes=int(succ), collisions=int(coll), timeouts=int(tmo),
                     completed_steps=int(steps), avg_ep_rews=(ret / ep if ep else 0.0),       # ppo.py:833
                     avg_ep_lens=(steps / ep if ep else 0.0), success_rate=(succ / ep if ep else 0.0))
 
     def iteration(self):
+        """One pass of the loop of PPO.learn (ppo.py:241-459).  Rollout, metric sums and update are queued back to back and
+        the host waits once, at the end; rollout / update times come from events on the stream (wall clock on CPU)."""
         cfg = self.cfg
-        sync = (lambda: torch.cuda.synchronize(self.device)) if self.device.type == "cuda" else (lambda: None)
-        t0 = time.time()
-        self.rollout()
-        sync()
-        t1 = time.time()
+        cuda = self.device.type == "cuda"
         T, N, D = cfg.rollout_len, self.env.N, self.env.D
-        metrics = self._rollout_metrics()
+        t0 = time.time()
+        if cuda:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+        self.rollout()
+        if cuda:
+            ev[1].record()
+        t1 = time.time()
+        m = self._rollout_metrics_dev()
+        stats = self.updater.update(self.obs_buf[:T].reshape(T * N, D), self.act_buf.reshape(T * N, 2),
+                                    self.logp_buf.reshape(T * N), self.rtg_buf.reshape(T * N),
+                                    self.var_host if self.updater.fused_mlp64 else self.var)
+        if cuda:
+            ev[2].record()
+            torch.cuda.synchronize(self.device)
+        t2 = time.time()
+        if cuda:   # the host ran ahead of the stream: split the wall clock of the iteration by the stream's own stamps
+            r_ms, u_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+            t1 = t0 + (t2 - t0) * r_ms / max(r_ms + u_ms, 1e-9)
+        metrics = self._rollout_metrics(m)
         self.t_so_far += metrics["completed_steps"]
         self.i_so_far += 1
-        stats = self.updater.update(self.obs_buf[:T].reshape(T * N, D), self.act_buf.reshape(T * N, 2),
-                                    self.logp_buf.reshape(T * N), self.rtg_buf.reshape(T * N), self.var)
-        sync()
-        t2 = time.time()
         world = self.ctx.world if self.ctx is not None else 1
         self.logger = dict(metrics, **stats, iteration=self.i_so_far, t_so_far=self.t_so_far,
                            rollout_time=t1 - t0, update_time=t2 - t1, iter_time=t2 - t0,
                            steps_per_sec=T * N * world / (t2 - t0),                      # ppo.py:855
-                           rollout_steps_per_sec=T * N * world / (t1 - t0), var=float(self.var))
+                           rollout_steps_per_sec=T * N * world / (t1 - t0), var=self.var_host)
         if cfg.output_dir and (self.ctx is None or self.ctx.rank == 0):
             if self.i_so_far % cfg.save_freq == 0:
                 self.save_checkpoint()
