@@ -53,6 +53,16 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
 int navppo_adam_step(float* params_dev, const float* grad_dev, float* adam_m_dev, float* adam_v_dev, int64_t n, float grad_scale,
                      float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
 
+/*
+ * The episode sums behind one iteration's log line (ppo.py:552-560, :833) over the [T, N] buffers a rollout fills (n = T N
+ * entries each): sums_dev [6] f64 = episodes (ended), successes (arrive), collisions (done and not arrive), timeouts (ended,
+ * neither), sum of ep_length (all entries; the buffer is zero where no episode ended), sum of ep_return over ended entries.
+ * workspace_dev: NAVPPO_EPISODE_SUMS_WS_BYTES.  Per-block partials are added in a fixed order: the result is deterministic.
+ */
+#define NAVPPO_EPISODE_SUMS_WS_BYTES (256 * 6 * 8)
+int navppo_episode_sums(const uint8_t* ended_dev, const uint8_t* arrive_dev, const uint8_t* done_dev, const int32_t* ep_length_dev,
+                        const float* ep_return_dev, int64_t n, double* sums_dev, void* workspace_dev, void* stream);
+
 /* V = critic(obs).squeeze() (ppo.py:275, :724) for n rows: the forward half of the critic's fused pass.  value_dev [n] f32. */
 int navppo_mlp64_value(const float* critic_params_dev, const float* obs_dev, int64_t n_samples, float* value_dev, void* stream);
 

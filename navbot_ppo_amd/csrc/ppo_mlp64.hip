@@ -616,6 +616,55 @@ __global__ __launch_bounds__(64) void mlp64_act(const float* __restrict__ params
     }
 }
 
+// ---------------------------------------------------------------- episode sums of one rollout (the iteration's logging line)
+// ppo.py:552-560,833: episodes, successes (arrive), collisions (done and not arrive), timeouts (neither), the sum of episode
+// lengths and the sum of episode returns over the [T, N] buffers a rollout fills.  One pass over 22 MB instead of a dozen
+// PyTorch reductions; per-block partials summed in a fixed order, so the result does not depend on the schedule.
+constexpr int kSumBlocks = 256, kSumThreads = 256;
+
+__global__ __launch_bounds__(kSumThreads) void episode_sums_partial(const uint8_t* __restrict__ ended, const uint8_t* __restrict__ arrive,
+                                                                     const uint8_t* __restrict__ done, const int32_t* __restrict__ ep_len,
+                                                                     const float* __restrict__ ep_ret, long long n,
+                                                                     double* __restrict__ partial) {
+    __shared__ double red[kSumThreads / 64][6];
+    unsigned c_ep = 0, c_ok = 0, c_hit = 0, c_tmo = 0;
+    long long len = 0;
+    double ret = 0;
+    const long long stride = (long long)gridDim.x * kSumThreads;
+    for (long long k = (long long)blockIdx.x * kSumThreads + threadIdx.x; k < n; k += stride) {
+        const bool e = ended[k] != 0, a = (arrive[k] != 0) && e, d = (done[k] != 0) && e;
+        c_ep += e;
+        c_ok += a;
+        c_hit += d && !a;
+        c_tmo += e && !d && !a;
+        len += ep_len[k];
+        ret += e ? (double)ep_ret[k] : 0.0;
+    }
+    double v[6] = {(double)c_ep, (double)c_ok, (double)c_hit, (double)c_tmo, (double)len, ret};
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v[j] += __shfl_xor(v[j], m, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) red[wave][j] = v[j];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double t = 0;
+        for (int w = 0; w < kSumThreads / 64; ++w) t += red[w][threadIdx.x];
+        partial[(size_t)blockIdx.x * 6 + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void episode_sums_final(const double* __restrict__ partial, int blocks, double* __restrict__ out) {
+    if (threadIdx.x < 6) {
+        double t = 0;
+        for (int b = 0; b < blocks; ++b) t += partial[(size_t)b * 6 + threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+}
+
 thread_local std::string g_err;
 
 }  // namespace
@@ -733,6 +782,26 @@ int navppo_mlp64_update_epoch(float* params_dev, const float* obs_dev, const flo
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_update_epoch: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+int navppo_episode_sums(const uint8_t* ended_dev, const uint8_t* arrive_dev, const uint8_t* done_dev, const int32_t* ep_length_dev,
+                        const float* ep_return_dev, int64_t n, double* sums_dev, void* workspace_dev, void* stream) {
+    if (!ended_dev || !arrive_dev || !done_dev || !ep_length_dev || !ep_return_dev || !sums_dev || !workspace_dev || n < 0) {
+        g_err = "navppo_episode_sums: bad argument";
+        return -1;
+    }
+    double* partial = reinterpret_cast<double*>(workspace_dev);
+    const long long want = (n + kSumThreads - 1) / kSumThreads;
+    const int blocks = (int)(want < 1 ? 1 : (want < kSumBlocks ? want : kSumBlocks));
+    hipLaunchKernelGGL(episode_sums_partial, dim3(blocks), dim3(kSumThreads), 0, (hipStream_t)stream, ended_dev, arrive_dev, done_dev,
+                       ep_length_dev, ep_return_dev, (long long)n, partial);
+    hipLaunchKernelGGL(episode_sums_final, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, blocks, sums_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_err = std::string("navppo_episode_sums: ") + hipGetErrorString(e);
         return -2;
     }
     return 0;

@@ -473,12 +473,18 @@ class PPOTrainer:
     def _rollout_metrics_dev(self):
         """The six sums behind the iteration's episode metrics as ONE device tensor (all-reduced over the ranks); nothing
         here waits for the GPU, so the update can be queued behind it."""
-        ended = self.ended_buf.bool()
-        arrive = self.arrive_buf.bool() & ended
-        done = self.done_buf.bool() & ended
-        m = torch.stack([ended.sum(), arrive.sum(), (done & ~arrive).sum(), (ended & ~done & ~arrive).sum(),
-                         self.eplen_buf.sum()]).double()
-        m = torch.cat([m, (self.epret_buf.double() * ended).sum().view(1)])
+        import ctypes as C   # one pass over the five buffers (navppo_episode_sums), deterministic
+        from ._native import lib
+        ptr = lambda x: C.c_void_p(x.data_ptr())
+        if getattr(self, "_sums_ws", None) is None:
+            self._sums_ws = torch.empty(256 * 6, dtype=torch.float64, device=self.device)
+        m = torch.empty(6, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = lib().navppo_episode_sums(ptr(self.ended_buf), ptr(self.arrive_buf), ptr(self.done_buf), ptr(self.eplen_buf),
+                                           ptr(self.epret_buf), self.ended_buf.numel(), ptr(m), ptr(self._sums_ws),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"navppo_episode_sums failed: {lib().navppo_last_error().decode()}")
         if self.ctx is not None:
             self.ctx.all_reduce_sum(m)
         return m

@@ -329,3 +329,33 @@ def test_fused_multi_rank_epoch_equals_single_rank(tmp_path):
     cu = lambda k: torch.from_numpy(d[k]).cuda()
     up.update(cu("obs"), cu("acts"), cu("logp"), cu("rtgs"), torch.tensor(0.8, device="cuda"))
     np.testing.assert_allclose(r0["flat"].numpy(), up.fp.flat.cpu().numpy(), rtol=0, atol=3e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 1), (7, 33), (512, 4096), (100, 37)])
+def test_episode_sums_match_torch_reductions(shape):
+    """navppo_episode_sums == the reductions behind the iteration's log line (ppo.py:552-560, :833), counts exact, the
+    float64 return sum to 1e-12 relative, and identical from call to call (fixed summation order)."""
+    import ctypes as C
+    from navbot_ppo_amd._native import lib
+    g = torch.Generator().manual_seed(5)
+    ended = (torch.rand(shape, generator=g) < 0.05).to(torch.uint8)
+    arrive = (torch.rand(shape, generator=g) < 0.3).to(torch.uint8)    # also set where no episode ended: must not count
+    done = (torch.rand(shape, generator=g) < 0.5).to(torch.uint8)
+    eplen = (torch.randint(1, 500, shape, generator=g) * ended).to(torch.int32)
+    epret = (torch.randn(shape, generator=g) * 300).float()            # garbage outside ended entries: masked by the kernel
+    e, a, d = ended.bool(), arrive.bool() & ended.bool(), done.bool() & ended.bool()
+    want = [e.sum().item(), a.sum().item(), (d & ~a).sum().item(), (e & ~d & ~a).sum().item(), eplen.sum().item(),
+            (epret.double() * e).sum().item()]
+    bufs = [t.cuda().contiguous() for t in (ended, arrive, done, eplen, epret)]
+    ws = torch.empty(256 * 6, dtype=torch.float64, device="cuda")
+    outs = []
+    for _ in range(2):
+        out = torch.full((6,), -1.0, dtype=torch.float64, device="cuda")
+        rc = lib().navppo_episode_sums(*[C.c_void_p(t.data_ptr()) for t in bufs], ended.numel(), C.c_void_p(out.data_ptr()),
+                                       C.c_void_p(ws.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        outs.append(out.cpu().numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0][:5], np.array(want[:5], dtype=np.float64))
+    assert abs(outs[0][5] - want[5]) <= 1e-12 * max(1.0, abs(want[5])) + 1e-9
