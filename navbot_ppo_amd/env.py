@@ -262,11 +262,14 @@ class Env:
         else:
             seg = map
         self._sim.set_map(seg)
-        self._io = self._sim.alloc_io()
-        dev = self._sim.device
-        self._ap = torch.zeros((2, 1, 2), dtype=torch.float32, device=dev)     # action | past_action: one H2D copy per step
-        self._ap_host = torch.zeros((2, 1, 2), dtype=torch.float32).pin_memory()
-        self._out = torch.zeros(16 + 3, dtype=torch.float32, device=dev)         # obs | reward | done | arrive: one D2H copy
+        # One pinned (host-mapped, device-visible) block carries a step's inputs and outputs: the kernel reads the action pair
+        # from it and stores observation, reward and flags into it, so a step is one launch + one stream wait, no copies.
+        self._pin = torch.zeros(48, dtype=torch.float32).pin_memory()
+        self._pin_u8 = torch.zeros(16, dtype=torch.uint8).pin_memory()
+        self._pin_np, self._pin_u8_np = self._pin.numpy(), self._pin_u8.numpy()
+        self._act_t, self._past_t = self._pin[0:2].view(1, 2), self._pin[2:4].view(1, 2)
+        self._obs_t, self._rew_t = self._pin[16:32].view(1, 16), self._pin[32:33]
+        self._done_t, self._arrive_t, self._ended_t = self._pin_u8[0:1], self._pin_u8[1:2], self._pin_u8[2:3]
         self._state = None   # host copy of pose / goal / past_distance, fetched when an attribute is read
 
     # -- attributes the reference's callers read (ppo.py:535, main.py:202; environment_new.py:29-41): fetched lazily, one
@@ -296,28 +299,28 @@ class Env:
     def past_distance(self):
         return float(self._st()["past_dist"][0])
 
+    def _wait(self):
+        torch.cuda.current_stream(self._sim.device).synchronize()   # the step's only synchronisation
+
     def reset(self):
-        self._sim.reset(self._io.obs)
+        self._sim.reset(self._obs_t)
+        self._wait()
         self._state = None
-        return self._io.obs[0].double().cpu().numpy()
+        return self._pin_np[16:32].astype(np.float64)
 
     def step(self, action, past_action):
         a = np.asarray(action, dtype=np.float32).reshape(-1)
         p = np.asarray(past_action, dtype=np.float32).reshape(-1)
         if a.shape[0] < 2 or p.shape[0] < 2:
             raise IndexError("action and past_action need two components")  # as action[1] would in the reference
-        self._ap_host[0, 0, 0], self._ap_host[0, 0, 1] = float(a[0]), float(a[1])
-        self._ap_host[1, 0, 0], self._ap_host[1, 0, 1] = float(p[0]), float(p[1])
-        self._ap.copy_(self._ap_host, non_blocking=True)
-        io = self._io
-        self._sim.step(self._ap[0], io.obs, io.reward, io.done, io.arrive, io.ended, None, None, past_action=self._ap[1])
-        self._out[:16] = io.obs[0]
-        self._out[16] = io.reward[0]
-        self._out[17] = io.done[0]
-        self._out[18] = io.arrive[0]
-        out = self._out.cpu().numpy()          # the step's only synchronisation
+        self._pin_np[0:2] = a[:2]
+        self._pin_np[2:4] = p[:2]
+        self._sim.step(self._act_t, self._obs_t, self._rew_t, self._done_t, self._arrive_t, self._ended_t, None, None,
+                       past_action=self._past_t)
+        self._wait()
         self._state = None
-        return out[:16].astype(np.float64), float(out[16]), bool(out[17]), bool(out[18])
+        return (self._pin_np[16:32].astype(np.float64), float(self._pin_np[32]), bool(self._pin_u8_np[0]),
+                bool(self._pin_u8_np[1]))
 
     def getLatestImage(self):
         return None

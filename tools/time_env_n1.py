@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev tool: steps/s of the N=1 drop-in `Env` (one H2D + launch + D2H per step), the surface project_ppo/src/ppo.py drives."""
+"""Dev tool: steps/s of the N=1 drop-in `Env` (one launch + one stream wait per step), the surface project_ppo/src/ppo.py drives."""
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np
