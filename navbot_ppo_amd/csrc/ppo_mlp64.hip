@@ -622,6 +622,7 @@ __global__ __launch_bounds__(64) void mlp64_act(const float* __restrict__ params
 // PyTorch reductions; per-block partials summed in a fixed order, so the result does not depend on the schedule.
 constexpr int kSumBlocks = 256, kSumThreads = 256;
 
+template <bool VEC>   // VEC: four entries per thread and load (n % 4 == 0, 16-byte aligned buffers)
 __global__ __launch_bounds__(kSumThreads) void episode_sums_partial(const uint8_t* __restrict__ ended, const uint8_t* __restrict__ arrive,
                                                                      const uint8_t* __restrict__ done, const int32_t* __restrict__ ep_len,
                                                                      const float* __restrict__ ep_ret, long long n,
@@ -630,15 +631,30 @@ __global__ __launch_bounds__(kSumThreads) void episode_sums_partial(const uint8_
     unsigned c_ep = 0, c_ok = 0, c_hit = 0, c_tmo = 0;
     long long len = 0;
     double ret = 0;
-    const long long stride = (long long)gridDim.x * kSumThreads;
-    for (long long k = (long long)blockIdx.x * kSumThreads + threadIdx.x; k < n; k += stride) {
-        const bool e = ended[k] != 0, a = (arrive[k] != 0) && e, d = (done[k] != 0) && e;
+    auto one = [&](unsigned eb, unsigned ab, unsigned db, int l, float r) {
+        const bool e = eb != 0, a = (ab != 0) && e, d = (db != 0) && e;
         c_ep += e;
         c_ok += a;
         c_hit += d && !a;
         c_tmo += e && !d && !a;
-        len += ep_len[k];
-        ret += e ? (double)ep_ret[k] : 0.0;
+        len += l;
+        ret += e ? (double)r : 0.0;
+    };
+    const long long stride = (long long)gridDim.x * kSumThreads;
+    if (VEC) {
+        for (long long q = (long long)blockIdx.x * kSumThreads + threadIdx.x; q < n / 4; q += stride) {
+            const unsigned e4 = reinterpret_cast<const unsigned*>(ended)[q], a4 = reinterpret_cast<const unsigned*>(arrive)[q],
+                           d4 = reinterpret_cast<const unsigned*>(done)[q];
+            const int4 l4 = reinterpret_cast<const int4*>(ep_len)[q];
+            const float4 r4 = reinterpret_cast<const float4*>(ep_ret)[q];
+            one(e4 & 0xffu, a4 & 0xffu, d4 & 0xffu, l4.x, r4.x);
+            one((e4 >> 8) & 0xffu, (a4 >> 8) & 0xffu, (d4 >> 8) & 0xffu, l4.y, r4.y);
+            one((e4 >> 16) & 0xffu, (a4 >> 16) & 0xffu, (d4 >> 16) & 0xffu, l4.z, r4.z);
+            one(e4 >> 24, a4 >> 24, d4 >> 24, l4.w, r4.w);
+        }
+    } else {
+        for (long long k = (long long)blockIdx.x * kSumThreads + threadIdx.x; k < n; k += stride)
+            one(ended[k], arrive[k], done[k], ep_len[k], ep_ret[k]);
     }
     double v[6] = {(double)c_ep, (double)c_ok, (double)c_hit, (double)c_tmo, (double)len, ret};
 #pragma unroll
@@ -657,12 +673,20 @@ __global__ __launch_bounds__(kSumThreads) void episode_sums_partial(const uint8_
     }
 }
 
-__global__ __launch_bounds__(64) void episode_sums_final(const double* __restrict__ partial, int blocks, double* __restrict__ out) {
-    if (threadIdx.x < 6) {
-        double t = 0;
-        for (int b = 0; b < blocks; ++b) t += partial[(size_t)b * 6 + threadIdx.x];
-        out[threadIdx.x] = t;
+// the partial rows of up to kSumBlocks workgroups, pairwise in a fixed tree
+__global__ __launch_bounds__(kSumBlocks) void episode_sums_final(const double* __restrict__ partial, int blocks, double* __restrict__ out) {
+    __shared__ double red[kSumBlocks][6];
+    const int b = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) red[b][j] = (b < blocks) ? partial[(size_t)b * 6 + j] : 0.0;
+    __syncthreads();
+    for (int h = kSumBlocks / 2; h >= 1; h >>= 1) {
+        if (b < h)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) red[b][j] += red[b + h][j];
+        __syncthreads();
     }
+    if (b < 6) out[b] = red[0][b];
 }
 
 thread_local std::string g_err;
@@ -796,9 +820,15 @@ int navppo_episode_sums(const uint8_t* ended_dev, const uint8_t* arrive_dev, con
     double* partial = reinterpret_cast<double*>(workspace_dev);
     const long long want = (n + kSumThreads - 1) / kSumThreads;
     const int blocks = (int)(want < 1 ? 1 : (want < kSumBlocks ? want : kSumBlocks));
-    hipLaunchKernelGGL(episode_sums_partial, dim3(blocks), dim3(kSumThreads), 0, (hipStream_t)stream, ended_dev, arrive_dev, done_dev,
-                       ep_length_dev, ep_return_dev, (long long)n, partial);
-    hipLaunchKernelGGL(episode_sums_final, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, blocks, sums_dev);
+    const bool vec = (n % 4 == 0) && !(((uintptr_t)ended_dev | (uintptr_t)arrive_dev | (uintptr_t)done_dev) & 3) &&
+                     !(((uintptr_t)ep_length_dev | (uintptr_t)ep_return_dev) & 15);
+    if (vec)
+        hipLaunchKernelGGL(episode_sums_partial<true>, dim3(blocks), dim3(kSumThreads), 0, (hipStream_t)stream, ended_dev, arrive_dev,
+                           done_dev, ep_length_dev, ep_return_dev, (long long)n, partial);
+    else
+        hipLaunchKernelGGL(episode_sums_partial<false>, dim3(blocks), dim3(kSumThreads), 0, (hipStream_t)stream, ended_dev, arrive_dev,
+                           done_dev, ep_length_dev, ep_return_dev, (long long)n, partial);
+    hipLaunchKernelGGL(episode_sums_final, dim3(1), dim3(kSumBlocks), 0, (hipStream_t)stream, partial, blocks, sums_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_episode_sums: ") + hipGetErrorString(e);
