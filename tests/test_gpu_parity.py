@@ -722,3 +722,48 @@ def test_actions_outside_the_policy_range():
     seg = maps.replicate_per_env(maps.stage_2(), N, seed=2)
     gpu, cpu = _mk(N, seg, per_env=True, max_episode_steps=20, auto_reset=True, seed=13)
     _lockstep(gpu, cpu, a[:40])
+
+
+def test_g10_reference_rollout_through_the_env_class():
+    """a-8 / b: G10 replayed through the N = 1 drop-in class `Env`, driven EXACTLY as the reference's rollout drives its Env
+    (ppo.py:486 reset at batch start; :535 position read for the path length; :541 step(action, past_action);
+    :543 past_action <- action; :552-553 termination; :591-593 past_action <- [0, 0] and a caller-side reset()).
+    `Env.step` never resets and re-spawns the goal on arrival like setReward (environment_new.py:245-267), so the goal
+    stream must advance exactly as the reference's did (rng_ctr_final)."""
+    from navbot_ppo_amd.env import Env, rtg_scan
+    from test_rollout_golden_cpu import check_against_g10, replay_on
+    d = np.load(os.path.join(G, "g10_rollout.npz"))
+    cap = int(d["cap"])
+    env = Env(is_training=True, seed=int(d["seed"]))
+
+    class Caller:   # the caller side of ppo.py:486-594, returning what replay_on() stores
+        def reset(self):
+            self.past_action, self.one_round, self.ep_ret, self.path, self.prev = [0, 0], 0, 0.0, 0.0, None
+            return env.reset()[None, :]
+
+        def step(self, a):
+            cur = np.array([env.position.x, env.position.y])               # ppo.py:535
+            if self.prev is not None:
+                self.path += float(np.linalg.norm(cur - self.prev))
+            self.prev = cur
+            obs, rew, done, arrive = env.step(a[0], self.past_action)       # ppo.py:541
+            assert obs.shape == (16,) and obs.dtype == np.float64 and isinstance(rew, float)
+            assert isinstance(done, bool) and isinstance(arrive, bool)
+            self.past_action = a[0]                                         # ppo.py:543
+            self.ep_ret += rew
+            self.one_round += 1
+            ended = done or arrive or self.one_round >= cap                 # ppo.py:552-553
+            out = dict(reward=np.float32([rew]), done=np.uint8([done]), arrive=np.uint8([arrive]), ended=np.uint8([ended]),
+                       ep_return=np.float32([self.ep_ret if ended else 0]), ep_length=np.int32([self.one_round if ended else 0]),
+                       ep_path=np.float32([self.path if ended else 0]))
+            if ended:
+                obs = self.reset()[0]                                       # ppo.py:591-593
+            out["obs"] = obs[None, :]
+            return out
+
+    obs, rew, ended, flags, eplen, epret, eppath = replay_on(Caller(), d)
+    rtg = rtg_scan(torch.from_numpy(rew[:, None].copy()).cuda(), torch.from_numpy(ended[:, None].copy()).cuda(),
+                   float(d["gamma"])).cpu().numpy()[:, 0]
+    check_against_g10(d, obs, rew, ended, flags, eplen, epret, eppath, rtg)
+    assert int(env._sim.get_state()["rng_ctr"][0]) == int(d["rng_ctr_final"])
+    env.close()

@@ -25,7 +25,7 @@ def _batch(n, seed, dev):
     return [t.to(dev).contiguous() for t in (obs, acts, logp, rtg, adv)]
 
 
-@pytest.mark.parametrize("n", [128, 1000, 128 * 300 + 7, 1 << 17])
+@pytest.mark.parametrize("n", [128, 1000, 128 * 300 + 7, 1 << 17, 512 * 4096])   # the last one is the bench's own batch
 def test_fused_mlp64_gradients_match_autograd(n):
     dev = torch.device("cuda")
     torch.manual_seed(3)
@@ -359,3 +359,57 @@ def test_episode_sums_match_torch_reductions(shape):
     np.testing.assert_array_equal(outs[0], outs[1])
     np.testing.assert_array_equal(outs[0][:5], np.array(want[:5], dtype=np.float64))
     assert abs(outs[0][5] - want[5]) <= 1e-12 * max(1.0, abs(want[5])) + 1e-9
+
+
+def test_persistent_rollout_at_bench_size_against_the_oracle():
+    """navsim_rollout_mlp64 at the timed configuration (BASELINE configs[1]: T = 512, N = 4096, episode cap 500) checked
+    DIRECTLY against the oracle, not against the per-step HIP path: the actions the kernel recorded for a block of 96 envs
+    are replayed on an OracleSim keyed by the same global env ids (goal stream = Philox(seed, env id)); flags must be
+    bit-exact, observations within 1e-6, rewards within 1e-5; the stored log-probs are those of the stored (clamped)
+    actions under PyTorch's evaluation of the same actor (ppo.py:696-704)."""
+    from navbot_ppo_amd import maps
+    from navbot_ppo_amd.env import VecEnv
+    from oracle import navsim_oracle as O
+    N, T, cap, lo, n_s = 4096, 512, 500, 2000, 96
+    env = VecEnv(N, map="stage_1", max_episode_steps=cap, seed=7)
+    cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=cap, policy="mlp64x2", seed=3)
+    tr = ppo.PPOTrainer(env, cfg)
+    with torch.no_grad():   # drive: a forward bias so that collisions / arrivals happen inside 512 steps, not only timeouts
+        tr.actor.layer3.bias.add_(2.0)
+    tr.rollout()
+    torch.cuda.synchronize()
+    assert tr.updater.fused_mlp64 and cfg.persistent_rollout
+    sl = slice(lo, lo + n_s)
+    acts = tr.act_buf[:, sl].cpu().numpy()
+    cpu = O.OracleSim(n_s, max_episode_steps=cap, auto_reset=True, seed=7, env_id_base=lo)
+    cpu.set_map(maps.stage_1())
+    rr, rs = maps.goal_rects("stage_1")
+    cpu.set_goal_rects(0, rr)
+    cpu.set_goal_rects(1, rs)
+    obs = tr.obs_buf[:, sl].cpu().numpy()
+    np.testing.assert_allclose(obs[0], cpu.reset(), rtol=0, atol=1e-6)
+    g = {k: getattr(tr, k + "_buf")[:, sl].cpu().numpy() for k in ("rew", "done", "arrive", "ended", "epret", "eplen", "eppath")}
+    n_end = 0
+    for t in range(T):
+        out = cpu.step(acts[t])
+        for k in ("done", "arrive", "ended"):
+            np.testing.assert_array_equal(g[k][t], out[k], err_msg=f"{k}, step {t}")
+        np.testing.assert_allclose(obs[t + 1], out["obs"], rtol=0, atol=1e-6, err_msg=f"obs, step {t}")
+        np.testing.assert_allclose(g["rew"][t], out["reward"], rtol=1e-5, atol=1e-5, err_msg=f"reward, step {t}")
+        e = out["ended"].astype(bool)
+        np.testing.assert_array_equal(g["eplen"][t][e], out["ep_length"][e])
+        np.testing.assert_allclose(g["epret"][t][e], out["ep_return"][e], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(g["eppath"][t][e], out["ep_path"][e], rtol=1e-6, atol=1e-7)
+        n_end += int(e.sum())
+    assert n_end >= n_s and int(g["done"].sum()) > 0          # every env ended at least once; collisions happened
+    # policy side over the WHOLE rollout: log-prob of the stored clamped action under the PyTorch actor, action range
+    with torch.no_grad():
+        o = tr.obs_buf[:T].reshape(T * N, 16)
+        lp_ref = ppo.gaussian_log_prob(tr.actor(o), tr.act_buf.reshape(T * N, 2), tr.var)
+    np.testing.assert_allclose(tr.logp_buf.reshape(-1).cpu().numpy(), lp_ref.cpu().numpy(), rtol=1e-4, atol=3e-5)
+    a = tr.act_buf
+    assert (a[..., 0] >= 0).all() and (a[..., 0] <= 1).all() and (a[..., 1].abs() <= 1).all()
+    # return scan of the same buffers == the oracle's compute_rtgs (<= 1 f32 ulp, the T-split scan's contract)
+    from test_gpu_parity import assert_rtg_close
+    assert_rtg_close(tr.rtg_buf[:, sl].cpu().numpy(), O.compute_rtgs_tn(g["rew"], g["ended"], cfg.gamma))
+    env.close()
