@@ -92,6 +92,45 @@ int navppo_mlp64_act(const float* actor_params_dev, const float* obs_dev, const 
                      const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
                      uint32_t step_offset, float* act_dev, float* logp_dev, float* mean_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * The reference's ACTIVE nets ("resmlp512"): NetActor / NetCritic (project_ppo/src/net_actor.py:56-144, net_critic.py:50-130),
+ * two residual blocks ResBlock(16, 16) and ResBlock(32, 32) with 512 hidden units and LeakyReLU(0.2)
+ * (net_actor.py:16-53), actor heads sigmoid(out1) / tanh(out2), critic head out.  Fused f32-MFMA kernels
+ * (csrc/ppo_resmlp512.hip); same contracts as the mlp64 entry points above unless stated.
+ *
+ *   params_dev  [50290 + 50257] f32   actor then critic, each in nn.Module.named_parameters() order WITHOUT the BatchNorm
+ *               entries the reference's forward never uses (net_actor.py:44,48,137):
+ *               rb1.fc1.weight[512,16], rb1.fc1.bias[512], rb1.fc2.weight[16,512], rb1.fc2.bias[16],
+ *               rb2.fc1.weight[512,32], rb2.fc1.bias[512], rb2.fc2.weight[32,512], rb2.fc2.bias[32],
+ *               out1.weight[1,32], out1.bias[1], out2.weight[1,32], out2.bias[1]      (critic: out.weight[1,32], out.bias[1])
+ *   workspace_dev  navppo_resmlp512_workspace_bytes(n_samples) bytes (partial block outputs per hidden slice, 2.5 KB per
+ *               sample, + partial-gradient rows); contents are scratch.
+ */
+#define NAVPPO_RESMLP512_ACTOR_PARAMS 50290
+#define NAVPPO_RESMLP512_CRITIC_PARAMS 50257
+
+size_t navppo_resmlp512_workspace_bytes(int64_t n_samples);
+
+/* evaluate() + losses + both backward() calls of ppo.py:307-386; grad_dev [50290 + 50257], stats_dev [8] as navppo_mlp64_loss_grad */
+int navppo_resmlp512_loss_grad(const float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
+                               const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip,
+                               float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
+
+/* one whole epoch of ppo.py:305-392 on one GPU (losses, gradients, both Adam steps); as navppo_mlp64_update_epoch */
+int navppo_resmlp512_update_epoch(float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
+                                  const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
+                                  float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
+                                  float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
+
+/* V = critic(obs).squeeze() (ppo.py:275, :724); critic_params_dev [50257] (8-byte aligned suffices), value_dev [n] */
+int navppo_resmlp512_value(const float* critic_params_dev, const float* obs_dev, int64_t n_samples, float* value_dev,
+                           void* workspace_dev, void* stream);
+
+/* PPO.get_action() (ppo.py:673-706) for all envs of a shard in one launch; arguments as navppo_mlp64_act, actor_params_dev [50290] */
+int navppo_resmlp512_act(const float* actor_params_dev, const float* obs_dev, const float* noise_dev, int64_t n_envs,
+                         const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
+                         uint32_t step_offset, float* act_dev, float* logp_dev, float* mean_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

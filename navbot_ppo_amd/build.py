@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-SRCS = [os.path.join(HERE, "csrc", "navsim.hip"), os.path.join(HERE, "csrc", "ppo_mlp64.hip")]
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("navsim.hip", "ppo_mlp64.hip", "ppo_resmlp512.hip")]
 HDRS = ["navsim.h", "navppo.h"]
 INC = os.path.join(REPO, "include")
 LIB = os.path.join(HERE, "libnavsim.so")
@@ -28,7 +28,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SRCS + [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", "mlp64_policy.h")]
+    deps = SRCS + [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h")]
     return any(os.path.getmtime(p) > t for p in deps)
 
 

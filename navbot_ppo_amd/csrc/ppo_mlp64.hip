@@ -33,6 +33,7 @@
 #include <string>
 
 #include "navppo.h"
+#include "navppo_internal.h"
 #include "mlp64_policy.h"
 
 namespace {
@@ -692,6 +693,8 @@ __global__ __launch_bounds__(kSumBlocks) void episode_sums_final(const double* _
 thread_local std::string g_err;
 
 }  // namespace
+
+void navppo_set_error(const char* msg) { g_err = msg ? msg : ""; }
 
 #pragma GCC visibility push(default)
 extern "C" {

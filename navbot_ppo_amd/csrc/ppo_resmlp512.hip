@@ -1,0 +1,959 @@
+// ppo_resmlp512.hip -- fused PPO update + rollout-time policy step for the reference's ACTIVE nets on gfx950 (f32 MFMA).
+//
+// Nets (project_ppo/src/net_actor.py:16-144, net_critic.py:13-130), D = 16 observation floats:
+//   rb1   h1 = leaky(x + W2a leaky(W1a x + b1a) + b2a)            W1a [512,16], W2a [16,512]
+//   X1    = cat[x, h1]                                             (32)
+//   rb2   h2 = leaky(X1 + W2b leaky(W1b X1 + b1b) + b2b)           W1b [512,32], W2b [32,512]
+//   actor mean = (sigmoid(wo1 . h2 + bo1), tanh(wo2 . h2 + bo2)) ;  critic V = wo . h2 + bo        LeakyReLU(0.2) throughout
+// and one epoch of the update loop (project_ppo/src/ppo.py:305-397): evaluate() (:708-737), ratios / clipped surrogate
+// (:316-320,342), MSE critic loss (:343), both backward() calls (:349,386) and both Adam steps (:381,392).
+//
+// Why kernels: through PyTorch every [2.1 M, 512] f32 hidden activation (4.3 GB) makes several HBM round trips per epoch
+// (round 2: 41 ms per epoch, 19 % of the f32-MFMA peak).  Here a 512-wide hidden activation never leaves the registers of
+// the wave that produced it.
+//
+// What does not fit on a CU, and the decomposition that follows from it.  One net has 192 KB of weights and as many weight
+// gradients; a CU has 160 KB of LDS and 512 KB of registers.  So the hidden dimension is cut into NSL = 4 SLICES of 128
+// units and a workgroup owns (net, slice, group of sample tiles): its slice of the weights sits in LDS (<= 37 KB), its slice
+// of the weight gradients in accumulator registers (<= 128 per lane) for the whole launch, and a WAVE owns a 32-sample
+// tile end to end (no workgroup barrier in the tile loop, as in ppo_mlp64.hip).  A residual block's output is a sum over the
+// hidden units, i.e. over the slices: each slice writes its partial [n, 16 | 32] sum to HBM and a small streaming kernel adds
+// the four partials and applies the element-wise part (residual, bias, LeakyReLU, heads, PPO loss, LeakyReLU').  Per epoch:
+//   fwd<16>  P1[s] = W2a[:, s] leaky(W1a[s] x + b1a[s])                 (MFMA)      s = slice
+//   E1       h1 = leaky(x + b2a + sum_s P1[s])                           (stream)
+//   fwd<32>  P2[s] = W2b[:, s] leaky(W1b[s] X1 + b1b[s])                 (MFMA)
+//   E2       h2, heads, loss, dpre2 = dL/d(pre-activation of h2), d(heads), db2b, statistics      (stream)
+//   bwd<32>  per slice: hidden recomputed, dH = W2b[:, s]^T dpre2 . leaky', dW2b[:, s] += dpre2 H^T, dW1b[s] += dH X1^T,
+//            db1b[s], Q[s] = W1b[s][:, 16:32]^T dH                       (MFMA)
+//   E3       dpre1 = (sum_s Q[s] + dpre2[16:32]) . leaky'(h1), db2a      (stream)
+//   bwd<16>  the same for rb1 (no input gradient)                        (MFMA)
+//   reduce   partial rows -> gradient (-> Adam in place)
+// The hidden activation is recomputed in the backward kernels (K = 16 / 32: 16 % more MFMA work) instead of being stored
+// (4 KB per sample and net).  MFMA work per sample and net: 2 x 155,648 MAC = 311 kFLOP -> 1.31 TFLOP per epoch at
+// BASELINE configs[1] = 8.3 ms at the 157.3 TF f32-MFMA peak.
+//
+// All GEMMs are v_mfma_f32_16x16x4_f32 (exact k-ordered f32 fma chains; same rate as 32x32x2, and the 16-row output blocks
+// of rb1 waste nothing).  Layout ("16-layout"): a [rows, 32 samples] activation lives as f32x4 v[rows / 16][2]: lane
+// (n = lane & 15, q = lane >> 4) holds rows 16 b + 4 q + r (r = 0..3) of sample 16 st + n -- which is both the C/D layout of
+// the MFMA and, register r taken as the B operand of step r, a legal k-pairing when the A operand (weights) is read
+// k-permuted: lane (m, q) fetches columns 16 b + 4 q .. + 3 of its row with ONE ds_read_b128.  Products that contract over
+// samples (the weight gradients) take both operands from wave-private LDS tiles stored [row][sample].
+//
+// Arithmetic: float32; sums over hidden units are taken slice by slice and over samples tile by tile, so results agree with
+// PyTorch autograd to f32 round-off (tests: <= 2e-4 of each tensor's scale), not bit for bit.  Deterministic: no atomics.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <string>
+
+#include "mlp64_policy.h"   // Philox / Box-Muller noise of the rollout policy step (same stream as the mlp64x2 path)
+#include "navppo.h"
+#include "navppo_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace rp {   // flat parameter layout of one net = nn.Module.named_parameters() order without the unused BatchNorm entries
+constexpr int D = 16, HID = 512;
+constexpr int W1A = 0, B1A = W1A + HID * D, W2A = B1A + HID, B2A = W2A + D * HID, W1B = B2A + D, B1B = W1B + HID * 2 * D,
+              W2B = B1B + HID, B2B = W2B + 2 * D * HID, WO1 = B2B + 2 * D, BO1 = WO1 + 2 * D, WO2 = BO1 + 1, BO2 = WO2 + 2 * D;
+constexpr int P_ACTOR = BO2 + 1, P_CRITIC = BO1 + 1;
+static_assert(P_ACTOR == NAVPPO_RESMLP512_ACTOR_PARAMS && P_CRITIC == NAVPPO_RESMLP512_CRITIC_PARAMS, "layout");
+}  // namespace rp
+
+constexpr int NSL = 4;               // hidden slices
+constexpr int HS = rp::HID / NSL;    // 128 hidden units per slice
+constexpr int NCH = HS / 32;         // chunks of 32 hidden units per slice
+constexpr int kWaves = 8, kThreads = 64 * kWaves;
+constexpr int LT = 36;               // row pitch of the wave tiles (floats): 16-byte rows, conflict-free ds_read_b128
+constexpr int kMaxWG = 256;          // one persistent workgroup per CU
+constexpr int kWRows = kMaxWG / NSL * kWaves;   // partial-gradient rows: 2 nets x 32 groups x 8 waves
+constexpr int PSTRIDE = 50304;       // pitch of a partial-gradient row (>= P_ACTOR, multiple of 64)
+constexpr int EP = 128;              // pitch of a streaming-kernel partial row
+constexpr int kEMaxBlocks = 1024, kEThreads = 256;
+// columns of a streaming-kernel partial row
+constexpr int EC_B2A = 0, EC_B2B = 16, EC_WO1 = 48, EC_BO1 = 80, EC_WO2 = 81, EC_BO2 = 113, EC_STAT = 120;
+
+template <int IN> struct Blk;
+template <> struct Blk<16> { static constexpr int W1 = rp::W1A, B1 = rp::B1A, W2 = rp::W2A; };
+template <> struct Blk<32> { static constexpr int W1 = rp::W1B, B1 = rp::B1B, W2 = rp::W2B; };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ f32x4 v4(const float4 a) { return f32x4{a.x, a.y, a.z, a.w}; }
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ float leaky(float x) { return fmaxf(x, 0.2f * x); }          // nn.LeakyReLU(0.2), net_actor.py:38
+__device__ __forceinline__ float dleaky(float g, float act) { return act > 0.f ? g : 0.2f * g; }   // sign(leaky(x)) == sign(x)
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wave are performed in issue order: this only stops the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct WG { int net_i, sl, grp; };
+// blockIdx -> (net, slice, group).  With a multiple of 8 groups the 4 (or 8) workgroups that stream the SAME sample tiles
+// (the slices of a group, both nets) get block ids that differ by multiples of 8, i.e. the same XCD and the same L2.
+__device__ __forceinline__ WG decode_block(int b, int n_nets, int groups) {
+    const int nsc = NSL * n_nets;
+    int ns, grp;
+    if ((groups & 7) == 0) {
+        const int xcd = b & 7, rest = b >> 3;
+        ns = rest % nsc;
+        grp = xcd + 8 * (rest / nsc);
+    } else {
+        ns = b % nsc;
+        grp = b / nsc;
+    }
+    return WG{ns >> 2, ns & 3, grp};
+}
+
+// the wave's [IN, 32] input tile in the 16-layout: rows 0..15 = observation, rows 16..31 = h1 (IN == 32)
+template <int IN>
+__device__ __forceinline__ void load_x(f32x4 (&X)[IN / 16][2], const float* __restrict__ obs, const float* __restrict__ h1n,
+                                       long long n, long long m0, int l15, int q) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const long long s = m0 + 16 * st + l15;
+        const bool v = s < n;
+        X[0][st] = v ? v4(ld4(obs + s * 16 + 4 * q)) : zero4();
+        if (IN == 32) X[IN / 16 - 1][st] = v ? v4(ld4(h1n + s * 16 + 4 * q)) : zero4();
+    }
+}
+
+// H = leaky(W1[chunk] X + b1[chunk]): 32 hidden units x 32 samples, as [2 j-blocks][2 sample tiles]
+template <int IN>
+__device__ __forceinline__ void hidden_chunk(const float* W1s, const float* b1s, int c, const f32x4 (&X)[IN / 16][2],
+                                             f32x4 (&H)[2][2], int l15, int q) {
+    constexpr int S1 = IN + 4;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) H[jb][0] = H[jb][1] = v4(ld4(b1s + c * 32 + 16 * jb + 4 * q));
+#pragma unroll
+    for (int b = 0; b < IN / 16; ++b) {
+        const f32x4 a0 = v4(ld4(W1s + (c * 32 + l15) * S1 + 16 * b + 4 * q));
+        const f32x4 a1 = v4(ld4(W1s + (c * 32 + 16 + l15) * S1 + 16 * b + 4 * q));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // four independent accumulators back to back (dependent latency 40 > issue 32 cycles)
+            H[0][0] = mfma16(a0[r], X[b][0][r], H[0][0]);
+            H[0][1] = mfma16(a0[r], X[b][1][r], H[0][1]);
+            H[1][0] = mfma16(a1[r], X[b][0][r], H[1][0]);
+            H[1][1] = mfma16(a1[r], X[b][1][r], H[1][1]);
+        }
+    }
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H[jb][st][r] = leaky(H[jb][st][r]);
+}
+
+// ---------------------------------------------------------------- forward partial of one residual block
+template <int IN>
+struct FwdSmem {
+    float W1s[HS * (IN + 4)];    // [hidden j][input i]
+    float W2s[IN * (HS + 4)];    // [output o][hidden j]
+    float b1s[HS];
+};
+
+// pout[net][slice][n][IN] = W2[:, slice] leaky(W1[slice] X + b1[slice])
+template <int IN>
+__global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__ params, int net_base, int n_nets,
+                                                       const float* __restrict__ obs, const float* __restrict__ h1buf,
+                                                       long long n, int groups, float* __restrict__ pout) {
+    __shared__ __attribute__((aligned(16))) FwdSmem<IN> sm;
+    constexpr int S1 = IN + 4, S2 = HS + 4, NB = IN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const WG wg = decode_block(blockIdx.x, n_nets, groups);
+    const float* __restrict__ pn = params + ((net_base + wg.net_i) ? rp::P_ACTOR : 0);
+    for (int k = tid; k < HS * IN; k += kThreads) sm.W1s[(k / IN) * S1 + (k % IN)] = pn[Blk<IN>::W1 + (wg.sl * HS + k / IN) * IN + (k % IN)];
+    for (int k = tid; k < IN * HS; k += kThreads) sm.W2s[(k / HS) * S2 + (k % HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
+    if (tid < HS) sm.b1s[tid] = pn[Blk<IN>::B1 + wg.sl * HS + tid];
+    __syncthreads();
+    const float* __restrict__ h1n = IN == 32 ? h1buf + (size_t)wg.net_i * n * 16 : nullptr;
+    float* __restrict__ po = pout + (size_t)(wg.net_i * NSL + wg.sl) * n * IN;
+    const long long n_tiles = (n + 31) / 32, stride = (long long)groups * kWaves;
+    f32x4 Xn[NB][2];
+    long long tile = (long long)wg.grp * kWaves + wave;
+    if (tile < n_tiles) load_x<IN>(Xn, obs, h1n, n, tile * 32, l15, q);
+    for (; tile < n_tiles; tile += stride) {
+        f32x4 X[NB][2];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) X[b][0] = Xn[b][0], X[b][1] = Xn[b][1];
+        if (tile + stride < n_tiles) load_x<IN>(Xn, obs, h1n, n, (tile + stride) * 32, l15, q);   // next tile streams in
+        f32x4 Y[NB][2];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) Y[ob][0] = Y[ob][1] = zero4();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            f32x4 H[2][2];
+            hidden_chunk<IN>(sm.W1s, sm.b1s, c, X, H, l15, q);
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                f32x4 a[NB];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) a[ob] = v4(ld4(sm.W2s + (16 * ob + l15) * S2 + c * 32 + 16 * jb + 4 * q));
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ob = 0; ob < NB; ++ob) {
+                        Y[ob][0] = mfma16(a[ob][r], H[jb][0][r], Y[ob][0]);
+                        Y[ob][1] = mfma16(a[ob][r], H[jb][1][r], Y[ob][1]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const long long s = tile * 32 + 16 * st + l15;
+            if (s < n)
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+                    *reinterpret_cast<float4*>(po + s * IN + 16 * ob + 4 * q) = make_float4(Y[ob][st][0], Y[ob][st][1], Y[ob][st][2], Y[ob][st][3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- backward of one residual block, one hidden slice
+template <int IN>
+struct BwdSmem {
+    float W1s[HS * (IN + 4)];     // [hidden j][input i]
+    float W2Ts[HS * (IN + 4)];    // [hidden j][output o]
+    float b1s[HS];
+    float tiles[kWaves * (2 * IN + 32) * LT];   // per wave: TX [IN][32] | TDY [IN][32] | TH [32][32]
+};
+static_assert(sizeof(BwdSmem<32>) <= 160 * 1024, "LDS");
+
+// dypre [net][n][IN] = dL / d(pre-activation of the block's output).  Writes this slice's weight-gradient partials into row
+// (net, grp * 8 + wave) of wpart and, for rb2 (IN == 32), qout[net][slice][n][16] = W1[slice][:, 16:32]^T dH.
+template <int IN>
+__global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__ params, int n_nets, const float* __restrict__ obs,
+                                                       const float* __restrict__ h1buf, const float* __restrict__ dypre,
+                                                       long long n, int groups, float* __restrict__ wpart,
+                                                       float* __restrict__ qout) {
+    __shared__ __attribute__((aligned(16))) BwdSmem<IN> sm;
+    constexpr int S1 = IN + 4, NB = IN / 16;
+    constexpr bool NEED_DX = IN == 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const WG wg = decode_block(blockIdx.x, n_nets, groups);
+    const float* __restrict__ pn = params + (wg.net_i ? rp::P_ACTOR : 0);
+    for (int k = tid; k < HS * IN; k += kThreads) sm.W1s[(k / IN) * S1 + (k % IN)] = pn[Blk<IN>::W1 + (wg.sl * HS + k / IN) * IN + (k % IN)];
+    for (int k = tid; k < IN * HS; k += kThreads) sm.W2Ts[(k % HS) * S1 + (k / HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
+    if (tid < HS) sm.b1s[tid] = pn[Blk<IN>::B1 + wg.sl * HS + tid];
+    __syncthreads();
+    float* const TX = sm.tiles + wave * (2 * IN + 32) * LT;
+    float* const TDY = TX + IN * LT;
+    float* const TH = TDY + IN * LT;
+    const int wr = 4 * q * LT + l15;          // tile[row 16 b + 4 q + r][sample 16 st + l15]: + (16 b + r) * LT + 16 st
+    const int rd = l15 * LT + 8 * q;          // row 16 b + l15, samples 8 q .. 8 q + 7:        + 16 b * LT
+
+    const float* __restrict__ h1n = IN == 32 ? h1buf + (size_t)wg.net_i * n * 16 : nullptr;
+    const float* __restrict__ dyn = dypre + (size_t)wg.net_i * n * IN;
+    float* __restrict__ qo = NEED_DX ? qout + (size_t)(wg.net_i * NSL + wg.sl) * n * 16 : nullptr;
+
+    f32x4 aW2[NCH][NB][2];   // dW2[o block][j block of chunk c]
+    f32x4 aW1[NCH][2][NB];   // dW1[j block of chunk c][i block]
+    float adb1[NCH][2];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            adb1[c][jb] = 0.f;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) aW2[c][b][jb] = aW1[c][jb][b] = zero4();
+        }
+
+    const long long n_tiles = (n + 31) / 32, stride = (long long)groups * kWaves;
+    for (long long tile = (long long)wg.grp * kWaves + wave; tile < n_tiles; tile += stride) {
+        f32x4 X[NB][2], DY[NB][2];
+        load_x<IN>(X, obs, h1n, n, tile * 32, l15, q);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const long long s = tile * 32 + 16 * st + l15;
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) DY[ob][st] = s < n ? v4(ld4(dyn + s * IN + 16 * ob + 4 * q)) : zero4();
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    TX[wr + (16 * b + r) * LT + 16 * st] = X[b][st][r];
+                    TDY[wr + (16 * b + r) * LT + 16 * st] = DY[b][st][r];
+                }
+        f32x4 dXa[2] = {zero4(), zero4()};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            f32x4 H[2][2], dH[2][2];
+            hidden_chunk<IN>(sm.W1s, sm.b1s, c, X, H, l15, q);
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) dH[jb][0] = dH[jb][1] = zero4();
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+                const f32x4 a0 = v4(ld4(sm.W2Ts + (c * 32 + l15) * S1 + 16 * ob + 4 * q));
+                const f32x4 a1 = v4(ld4(sm.W2Ts + (c * 32 + 16 + l15) * S1 + 16 * ob + 4 * q));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dH[0][0] = mfma16(a0[r], DY[ob][0][r], dH[0][0]);
+                    dH[0][1] = mfma16(a0[r], DY[ob][1][r], dH[0][1]);
+                    dH[1][0] = mfma16(a1[r], DY[ob][0][r], dH[1][0]);
+                    dH[1][1] = mfma16(a1[r], DY[ob][1][r], dH[1][1]);
+                }
+            }
+            wave_lds_fence();   // the previous chunk's reads of TH are done (in order), its stores may follow
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        TH[wr + (16 * jb + r) * LT + 16 * st] = H[jb][st][r];
+                        dH[jb][st][r] = dleaky(dH[jb][st][r], H[jb][st][r]);
+                    }
+            wave_lds_fence();
+            // dW2[o][j] += sum_s dY[o][s] H[j][s]
+            {
+                float hb[2][8];
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const float4 h0 = ld4(TH + rd + 16 * jb * LT), h1 = ld4(TH + rd + 16 * jb * LT + 4);
+                    hb[jb][0] = h0.x; hb[jb][1] = h0.y; hb[jb][2] = h0.z; hb[jb][3] = h0.w;
+                    hb[jb][4] = h1.x; hb[jb][5] = h1.y; hb[jb][6] = h1.z; hb[jb][7] = h1.w;
+                }
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    const float4 d0 = ld4(TDY + rd + 16 * ob * LT), d1 = ld4(TDY + rd + 16 * ob * LT + 4);
+                    const float da[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        aW2[c][ob][0] = mfma16(da[u], hb[0][u], aW2[c][ob][0]);
+                        aW2[c][ob][1] = mfma16(da[u], hb[1][u], aW2[c][ob][1]);
+                    }
+                }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) TH[wr + (16 * jb + r) * LT + 16 * st] = dH[jb][st][r];
+            wave_lds_fence();
+            // dW1[j][i] += sum_s dH[j][s] X[i][s] ; db1[j] += sum_s dH[j][s]
+            {
+                float ga[2][8];
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const float4 g0 = ld4(TH + rd + 16 * jb * LT), g1 = ld4(TH + rd + 16 * jb * LT + 4);
+                    ga[jb][0] = g0.x; ga[jb][1] = g0.y; ga[jb][2] = g0.z; ga[jb][3] = g0.w;
+                    ga[jb][4] = g1.x; ga[jb][5] = g1.y; ga[jb][6] = g1.z; ga[jb][7] = g1.w;
+                    adb1[c][jb] += ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w));
+                }
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib) {
+                    const float4 x0 = ld4(TX + rd + 16 * ib * LT), x1 = ld4(TX + rd + 16 * ib * LT + 4);
+                    const float xb[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        aW1[c][0][ib] = mfma16(ga[0][u], xb[u], aW1[c][0][ib]);
+                        aW1[c][1][ib] = mfma16(ga[1][u], xb[u], aW1[c][1][ib]);
+                    }
+                }
+            }
+            if (NEED_DX) {   // Q[i][s] += sum_j W1[j][16 + i] dH[j][s]: A = a column of W1 per step (conflict-free ds_read_b32)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = sm.W1s[(c * 32 + 16 * jb + 4 * q + r) * S1 + 16 + l15];
+                        dXa[0] = mfma16(a, dH[jb][0][r], dXa[0]);
+                        dXa[1] = mfma16(a, dH[jb][1][r], dXa[1]);
+                    }
+            }
+        }
+        if (NEED_DX) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const long long s = tile * 32 + 16 * st + l15;
+                if (s < n) *reinterpret_cast<float4*>(qo + s * 16 + 4 * q) = make_float4(dXa[st][0], dXa[st][1], dXa[st][2], dXa[st][3]);
+            }
+        }
+        wave_lds_fence();   // the next tile's TX / TDY stores stay behind this tile's reads
+    }
+
+    // one partial-gradient row per WAVE (no cross-wave reduction here; resmlp_reduce sums the rows in a fixed order)
+    float* __restrict__ row = wpart + ((size_t)(wg.net_i * (groups * kWaves)) + (size_t)wg.grp * kWaves + wave) * PSTRIDE;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int j0 = wg.sl * HS + c * 32 + 16 * jb;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    row[Blk<IN>::W2 + (16 * b + 4 * q + r) * rp::HID + j0 + l15] = aW2[c][b][jb][r];   // dW2[o][j]: lane n = j
+                    row[Blk<IN>::W1 + (j0 + 4 * q + r) * IN + 16 * b + l15] = aW1[c][jb][b][r];        // dW1[j][i]: lane n = i
+                }
+            float v = adb1[c][jb];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (q == 0) row[Blk<IN>::B1 + j0 + l15] = v;
+        }
+}
+
+// ---------------------------------------------------------------- streaming kernels (element-wise + reductions over samples)
+// E1: h1 = leaky(x + b2a + sum_s P1[s])   -- thread = (sample, 4 outputs)
+__global__ __launch_bounds__(kEThreads) void resmlp_e1(const float* __restrict__ params, int net_base, const float* __restrict__ obs,
+                                                       const float* __restrict__ p1, long long n, float* __restrict__ h1buf) {
+    const int net_i = blockIdx.y;
+    const float* __restrict__ pn = params + ((net_base + net_i) ? rp::P_ACTOR : 0);
+    const int og = threadIdx.x & 3;
+    float b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = pn[rp::B2A + 4 * og + k];
+    const float* __restrict__ pp = p1 + (size_t)net_i * NSL * n * 16;
+    float* __restrict__ ho = h1buf + (size_t)net_i * n * 16;
+    const long long total = n * 4, step = (long long)gridDim.x * kEThreads;
+    for (long long g = (long long)blockIdx.x * kEThreads + threadIdx.x; g < total; g += step) {
+        const long long o = g * 4;   // == s * 16 + 4 * og
+        const float4 x = ld4(obs + o), a0 = ld4(pp + o), a1 = ld4(pp + (size_t)n * 16 + o), a2 = ld4(pp + (size_t)2 * n * 16 + o),
+                     a3 = ld4(pp + (size_t)3 * n * 16 + o);
+        float4 h;
+        h.x = leaky((x.x + b[0]) + ((a0.x + a1.x) + (a2.x + a3.x)));
+        h.y = leaky((x.y + b[1]) + ((a0.y + a1.y) + (a2.y + a3.y)));
+        h.z = leaky((x.z + b[2]) + ((a0.z + a1.z) + (a2.z + a3.z)));
+        h.w = leaky((x.w + b[3]) + ((a0.w + a1.w) + (a2.w + a3.w)));
+        *reinterpret_cast<float4*>(ho + o) = h;
+    }
+}
+
+// block-wide sum of per-thread accumulators over the threads that share (tid & (LPS - 1)); result in row[col0 + 4 * og + k]
+template <int LPS, int NV>
+__device__ __forceinline__ void block_sum_to_row(float (&acc)[NV], float* red /* [kEThreads / 64][LPS][NV] */, float* __restrict__ row,
+                                                 const int* cols /* NV column bases; value v of group og -> cols[v] + og * stride[v] */,
+                                                 const int* strides, const bool* og0_only) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        float x = acc[v];
+#pragma unroll
+        for (int o = LPS; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+        acc[v] = x;
+    }
+    if (lane < LPS)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) red[(wave * LPS + lane) * NV + v] = acc[v];
+    __syncthreads();
+    for (int k = threadIdx.x; k < LPS * NV; k += kEThreads) {
+        const int og = k / NV, v = k % NV;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kEThreads / 64; ++w) s += red[(w * LPS + og) * NV + v];
+        if (!og0_only[v] || og == 0) row[cols[v] + og * strides[v]] = s;
+    }
+}
+
+// E2: h2, heads, PPO loss / MSE, dpre2, and the sample sums d(heads), db2b, statistics.  thread = (sample, 4 of the 32 units)
+// HEAD_ONLY: V = critic(obs).squeeze() only (ppo.py:275, :724).
+template <bool HEAD_ONLY>
+__global__ __launch_bounds__(kEThreads) void resmlp_e2(const float* __restrict__ params, int net_base, const float* __restrict__ obs,
+                                                       const float* __restrict__ h1buf, const float* __restrict__ p2,
+                                                       const float* __restrict__ act, const float* __restrict__ logp_old,
+                                                       const float* __restrict__ rtg, const float* __restrict__ adv, long long n,
+                                                       float var, float clip, float inv_n, float* __restrict__ dy2,
+                                                       float* __restrict__ epart, float* __restrict__ v_out) {
+    __shared__ float red[(kEThreads / 64) * 8 * 17];
+    const int net_i = blockIdx.y, net = net_base + net_i;
+    const bool actor = net == 0;
+    const float* __restrict__ pn = params + (net ? rp::P_ACTOR : 0);
+    const int og = threadIdx.x & 7;
+    float b[4], w1[4], w2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        b[k] = pn[rp::B2B + 4 * og + k];
+        w1[k] = pn[rp::WO1 + 4 * og + k];
+        w2[k] = actor ? pn[rp::WO2 + 4 * og + k] : 0.f;
+    }
+    const float bo1 = pn[rp::BO1], bo2 = actor ? pn[rp::BO2] : 0.f;
+    const float* __restrict__ hn = h1buf + (size_t)net_i * n * 16;
+    const float* __restrict__ pp = p2 + (size_t)net_i * NSL * n * 32;
+    float* __restrict__ dyo = HEAD_ONLY ? nullptr : dy2 + (size_t)net_i * n * 32;
+    // accumulators: db2b[4] dwo1[4] dwo2[4] dbo1 dbo2 st0 st1 st2   (17 values)
+    float acc[17];
+#pragma unroll
+    for (int v = 0; v < 17; ++v) acc[v] = 0.f;
+    const long long total = n * 8, step = (long long)gridDim.x * kEThreads;
+    for (long long g = (long long)blockIdx.x * kEThreads + threadIdx.x; g < total; g += step) {
+        const long long s = g >> 3, o = g * 4;   // o == s * 32 + 4 * og
+        const float4 x1 = og < 4 ? ld4(obs + s * 16 + 4 * og) : ld4(hn + s * 16 + 4 * (og - 4));
+        const float4 a0 = ld4(pp + o), a1 = ld4(pp + (size_t)n * 32 + o), a2 = ld4(pp + (size_t)2 * n * 32 + o),
+                     a3 = ld4(pp + (size_t)3 * n * 32 + o);
+        float h[4];
+        h[0] = leaky((x1.x + b[0]) + ((a0.x + a1.x) + (a2.x + a3.x)));
+        h[1] = leaky((x1.y + b[1]) + ((a0.y + a1.y) + (a2.y + a3.y)));
+        h[2] = leaky((x1.z + b[2]) + ((a0.z + a1.z) + (a2.z + a3.z)));
+        h[3] = leaky((x1.w + b[3]) + ((a0.w + a1.w) + (a2.w + a3.w)));
+        float z3 = 0.f, z4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            z3 = fmaf(h[k], w1[k], z3);
+            z4 = fmaf(h[k], w2[k], z4);
+        }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            z3 += __shfl_xor(z3, m, 64);
+            z4 += __shfl_xor(z4, m, 64);
+        }
+        z3 += bo1;
+        z4 += bo2;
+        if (HEAD_ONLY) {
+            if (og == 0) v_out[s] = z3;
+            continue;
+        }
+        const float own = og == 0 ? 1.f : 0.f;   // statistics are counted once per sample
+        float g3, g4 = 0.f;
+        if (actor) {
+            const float2 a = reinterpret_cast<const float2*>(act)[s];
+            const float mu0 = 1.0f / (1.0f + expf(-z3));   // F.sigmoid, net_actor.py:141
+            const float mu1 = tanhf(z4);                    // F.tanh, net_actor.py:142
+            const float d0 = a.x - mu0, d1 = a.y - mu1;
+            // MultivariateNormal(mean, var * I).log_prob, ppo.py:734-735
+            const float lp = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);
+            const float lr = lp - logp_old[s];
+            const float ratio = expf(lr);                  // ppo.py:316
+            const float A = adv[s];
+            const float s1 = ratio * A;                     // ppo.py:319
+            const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+            const float s2 = rc * A;                        // ppo.py:320
+            acc[14] += own * -fminf(s1, s2);                // ppo.py:342 (mean taken by inv_n at the end)
+            acc[15] += own * ((ratio - 1.0f) - lr);         // approx KL, ppo.py:326
+            acc[16] += (fabsf(ratio - 1.0f) > clip) ? own : 0.f;   // clip fraction, ppo.py:335
+            const bool inside = (ratio >= 1.0f - clip) && (ratio <= 1.0f + clip);
+            const float dL_dratio = (inside || s1 < s2) ? -A : 0.f;
+            const float dL_dlp = dL_dratio * ratio * inv_n;
+            g3 = dL_dlp * (d0 / var) * (mu0 * (1.0f - mu0));
+            g4 = dL_dlp * (d1 / var) * (1.0f - mu1 * mu1);
+        } else {
+            const float e = z3 - rtg[s];                    // critic(obs).squeeze(), ppo.py:724
+            acc[14] += own * (e * e);                       // MSELoss, ppo.py:343
+            g3 = 2.0f * e * inv_n;
+        }
+        float d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d[k] = dleaky(fmaf(g3, w1[k], g4 * w2[k]), h[k]);
+            acc[k] += d[k];
+            acc[4 + k] = fmaf(g3, h[k], acc[4 + k]);
+            acc[8 + k] = fmaf(g4, h[k], acc[8 + k]);
+        }
+        acc[12] += own * g3;
+        acc[13] += own * g4;
+        *reinterpret_cast<float4*>(dyo + o) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    if (HEAD_ONLY) return;
+    // value v of unit group og -> column cols[v] + og * strides[v]
+    __shared__ int cols[17], strides[17];
+    __shared__ bool og0[17];
+    if (threadIdx.x < 17) {
+        const int v = threadIdx.x;
+        const int c = v < 4 ? EC_B2B + v : v < 8 ? EC_WO1 + (v - 4) : v < 12 ? EC_WO2 + (v - 8)
+                      : v == 12 ? EC_BO1 : v == 13 ? EC_BO2 : EC_STAT + (v - 14);
+        cols[v] = c;
+        strides[v] = v < 12 ? 4 : 0;
+        og0[v] = v >= 12;
+    }
+    __syncthreads();
+    block_sum_to_row<8, 17>(acc, red, epart + ((size_t)net_i * gridDim.x + blockIdx.x) * EP, cols, strides, og0);
+}
+
+// E3: dpre1 = (sum_s Q[s] + dpre2[16:32]) . leaky'(h1) ; db2a   -- thread = (sample, 4 of the 16 units)
+__global__ __launch_bounds__(kEThreads) void resmlp_e3(const float* __restrict__ h1buf, const float* __restrict__ qbuf,
+                                                       const float* __restrict__ dy2, long long n, float* __restrict__ dy1,
+                                                       float* __restrict__ epart) {
+    __shared__ float red[(kEThreads / 64) * 4 * 4];
+    const int net_i = blockIdx.y;
+    const int og = threadIdx.x & 3;
+    const float* __restrict__ hn = h1buf + (size_t)net_i * n * 16;
+    const float* __restrict__ qq = qbuf + (size_t)net_i * NSL * n * 16;
+    const float* __restrict__ d2 = dy2 + (size_t)net_i * n * 32;
+    float* __restrict__ d1o = dy1 + (size_t)net_i * n * 16;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long total = n * 4, step = (long long)gridDim.x * kEThreads;
+    for (long long g = (long long)blockIdx.x * kEThreads + threadIdx.x; g < total; g += step) {
+        const long long s = g >> 2, o = g * 4;
+        const float4 h = ld4(hn + o), r = ld4(d2 + s * 32 + 16 + 4 * og);
+        const float4 a0 = ld4(qq + o), a1 = ld4(qq + (size_t)n * 16 + o), a2 = ld4(qq + (size_t)2 * n * 16 + o),
+                     a3 = ld4(qq + (size_t)3 * n * 16 + o);
+        float4 d;
+        d.x = dleaky(r.x + ((a0.x + a1.x) + (a2.x + a3.x)), h.x);
+        d.y = dleaky(r.y + ((a0.y + a1.y) + (a2.y + a3.y)), h.y);
+        d.z = dleaky(r.z + ((a0.z + a1.z) + (a2.z + a3.z)), h.z);
+        d.w = dleaky(r.w + ((a0.w + a1.w) + (a2.w + a3.w)), h.w);
+        acc[0] += d.x; acc[1] += d.y; acc[2] += d.z; acc[3] += d.w;
+        *reinterpret_cast<float4*>(d1o + o) = d;
+    }
+    __shared__ int cols[4], strides[4];
+    __shared__ bool og0[4];
+    if (threadIdx.x < 4) {
+        cols[threadIdx.x] = EC_B2A + threadIdx.x;
+        strides[threadIdx.x] = 4;
+        og0[threadIdx.x] = false;
+    }
+    __syncthreads();
+    block_sum_to_row<4, 4>(acc, red, epart + ((size_t)net_i * gridDim.x + blockIdx.x) * EP, cols, strides, og0);
+}
+
+// ---------------------------------------------------------------- partial rows -> gradient (-> Adam)
+// grad[q] = sum of the partial rows that hold parameter q, rows in a fixed order (deterministic); ADAM: torch.optim.Adam's
+// step in place (ppo.py:116-117,381,392: betas (0.9, 0.999), eps 1e-8, no weight decay).
+constexpr int kRedGroups = 16;
+template <bool ADAM>
+__global__ __launch_bounds__(64 * kRedGroups) void resmlp_reduce(const float* __restrict__ wpart, int w_rows, const float* __restrict__ epart,
+                                                                  int e_rows, float inv_n, float* __restrict__ grad, float* __restrict__ stats,
+                                                                  float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
+                                                                  float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+    __shared__ float part[kRedGroups][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, qi = blockIdx.x * 64 + lane;   // qi: index into actor | critic
+    const bool valid = qi < rp::P_ACTOR + rp::P_CRITIC;
+    const int net_i = qi < rp::P_ACTOR ? 0 : 1, p = qi - net_i * rp::P_ACTOR;
+    // where parameter p lives: biases of the block outputs and the heads come from the streaming kernels' rows
+    const bool from_e = (p >= rp::B2A && p < rp::B2A + 16) || p >= rp::B2B;
+    const int ecol = p < rp::B2B ? EC_B2A + (p - rp::B2A) : EC_B2B + (p - rp::B2B);   // B2B.. -> b2b | wo1 | bo1 | wo2 | bo2, same order
+    const float* __restrict__ src = from_e ? epart + (size_t)net_i * e_rows * EP + ecol : wpart + (size_t)net_i * w_rows * PSTRIDE + p;
+    const size_t pitch = from_e ? EP : PSTRIDE;
+    const int rows = from_e ? e_rows : w_rows;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (valid) {
+        int b = g;
+        for (; b + 3 * kRedGroups < rows; b += 4 * kRedGroups) {
+            s0 += src[(size_t)b * pitch];
+            s1 += src[(size_t)(b + kRedGroups) * pitch];
+            s2 += src[(size_t)(b + 2 * kRedGroups) * pitch];
+            s3 += src[(size_t)(b + 3 * kRedGroups) * pitch];
+        }
+        for (; b < rows; b += kRedGroups) s0 += src[(size_t)b * pitch];
+    }
+    part[g][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && valid) {
+        float gr = 0.f;
+#pragma unroll
+        for (int k = 0; k < kRedGroups; ++k) gr += part[k][lane];
+        grad[qi] = gr;
+        if (ADAM) {
+            const float mm = m[qi] + (gr - m[qi]) * (1.0f - beta1);          // exp_avg.lerp_(grad, 1 - beta1)
+            const float vv = beta2 * v[qi] + (1.0f - beta2) * (gr * gr);     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+            m[qi] = mm;
+            v[qi] = vv;
+            params[qi] -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        }
+    }
+    if (blockIdx.x == 0 && g < 8 && (g & 3) < 3) {   // stats[0..2] actor (loss, approx KL, clip fraction), stats[4] critic loss
+        const float* sp = epart + (size_t)(g >> 2) * e_rows * EP + EC_STAT + (g & 3);
+        float s = 0.f;
+        for (int b = lane; b < e_rows; b += 64) s += sp[(size_t)b * EP];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) stats[g] = s * inv_n;
+    }
+}
+
+// ---------------------------------------------------------------- rollout-time policy step (PPO.get_action, ppo.py:673-706)
+// One workgroup = 16 envs; its 8 waves split the hidden units 8 ways (64 each), weights come straight from global memory
+// (L2: all workgroups read the same 197 KB), the two block outputs are summed over the waves through LDS.
+constexpr int kActEnvs = 16;
+__global__ __launch_bounds__(kThreads) void resmlp_act(const float* __restrict__ pa, const float* __restrict__ obs,
+                                                       const float* __restrict__ noise, long long n, const float* __restrict__ var_ptr,
+                                                       uint64_t seed, uint64_t env_id_base, const uint32_t* __restrict__ step_base,
+                                                       uint32_t step_offset, float* __restrict__ act, float* __restrict__ logp,
+                                                       float* __restrict__ mean_out) {
+    __shared__ __attribute__((aligned(16))) float part1[kWaves][256];
+    __shared__ __attribute__((aligned(16))) float part2[kWaves][2][256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const long long e = (long long)blockIdx.x * kActEnvs + l15;
+    const bool valid = e < n;
+    const int j0 = 64 * w;
+    // every weight this wave needs, requested up front (addresses do not depend on anything computed)
+    f32x4 w1a[4], b1a[4], w2a[4], w1b[4][2], b1b[4], w2b[2][4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        w1a[jb] = v4(ld4(pa + rp::W1A + (j0 + 16 * jb + l15) * 16 + 4 * q));
+        b1a[jb] = v4(ld4(pa + rp::B1A + j0 + 16 * jb + 4 * q));
+        w2a[jb] = v4(ld4(pa + rp::W2A + l15 * rp::HID + j0 + 16 * jb + 4 * q));
+        w1b[jb][0] = v4(ld4(pa + rp::W1B + (j0 + 16 * jb + l15) * 32 + 4 * q));
+        w1b[jb][1] = v4(ld4(pa + rp::W1B + (j0 + 16 * jb + l15) * 32 + 16 + 4 * q));
+        b1b[jb] = v4(ld4(pa + rp::B1B + j0 + 16 * jb + 4 * q));
+        w2b[0][jb] = v4(ld4(pa + rp::W2B + l15 * rp::HID + j0 + 16 * jb + 4 * q));
+        w2b[1][jb] = v4(ld4(pa + rp::W2B + (16 + l15) * rp::HID + j0 + 16 * jb + 4 * q));
+    }
+    const f32x4 xq = valid ? v4(ld4(obs + e * 16 + 4 * q)) : zero4();
+    // rb1, this wave's 64 hidden units
+    f32x4 y1[2] = {zero4(), zero4()};
+    {
+        f32x4 H[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) H[jb] = b1a[jb];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) H[jb] = mfma16(w1a[jb][r], xq[r], H[jb]);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y1[jb & 1] = mfma16(w2a[jb][r], leaky(H[jb][r]), y1[jb & 1]);
+    }
+    *reinterpret_cast<float4*>(&part1[w][4 * lane]) = make_float4(y1[0][0] + y1[1][0], y1[0][1] + y1[1][1], y1[0][2] + y1[1][2], y1[0][3] + y1[1][3]);
+    __syncthreads();
+    f32x4 h1;
+    {
+        const float4 b = ld4(pa + rp::B2A + 4 * q);
+        f32x4 s = v4(ld4(&part1[0][4 * lane]));
+#pragma unroll
+        for (int k = 1; k < kWaves; ++k) s += v4(ld4(&part1[k][4 * lane]));
+        h1 = xq + v4(b) + s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[r] = leaky(h1[r]);
+    }
+    // rb2
+    f32x4 y2[2] = {zero4(), zero4()};
+    {
+        f32x4 H[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) H[jb] = b1b[jb];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) H[jb] = mfma16(w1b[jb][0][r], xq[r], H[jb]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) H[jb] = mfma16(w1b[jb][1][r], h1[r], H[jb]);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hl = leaky(H[jb][r]);
+                y2[0] = mfma16(w2b[0][jb][r], hl, y2[0]);
+                y2[1] = mfma16(w2b[1][jb][r], hl, y2[1]);
+            }
+    }
+    *reinterpret_cast<float4*>(&part2[w][0][4 * lane]) = make_float4(y2[0][0], y2[0][1], y2[0][2], y2[0][3]);
+    *reinterpret_cast<float4*>(&part2[w][1][4 * lane]) = make_float4(y2[1][0], y2[1][1], y2[1][2], y2[1][3]);
+    __syncthreads();
+    if (w != 0) return;
+    float z3 = 0.f, z4 = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+        f32x4 s = v4(ld4(&part2[0][ob][4 * lane]));
+#pragma unroll
+        for (int k = 1; k < kWaves; ++k) s += v4(ld4(&part2[k][ob][4 * lane]));
+        const f32x4 x1 = ob == 0 ? xq : h1;
+        const float4 b = ld4(pa + rp::B2B + 16 * ob + 4 * q), u = ld4(pa + rp::WO1 + 16 * ob + 4 * q);
+        const float* w2p = pa + rp::WO2 + 16 * ob + 4 * q;   // out2.weight starts one float after out1.bias: not 16-byte aligned
+        const f32x4 h2 = x1 + v4(b) + s;
+        const float uv[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float hl = leaky(h2[r]);
+            z3 = fmaf(hl, uv[r], z3);
+            z4 = fmaf(hl, w2p[r], z4);
+        }
+    }
+    z3 += __shfl_xor(z3, 16, 64);
+    z4 += __shfl_xor(z4, 16, 64);
+    z3 += __shfl_xor(z3, 32, 64);
+    z4 += __shfl_xor(z4, 32, 64);
+    if (q == 0 && valid) {
+        z3 += pa[rp::BO1];
+        z4 += pa[rp::BO2];
+        const float var = *var_ptr;
+        float e0, e1;
+        if (noise) {
+            e0 = noise[2 * e];
+            e1 = noise[2 * e + 1];
+        } else {
+            mlp64::policy_noise((step_base ? *step_base : 0u) + step_offset, seed, env_id_base + (uint64_t)e, e0, e1);
+        }
+        const float mu0 = 1.0f / (1.0f + expf(-z3)), mu1 = tanhf(z4);
+        const float sd = sqrtf(var);
+        const float a0 = fminf(fmaxf(fmaf(sd, e0, mu0), 0.f), 1.f);    // ppo.py:698-703
+        const float a1 = fminf(fmaxf(fmaf(sd, e1, mu1), -1.f), 1.f);
+        const float d0 = a0 - mu0, d1 = a1 - mu1;
+        act[2 * e] = a0;
+        act[2 * e + 1] = a1;
+        logp[e] = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);  // log-prob of the CLAMPED action, ppo.py:704
+        if (mean_out) {
+            mean_out[2 * e] = mu0;
+            mean_out[2 * e + 1] = mu1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+thread_local std::string g_err;
+
+struct Plan {
+    int groups, wgs, e_blocks;
+    float *p1, *h1, *p2, *dy2, *qb, *dy1, *wpart, *epart;
+};
+
+size_t ws_floats(int64_t n) {
+    const size_t N = (size_t)n;
+    return 2 * N * (NSL * 16 + 16 + NSL * 32 + 32 + NSL * 16 + 16) + (size_t)kWRows * PSTRIDE + (size_t)2 * kEMaxBlocks * EP + 64;
+}
+
+Plan make_plan(void* ws, int64_t n, int n_nets) {
+    Plan p;
+    const long long tiles = (n + 31) / 32;
+    long long g = (tiles + kWaves - 1) / kWaves;
+    const int gmax = kMaxWG / (NSL * n_nets);
+    if (g > gmax) g = gmax;
+    if (g >= 8) g &= ~7LL;
+    p.groups = (int)g;
+    p.wgs = p.groups * NSL * n_nets;
+    long long eb = (n + 31) / 32;
+    p.e_blocks = (int)(eb < 1 ? 1 : eb > kEMaxBlocks ? kEMaxBlocks : eb);
+    float* f = reinterpret_cast<float*>(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+    const size_t N = (size_t)n;
+    p.p1 = f; f += 2 * NSL * N * 16;
+    p.h1 = f; f += 2 * N * 16;
+    p.p2 = f; f += 2 * NSL * N * 32;
+    p.dy2 = f; f += 2 * N * 32;
+    p.qb = f; f += 2 * NSL * N * 16;
+    p.dy1 = f; f += 2 * N * 16;
+    p.wpart = f; f += (size_t)kWRows * PSTRIDE;
+    p.epart = f;
+    return p;
+}
+
+bool launch_ok(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_err = std::string(what) + ": " + hipGetErrorString(e);
+        return false;
+    }
+    return true;
+}
+
+// forward of `n_nets` nets starting at net_base (0 = actor, 1 = critic) up to the partial sums of rb2
+void launch_forward(const Plan& p, const float* params, int net_base, int n_nets, const float* obs, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(resmlp_fwd<16>, dim3(p.wgs), dim3(kThreads), 0, st, params, net_base, n_nets, obs, (const float*)nullptr,
+                       (long long)n, p.groups, p.p1);
+    hipLaunchKernelGGL(resmlp_e1, dim3(p.e_blocks, n_nets), dim3(kEThreads), 0, st, params, net_base, obs, (const float*)p.p1,
+                       (long long)n, p.h1);
+    hipLaunchKernelGGL(resmlp_fwd<32>, dim3(p.wgs), dim3(kThreads), 0, st, params, net_base, n_nets, obs, (const float*)p.h1,
+                       (long long)n, p.groups, p.p2);
+}
+
+int loss_grad_impl(const char* name, bool adam, float* params, const float* obs, const float* act, const float* logp_old,
+                   const float* rtg, const float* adv, int64_t n, float var, float clip, float lr, float beta1, float beta2,
+                   float eps, int32_t step, float* adam_m, float* adam_v, float* grad, float* stats, void* ws, void* stream) {
+    if (!params || !obs || !act || !logp_old || !rtg || !adv || !grad || !stats || !ws || n < 1 || !(var > 0.f) ||
+        (adam && (!adam_m || !adam_v || step < 1))) {
+        g_err = std::string(name) + ": bad argument";
+        return -1;
+    }
+    if (((uintptr_t)obs & 15) || ((uintptr_t)act & 7)) {
+        g_err = std::string(name) + ": obs must be 16-byte and act 8-byte aligned";
+        return -1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const Plan p = make_plan(ws, n, 2);
+    const float inv_n = 1.0f / (float)n;
+    launch_forward(p, params, 0, 2, obs, n, st);
+    hipLaunchKernelGGL(resmlp_e2<false>, dim3(p.e_blocks, 2), dim3(kEThreads), 0, st, (const float*)params, 0, obs, (const float*)p.h1,
+                       (const float*)p.p2, act, logp_old, rtg, adv, (long long)n, var, clip, inv_n, p.dy2, p.epart, (float*)nullptr);
+    hipLaunchKernelGGL(resmlp_bwd<32>, dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
+                       (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb);
+    hipLaunchKernelGGL(resmlp_e3, dim3(p.e_blocks, 2), dim3(kEThreads), 0, st, (const float*)p.h1, (const float*)p.qb,
+                       (const float*)p.dy2, (long long)n, p.dy1, p.epart);
+    hipLaunchKernelGGL(resmlp_bwd<16>, dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)nullptr,
+                       (const float*)p.dy1, (long long)n, p.groups, p.wpart, (float*)nullptr);
+    const int rblocks = (rp::P_ACTOR + rp::P_CRITIC + 63) / 64;
+    if (adam) {
+        const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
+        const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
+        hipLaunchKernelGGL(resmlp_reduce<true>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kWaves,
+                           (const float*)p.epart, p.e_blocks, inv_n, grad, stats, params, adam_m, adam_v, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+    } else {
+        hipLaunchKernelGGL(resmlp_reduce<false>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kWaves,
+                           (const float*)p.epart, p.e_blocks, inv_n, grad, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f,
+                           0.f, 0.f, 0.f, 1.f, 1.f);
+    }
+    return launch_ok(name) ? 0 : -2;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+size_t navppo_resmlp512_workspace_bytes(int64_t n_samples) { return n_samples < 1 ? 0 : ws_floats(n_samples) * sizeof(float); }
+
+int navppo_resmlp512_loss_grad(const float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
+                               const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip,
+                               float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
+    const int rc = loss_grad_impl("navppo_resmlp512_loss_grad", false, const_cast<float*>(params_dev), obs_dev, act_dev, logp_old_dev,
+                                  rtg_dev, adv_dev, n_samples, var, clip, 0.f, 0.f, 0.f, 0.f, 1, nullptr, nullptr, grad_dev, stats_dev,
+                                  workspace_dev, stream);
+    if (rc != 0) navppo_set_error(g_err.c_str());
+    return rc;
+}
+
+int navppo_resmlp512_update_epoch(float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
+                                  const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
+                                  float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
+                                  float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
+    const int rc = loss_grad_impl("navppo_resmlp512_update_epoch", true, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev, adv_dev,
+                                  n_samples, var, clip, lr, beta1, beta2, eps, step, adam_m_dev, adam_v_dev, grad_dev, stats_dev,
+                                  workspace_dev, stream);
+    if (rc != 0) navppo_set_error(g_err.c_str());
+    return rc;
+}
+
+int navppo_resmlp512_value(const float* critic_params_dev, const float* obs_dev, int64_t n_samples, float* value_dev,
+                           void* workspace_dev, void* stream) {
+    if (!critic_params_dev || !obs_dev || !value_dev || !workspace_dev || n_samples < 1 || ((uintptr_t)obs_dev & 15)) {
+        navppo_set_error("navppo_resmlp512_value: bad argument (obs must be 16-byte aligned)");
+        return -1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const Plan p = make_plan(workspace_dev, n_samples, 1);
+    // the kernels index the flat [actor | critic] buffer by net: hand them the address the actor would have
+    const float* base = critic_params_dev - rp::P_ACTOR;
+    launch_forward(p, base, 1, 1, obs_dev, n_samples, st);
+    hipLaunchKernelGGL(resmlp_e2<true>, dim3(p.e_blocks, 1), dim3(kEThreads), 0, st, base, 1, obs_dev, (const float*)p.h1,
+                       (const float*)p.p2, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (long long)n_samples, 1.f, 0.f, 0.f, (float*)nullptr, (float*)nullptr, value_dev);
+    if (!launch_ok("navppo_resmlp512_value")) {
+        navppo_set_error(g_err.c_str());
+        return -2;
+    }
+    return 0;
+}
+
+int navppo_resmlp512_act(const float* actor_params_dev, const float* obs_dev, const float* noise_dev, int64_t n_envs,
+                         const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
+                         uint32_t step_offset, float* act_dev, float* logp_dev, float* mean_dev, void* stream) {
+    if (!actor_params_dev || !obs_dev || !act_dev || !logp_dev || n_envs < 1 || !var_dev) {
+        navppo_set_error("navppo_resmlp512_act: bad argument");
+        return -1;
+    }
+    if (((uintptr_t)actor_params_dev & 15) || ((uintptr_t)obs_dev & 15)) {
+        navppo_set_error("navppo_resmlp512_act: params and obs must be 16-byte aligned");
+        return -1;
+    }
+    const int blocks = (int)((n_envs + kActEnvs - 1) / kActEnvs);
+    hipLaunchKernelGGL(resmlp_act, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, actor_params_dev, obs_dev, noise_dev,
+                       (long long)n_envs, var_dev, seed, env_id_base, step_base_dev, step_offset, act_dev, logp_dev, mean_dev);
+    if (!launch_ok("navppo_resmlp512_act")) {
+        navppo_set_error(g_err.c_str());
+        return -2;
+    }
+    return 0;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

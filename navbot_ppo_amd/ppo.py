@@ -50,6 +50,7 @@ class PPOConfig:
     fused_update: bool = True              # mlp64x2 on GPU: fused HIP loss+gradient kernel (csrc/ppo_mlp64.hip)
     output_dir: str = ""                   # "" = no checkpoints / logs
     episode_csv_rows: int = 2000           # per-iteration cap on rows appended to <method>_train_episodes.csv (0 = off)
+    tb_episode_rows: int = 256             # per-iteration cap on Episode_Rewards/train points in the TensorBoard file (0 = off)
     method_name: str = "baseline"
 
 
@@ -195,19 +196,36 @@ class PPOUpdater:
         fused = self.device.type == "cuda"
         self.opt = torch.optim.Adam([self.fp.proxy], lr=cfg.lr, fused=fused)  # == the two Adam(lr) of ppo.py:116-117
         self.stats = {}
-        # HIP path for the 16-64-64 heads: one fused MFMA kernel per net instead of ~40 PyTorch kernels per epoch
-        self.fused_mlp64 = (self.device.type == "cuda" and cfg.policy == "mlp64x2" and cfg.fused_update
-                            and isinstance(actor, nets.MLP64Actor) and actor.layer1.in_features == 16)
-        if self.fused_mlp64:
+        # HIP paths: fused f32-MFMA kernels instead of ~40 (mlp64x2) / ~120 (resmlp512) PyTorch kernels per epoch
+        on_gpu = self.device.type == "cuda" and cfg.fused_update
+        self.fused_mlp64 = (on_gpu and cfg.policy == "mlp64x2" and isinstance(actor, nets.MLP64Actor)
+                            and actor.layer1.in_features == 16)
+        self.fused_resmlp512 = (on_gpu and cfg.policy == "resmlp512" and isinstance(actor, nets.ResMLPActor)
+                                and actor.rb1.f_in == 16 and actor.rb1.fc1.out_features == 512)
+        self.fused = "navppo_mlp64" if self.fused_mlp64 else "navppo_resmlp512" if self.fused_resmlp512 else None
+        if self.fused:
             from ._native import lib
-            assert self.fp.numel == 5378 + 5313
-            self._ws = torch.empty(lib().navppo_mlp64_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
+            self._n_actor = self.fp.module_numel[0]
+            assert tuple(self.fp.module_numel) == ((5378, 5313) if self.fused_mlp64 else (50290, 50257))
+            self._ws = None
+            if self.fused_mlp64:
+                self._ws = torch.empty(lib().navppo_mlp64_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
             self._fstats = torch.zeros(8, dtype=torch.float32, device=self.device)
             self._fhist = torch.zeros((max(cfg.n_updates_per_iteration, 1), 8), dtype=torch.float32, device=self.device)
-            # single GPU: Adam runs inside the kernel that sums the partial gradients (navppo_mlp64_update_epoch)
+            # single GPU: Adam runs inside the kernel that sums the partial gradients (navppo_*_update_epoch)
             self._adam_m = torch.zeros_like(self.fp.flat)
             self._adam_v = torch.zeros_like(self.fp.flat)
             self._adam_t = 0
+
+    def _workspace(self, n):
+        """Scratch of the fused kernels: fixed for the 2x64 heads, per-sample partial block outputs for the 512-wide nets."""
+        if self.fused_resmlp512:
+            from ._native import lib
+            need = lib().navppo_resmlp512_workspace_bytes(int(n)) // 4 + 4
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        return self._ws
 
     def _fused_loss_grad(self, obs, acts, logp_old, rtg, adv, var, stats=None):
         """evaluate + losses + backward of ppo.py:307-386 in the HIP kernels of csrc/ppo_mlp64.hip; gradients land
@@ -218,12 +236,12 @@ class PPOUpdater:
         ptr = lambda t: C.c_void_p(t.data_ptr())
         for t in (obs, acts, logp_old, rtg, adv):
             assert t.is_contiguous() and t.dtype == torch.float32
-        rc = L.navppo_mlp64_loss_grad(ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
-                                      int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad),
-                                      ptr(self._fstats if stats is None else stats), ptr(self._ws),
-                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = getattr(L, self.fused + "_loss_grad")(ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+                                                   int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad),
+                                                   ptr(self._fstats if stats is None else stats), ptr(self._workspace(obs.shape[0])),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
-            raise RuntimeError(f"navppo_mlp64_loss_grad failed: {L.navppo_last_error().decode()}")
+            raise RuntimeError(f"{self.fused}_loss_grad failed: {L.navppo_last_error().decode()}")
 
     def _fused_adam(self, grad_scale):
         import ctypes as C
@@ -243,10 +261,15 @@ class PPOUpdater:
         from ._native import lib
         L = lib()
         out = torch.empty(obs.shape[0], dtype=torch.float32, device=obs.device)
-        rc = L.navppo_mlp64_value(C.c_void_p(self.fp.flat.data_ptr() + 4 * 5378), C.c_void_p(obs.data_ptr()), int(obs.shape[0]),
-                                  C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        critic = C.c_void_p(self.fp.flat.data_ptr() + 4 * self._n_actor)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self.fused_resmlp512:
+            rc = L.navppo_resmlp512_value(critic, C.c_void_p(obs.data_ptr()), int(obs.shape[0]), C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(self._workspace(obs.shape[0]).data_ptr()), st)
+        else:
+            rc = L.navppo_mlp64_value(critic, C.c_void_p(obs.data_ptr()), int(obs.shape[0]), C.c_void_p(out.data_ptr()), st)
         if rc != 0:
-            raise RuntimeError(f"navppo_mlp64_value failed: {L.navppo_last_error().decode()}")
+            raise RuntimeError(f"{self.fused}_value failed: {L.navppo_last_error().decode()}")
         return out
 
     def _fused_epoch(self, obs, acts, logp_old, rtg, adv, var, stats):
@@ -256,18 +279,19 @@ class PPOUpdater:
         L = lib()
         ptr = lambda t: C.c_void_p(t.data_ptr())
         self._adam_t += 1
-        rc = L.navppo_mlp64_update_epoch(ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
-                                         int(obs.shape[0]), float(var), float(self.cfg.clip), float(self.cfg.lr), 0.9, 0.999, 1e-8,
-                                         int(self._adam_t), ptr(self._adam_m), ptr(self._adam_v), ptr(self.fp.grad), ptr(stats),
-                                         ptr(self._ws), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = getattr(L, self.fused + "_update_epoch")(ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+                                                      int(obs.shape[0]), float(var), float(self.cfg.clip), float(self.cfg.lr), 0.9,
+                                                      0.999, 1e-8, int(self._adam_t), ptr(self._adam_m), ptr(self._adam_v),
+                                                      ptr(self.fp.grad), ptr(stats), ptr(self._workspace(obs.shape[0])),
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
-            raise RuntimeError(f"navppo_mlp64_update_epoch failed: {L.navppo_last_error().decode()}")
+            raise RuntimeError(f"{self.fused}_update_epoch failed: {L.navppo_last_error().decode()}")
 
     def update(self, obs, acts, logp_old, rtg, var):
         cfg, ctx = self.cfg, self.ctx
         world = ctx.world if ctx is not None else 1
         with torch.no_grad():
-            if self.fused_mlp64 and obs.is_contiguous() and obs.data_ptr() % 16 == 0:
+            if self.fused and obs.is_contiguous() and obs.data_ptr() % 16 == 0:
                 V0 = self._fused_value(obs)
             else:
                 V0 = self.critic(obs).squeeze(-1)
@@ -277,13 +301,13 @@ class PPOUpdater:
         a_loss = c_loss = torch.zeros((), device=obs.device)   # n_updates_per_iteration == 0: nothing to report
         acc = torch.zeros(6, device=obs.device)                # sums over epochs of diagnostics
         self.loss_history = torch.zeros((n_ep, 2), device=obs.device)  # per-epoch (actor, critic) loss, ppo.py:396-397
-        var_f = float(var) if self.fused_mlp64 else None
-        if self.fused_mlp64:
+        var_f = float(var) if self.fused else None
+        if self.fused:
             obs, acts, logp_old, rtg, adv = (t.contiguous() for t in (obs, acts, logp_old, rtg, adv))
             if self._fhist.shape[0] < n_ep:
                 self._fhist = torch.zeros((n_ep, 8), dtype=torch.float32, device=self.device)
         for ep in range(n_ep):                                 # ppo.py:305
-            if self.fused_mlp64:
+            if self.fused:
                 # per-epoch diagnostics land in row ep of a device buffer: no extra launches inside the epoch loop
                 if world > 1:   # fused passes -> ONE all-reduce of the flat gradient (RCCL) -> scale + Adam in one launch
                     self._fused_loss_grad(obs, acts, logp_old, rtg, adv, var_f, stats=self._fhist[ep])
@@ -295,7 +319,8 @@ class PPOUpdater:
                     h = self._fhist[:n_ep]
                     self.loss_history = h[:, 0:5:4].clone()   # columns 0 (actor loss) and 4 (critic loss)
                     hs = h.sum(0)
-                    acc = torch.cat([hs[[0, 4, 1, 2]], torch.stack([self.fp.grad.norm(), V0.mean()]) * n_ep])
+                    # multi-GPU: fp.grad holds the all-reduced SUM (the 1 / world scale is inside navppo_adam_step)
+                    acc = torch.cat([hs[[0, 4, 1, 2]], torch.stack([self.fp.grad.norm() / world, V0.mean()]) * n_ep])
                     # grad_norm: the LAST epoch's (the PyTorch path averages the norm over the epochs; a norm launch per epoch
                     # would cost 0.7 % of the iteration for a diagnostic, so the fused path reports the final epoch's norm)
                     a_loss, c_loss = self.loss_history[-1, 0], self.loss_history[-1, 1]
@@ -320,6 +345,8 @@ class PPOUpdater:
         n_a = self.fp.module_numel[0]
         d = self.fp.flat - flat_before
         extra = torch.stack(torch._foreach_norm([self.fp.grad[:n_a], self.fp.grad[n_a:], d[:n_a], d[n_a:]]))
+        if self.fused and world > 1:
+            extra = extra * extra.new_tensor([1.0 / world, 1.0 / world, 1.0, 1.0])   # norms of the MEAN gradient, as on one GPU
         self.stats = dict(zip(["actor_loss", "critic_loss", "approx_kl", "clip_frac", "grad_norm", "value_mean",
                                "actor_grad_norm", "critic_grad_norm", "actor_param_delta", "critic_param_delta"],
                               [float(v) for v in torch.cat([acc, extra]).tolist()]))   # grad norms: the last epoch's
@@ -372,20 +399,21 @@ class PPOTrainer:
         self.logger = {}
 
     def _fused_act(self, t, noise=None):
-        """PPO.get_action for all envs in ONE launch (csrc/ppo_mlp64.hip: mlp64_act)."""
+        """PPO.get_action for all envs in ONE launch (csrc/ppo_mlp64.hip: mlp64_act, csrc/ppo_resmlp512.hip: resmlp_act)."""
         import ctypes as C
         from ._native import lib
         ptr = lambda x: None if x is None else C.c_void_p(x.data_ptr())
         L = lib()
-        rc = L.navppo_mlp64_act(ptr(self.updater.fp.flat), ptr(self.obs_buf[t]), ptr(noise), self.env.N, ptr(self.var),
-                                self._act_seed, self._env_id_base, ptr(self._step_base), t, ptr(self.act_buf[t]),
-                                ptr(self.logp_buf[t]), None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = getattr(L, self.updater.fused + "_act")(ptr(self.updater.fp.flat), ptr(self.obs_buf[t]), ptr(noise), self.env.N,
+                                                     ptr(self.var), self._act_seed, self._env_id_base, ptr(self._step_base), t,
+                                                     ptr(self.act_buf[t]), ptr(self.logp_buf[t]), None,
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
-            raise RuntimeError(f"navppo_mlp64_act failed: {L.navppo_last_error().decode()}")
+            raise RuntimeError(f"{self.updater.fused}_act failed: {L.navppo_last_error().decode()}")
 
     # ---- ppo.py:673-706 + env.step, for rollout step t (all envs)
     def _rollout_step(self, t):
-        if self.updater.fused_mlp64:
+        if self.updater.fused:
             self._fused_act(t)
             self.env.sim.step(self.act_buf[t], self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.arrive_buf[t],
                               self.ended_buf[t], self.epret_buf[t], self.eplen_buf[t], ep_path=self.eppath_buf[t])
@@ -513,7 +541,7 @@ class PPOTrainer:
         m = self._rollout_metrics_dev()
         stats = self.updater.update(self.obs_buf[:T].reshape(T * N, D), self.act_buf.reshape(T * N, 2),
                                     self.logp_buf.reshape(T * N), self.rtg_buf.reshape(T * N),
-                                    self.var_host if self.updater.fused_mlp64 else self.var)
+                                    self.var_host if self.updater.fused else self.var)
         if cuda:
             ev[2].record()
             torch.cuda.synchronize(self.device)
@@ -612,25 +640,26 @@ class PPOTrainer:
             self._tb = SummaryWriter(self.tb_dir())
             self._tb_loss_steps = self._tb_ep_steps = 0
         w, it = self._tb, self.i_so_far
-        for k, v in self.tb_scalars().items():
-            if v is not None:
-                w.add_scalar(k, float(v), it)
+        t0 = time.time()
+        recs = [(k, float(v), it) for k, v in self.tb_scalars().items() if v is not None]
         hist = self.updater.loss_history.detach().cpu().numpy()
         for k in range(hist.shape[0]):
-            w.add_scalar("Actor_loss/train", float(hist[k, 0]), self._tb_loss_steps + k)
-            w.add_scalar("Critic_loss/train", float(hist[k, 1]), self._tb_loss_steps + k)
+            recs.append(("Actor_loss/train", float(hist[k, 0]), self._tb_loss_steps + k))
+            recs.append(("Critic_loss/train", float(hist[k, 1]), self._tb_loss_steps + k))
         self._tb_loss_steps += hist.shape[0]
-        ended = self.ended_buf.bool()
-        t_idx, n_idx = torch.nonzero(ended, as_tuple=True)
-        cap = self.cfg.episode_csv_rows or 0
-        if cap:
+        cap = int(self.cfg.tb_episode_rows or 0)
+        if cap:   # own cap, independent of the CSV's: with 4096 envs an iteration finishes ~1e5 episodes
+            ended = self.ended_buf.bool()
+            t_idx, n_idx = torch.nonzero(ended, as_tuple=True)
             t_idx, n_idx = t_idx[:cap], n_idx[:cap]
-        per_step = (self.epret_buf[t_idx, n_idx] / self.eplen_buf[t_idx, n_idx].clamp(min=1)).cpu().numpy()
-        for k, r in enumerate(per_step):
-            w.add_scalar("Episode_Rewards/train", float(r), self._tb_ep_steps + k)
-        self._tb_ep_steps += len(per_step)
-        w.add_scalar("avg_ep_rews/train", float(self.logger.get("avg_ep_rews", 0.0)), it)
+            per_step = (self.epret_buf[t_idx, n_idx] / self.eplen_buf[t_idx, n_idx].clamp(min=1)).cpu().numpy()
+            recs.extend(("Episode_Rewards/train", float(r), self._tb_ep_steps + k) for k, r in enumerate(per_step))
+            self._tb_ep_steps += len(per_step)
+        recs.append(("avg_ep_rews/train", float(self.logger.get("avg_ep_rews", 0.0)), it))
+        recs.append(("time/log", float(getattr(self, "_last_log_time", 0.0)), it))   # the previous iteration's logging cost
+        w.add_scalars(recs)   # one TFRecord per point; CRCs vectorised over the records (tb_writer._masked_crc_many)
         w.flush()
+        self._last_log_time = time.time() - t0
 
     def learn(self, total_timesteps, log=print):
         # The reference counts only COMPLETED episodes toward the budget (ppo.py:258); if a configuration never completes
