@@ -11,7 +11,8 @@ One "step" = one PPO iteration = T env steps of all envs (policy forward + sampl
 persistent HIP launch) + the HIP return scan + the 50-epoch update (two launches per epoch; + one RCCL all-reduce of the
 flat gradient per epoch when N > 1).  value = K * T * n_envs_total / wall, the reference's own
 `perf/steps_per_sec` (project_ppo/src/ppo.py:855), all inputs resident in HBM, synthetic (random-init
-policy, seeded goals).  Weak scaling: every GPU owns its own 4096-env shard.
+policy, seeded goals).  Default: weak scaling, every GPU owns its own 4096-env shard (no data-path collective; the units
+are independent envs).  `--scaling strong` keeps 4096 envs IN TOTAL (SURVEY.md 8d(i) read literally): shards of 4096 / N.
 
 Besides the contract fields, rank 0 adds
   roofline            step kernel on BASELINE configs[2] (16384 envs, per-env stage_2 segment buffers, S=128): algorithmic
@@ -19,7 +20,9 @@ Besides the contract fields, rank 0 adds
   roofline_beyond_l3  the same kernel with S=1024 per env (268 MB working set: past the 256 MiB Infinity Cache)
   roofline_timed_region   the persistent rollout kernel of the timed workload
   time_to_reward_s    PPO wall-clock until mean episode return >= +100 (ppo.py:833) from a fresh policy
-  resmlp512           the same iteration with the reference's active 512-wide residual nets (PyTorch-ROCm path)
+  resmlp512           the same iteration with the reference's active 512-wide residual nets (fused f32-MFMA kernels of
+                      csrc/ppo_resmlp512.hip) + `update_roofline`: MFMA FLOPs of one epoch / its duration vs the 157.3 TF peak
+  env_n1_step_us      one step of the N = 1 drop-in class `Env` driven from Python like PPO.rollout drives the reference's
   cpu_baseline / _all_cores / _n1   the CPU oracle (scalar C port) on 1 core, on every host core, and one env per call
 """
 import argparse
@@ -151,9 +154,12 @@ def time_to_reward(n_envs, target=100.0, max_iters=40):
                 env_steps=tr.env_steps, trace_sec_meanreward_success=trace)
 
 
+MFMA_F32_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+
+
 def resmlp512_leg(n_envs, rollout, epochs, steps=2):
     """SURVEY 8(d) cfg 2 "reported alongside": the reference's ACTIVE nets (net_actor.py:56-144, net_critic.py:50-130) on the
-    same workload; PyTorch-ROCm forward/backward, hipGraph rollout."""
+    same workload: fused HIP update (csrc/ppo_resmlp512.hip), hipGraph rollout of fused policy step + env step."""
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
     env = VecEnv(n_envs, map="stage_1", max_episode_steps=500, seed=0)
@@ -168,9 +174,61 @@ def resmlp512_leg(n_envs, rollout, epochs, steps=2):
         u += lg["update_time"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the update kernels alone: HIP events around whole epochs on the trainer's buffers (the epoch is 8 launches on one stream)
+    roof = None
+    up = tr.updater
+    if up.fused_resmlp512:
+        T, N, D = rollout, n_envs, env.D
+        obs, acts = tr.obs_buf[:T].reshape(T * N, D), tr.act_buf.reshape(T * N, 2)
+        logp, rtg = tr.logp_buf.reshape(T * N), tr.rtg_buf.reshape(T * N)
+        adv = torch.randn(T * N, device=obs.device)
+        st = torch.zeros(8, device=obs.device)
+        up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        flop = 2 * 2 * 155648 * T * N   # both nets; 155,648 MACs per sample incl. the hidden layer recomputed in the backward pass
+        roof = dict(bound="mfma", kernel="navppo_resmlp512_update_epoch (resmlp_fwd<16|32>, resmlp_bwd<16|32>, 3 streaming kernels, "
+                    "reduce+Adam)", achieved=round(flop / ms / 1e9, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                    frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4), epoch_ms=round(ms, 3), flop_per_epoch=flop, traffic=None,
+                    detail="f32-input MFMA (v_mfma_f32_16x16x4_f32); f32 MFMA and VALU share the SIMD's FMA lanes and the loop "
+                           "sustains ~2.2 GHz, so ~0.85 of the nominal peak is the practical ceiling")
     env.close()
     return dict(policy="resmlp512", value=round(steps * rollout * n_envs / dt, 1), unit="env-steps/s", steps=steps,
-                ms_per_step=round(dt / steps * 1e3, 2), rollout_ms=round(r / steps * 1e3, 2), update_ms=round(u / steps * 1e3, 2))
+                ms_per_step=round(dt / steps * 1e3, 2), rollout_ms=round(r / steps * 1e3, 2), update_ms=round(u / steps * 1e3, 2),
+                update="fused f32-MFMA kernels" if up.fused_resmlp512 else "PyTorch-ROCm", update_roofline=roof)
+
+
+def env_n1_step_us(budget_s=1.5):
+    """The N = 1 drop-in class `Env` (navbot_ppo_amd/env.py) stepped from Python exactly as PPO.rollout steps the reference's
+    (ppo.py:541, 591-593): one launch + one stream wait per step, caller-side reset."""
+    from navbot_ppo_amd.env import Env
+    env = Env(is_training=True)
+    env.reset()
+    rng = np.random.default_rng(0)
+    past = [0.0, 0.0]
+    n, t0 = 0, None
+    while True:
+        a = [rng.uniform(0, 1), rng.uniform(-1, 1)]
+        _, _, d, ar = env.step(a, past)
+        past = a
+        if d or ar:
+            env.reset()
+            past = [0.0, 0.0]
+        n += 1
+        if n == 200:
+            t0, n0 = time.perf_counter(), n
+        if t0 is not None and time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    env.close()
+    return round(dt / (n - n0) * 1e6, 2)
 
 
 def profiled_traffic(key):
@@ -193,6 +251,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --envs-per-gpu envs on every GPU; strong: --envs-total envs split over the GPUs")
+    ap.add_argument("--envs-total", type=int, default=4096, help="strong scaling: total envs (shards of envs-total / gpus)")
     ap.add_argument("--rollout", type=int, default=512)
     ap.add_argument("--epochs", type=int, default=50)
     ap.add_argument("--policy", default="mlp64x2")
@@ -208,7 +269,12 @@ def main():
     ctx = ppo.DistCtx()
     if ctx.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}: launch with torch.distributed.run")
-    n_local = args.envs_per_gpu
+    if args.scaling == "strong":
+        if args.envs_total % ctx.world:
+            raise SystemExit(f"--envs-total {args.envs_total} is not divisible by {ctx.world} GPUs")
+        n_local = args.envs_total // ctx.world
+    else:
+        n_local = args.envs_per_gpu
     n_total = n_local * ctx.world
     lo, _ = ctx.shard(n_total)
     env = VecEnv(n_local, map="stage_1", n_beams=10, max_episode_steps=500, auto_reset=True, seed=0, env_id_base=lo,
@@ -239,7 +305,7 @@ def main():
         out = {
             "metric": "env_steps_per_sec", "value": round(K * args.rollout * n_total / dt, 1), "unit": "env-steps/s",
             "n_gpus": ctx.world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "dtype_detail": "pose/goal angles/reward f64, ray-cast f32, PPO nets f32",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {n_local} envs/GPU, stage_1 (32 segments), 10 beams, "
@@ -273,9 +339,16 @@ def main():
             out["time_to_reward"] = ttr
             out["resmlp512"] = resmlp512_leg(n_local, args.rollout, args.epochs)
             cores = os.cpu_count() or 1
+            out["env_n1_step_us"] = env_n1_step_us()
             out["cpu_baseline"] = cpu_baseline(n_local, 1, 8.0)
+            # the reference's own Python arithmetic cannot travel to this box: its survey-time figure, for scale
+            out["cpu_baseline"]["reference_python_us_per_step"] = 29.3
+            out["cpu_baseline"]["reference_python_note"] = ("reference Env.getOdometry + Env.step arithmetic with stubbed ROS and a "
+                                                            "canned scan, 1 core of the survey container (Xeon 2.1 GHz), no simulator; "
+                                                            "container-only number, not measured on this box")
             out["cpu_baseline_all_cores"] = cpu_baseline(n_local, cores, 6.0)
             out["cpu_baseline_n1"] = cpu_baseline(1, 1, 3.0)
+            out["cpu_baseline_n1"]["gpu_env_n1_step_us"] = out["env_n1_step_us"]
     if ctx.rank == 0:
         print(json.dumps(out), flush=True)
     ctx.barrier()

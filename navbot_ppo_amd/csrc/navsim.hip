@@ -1333,7 +1333,7 @@ int g_epb = 0;   // envs per workgroup: 0 = by shard size (below); NAVSIM_EPB = 
 // costs the same with 16 or 64 active lanes) and start fewer workgroups, but need N / EPB >= the number of CUs to fill the
 // chip: measured (tools/time_step.py) 16384 envs: 18.5 / 16.7 / 15.9 us with 16 / 32 / 64; 8192: 69.8 / 64.8 / 73.9; 4096: 8.9 / 8.6 / 9.8.
 static int pick_epb(int n_envs) {
-    if (g_epb) return g_epb;
+    if (g_epb >= 8) return g_epb;
     return n_envs >= 16384 ? 64 : (n_envs >= 4096 ? 32 : 16);
 }
 
@@ -1496,7 +1496,7 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
 
     if (const char* e = std::getenv("NAVSIM_EPB")) {
         const int v = std::atoi(e);
-        if (v == 8 || v == 16 || v == 32 || v == 64) g_epb = v;
+        if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) g_epb = v;   // 4: the persistent rollout kernel only
     }
     navsim* h = new navsim();
     const int rc = init_handle(h, cfg);
@@ -1709,12 +1709,19 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
     R.ep_length = ep_length_dev; R.ep_path = ep_path_dev; R.var_ptr = var_dev; R.step_base = step_base_dev;
     R.seed = act_seed; R.T = n_steps;
     const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
-    const int epb = (g_epb == 8) ? 8 : 16;
-    // 8 waves per workgroup: a workgroup is one latency chain per step, more ray waves shorten its cast
+    // Envs per workgroup (NAVSIM_EPB = 4 | 8 | 16 forces one).  A workgroup is ONE latency chain per step whatever its size:
+    // measured (tools/time_rollout.py, 512 steps) 4096 / 2048 / 1024 / 512 envs take 2.92 / 2.90 / 2.89 / 2.97 ms with 16 envs
+    // per workgroup, 3.05-3.06 ms with 8 and 2.96 ms with 4 wherever the grid still fits one round of 256 CUs (a second
+    // round doubles the time: 256 registers x 8 waves fill a CU) -- spreading a small shard over more CUs buys nothing.
+    const int epb = (g_epb == 4 || g_epb == 8 || g_epb == 16) ? g_epb : 16;
+    // 8 waves per workgroup: more ray waves shorten the cast
     constexpr int kRollWaves = 8;
     const dim3 grid((h->P.N + epb - 1) / epb), block(64 * kRollWaves);
     hipStream_t st = (hipStream_t)stream;
-    if (epb == 8) {
+    if (epb == 4) {
+        if (sens) hipLaunchKernelGGL((rollout_kernel<4, true, kRollWaves>), grid, block, 0, st, h->P, R);
+        else hipLaunchKernelGGL((rollout_kernel<4, false, kRollWaves>), grid, block, 0, st, h->P, R);
+    } else if (epb == 8) {
         if (sens) hipLaunchKernelGGL((rollout_kernel<8, true, kRollWaves>), grid, block, 0, st, h->P, R);
         else hipLaunchKernelGGL((rollout_kernel<8, false, kRollWaves>), grid, block, 0, st, h->P, R);
     } else {

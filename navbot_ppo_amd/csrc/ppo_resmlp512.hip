@@ -83,7 +83,11 @@ template <> struct Blk<32> { static constexpr int W1 = rp::W1B, B1 = rp::B1B, W2
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ f32x4 v4(const float4 a) { return f32x4{a.x, a.y, a.z, a.w}; }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-__device__ __forceinline__ float leaky(float x) { return fmaxf(x, 0.2f * x); }          // nn.LeakyReLU(0.2), net_actor.py:38
+// nn.LeakyReLU(0.2) (net_actor.py:38) = max(x, 0.2 x).  Three instructions (the compiler quiets a possible signalling NaN
+// with v_max x, x first).  A hand-written v_max_f32 in inline asm saves one of them (fwd<16> -5 %, fwd<32> -3 %), but
+// the hazard recogniser does not see an asm statement as a VALU write, so an MFMA that consumes the result next reads a
+// stale register (the rollout policy step did): not used.
+__device__ __forceinline__ float leaky(float x) { return fmaxf(x, 0.2f * x); }
 __device__ __forceinline__ float dleaky(float g, float act) { return act > 0.f ? g : 0.2f * g; }   // sign(leaky(x)) == sign(x)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void wave_lds_fence() {
@@ -122,8 +126,8 @@ __device__ __forceinline__ void load_x(f32x4 (&X)[IN / 16][2], const float* __re
     }
 }
 
-// H = leaky(W1[chunk] X + b1[chunk]): 32 hidden units x 32 samples, as [2 j-blocks][2 sample tiles]
-template <int IN>
+// H = W1[chunk] X + b1[chunk] (LEAKY: leaky of it): 32 hidden units x 32 samples, as [2 j-blocks][2 sample tiles]
+template <int IN, bool LEAKY = true>
 __device__ __forceinline__ void hidden_chunk(const float* W1s, const float* b1s, int c, const f32x4 (&X)[IN / 16][2],
                                              f32x4 (&H)[2][2], int l15, int q) {
     constexpr int S1 = IN + 4;
@@ -141,12 +145,18 @@ __device__ __forceinline__ void hidden_chunk(const float* W1s, const float* b1s,
             H[1][1] = mfma16(a1[r], X[b][1][r], H[1][1]);
         }
     }
+    if (LEAKY) {
+        // f32 MFMA and VALU work share the SIMD's FMA lanes (times add, tools/ubench/mfma_valu_overlap.hip) and every switch
+        // between the two costs issue slots: keep the element-wise block in one piece instead of sprinkled between MFMAs
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
+        for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) H[jb][st][r] = leaky(H[jb][st][r]);
+                for (int r = 0; r < 4; ++r) H[jb][st][r] = leaky(H[jb][st][r]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // ---------------------------------------------------------------- forward partial of one residual block
@@ -215,18 +225,31 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
 }
 
 // ---------------------------------------------------------------- backward of one residual block, one hidden slice
+// The weight gradients contract over SAMPLES, the activations were produced contracting over FEATURES.  Instead of
+// transposing H and dH through LDS, the backward kernel computes them already transposed: the MFMA's output has its n index
+// on lanes and its m index on registers, so swapping the two operands of the same instruction,
+//   mfma(A = X  (lane = sample, registers = features), B = W1 rows (lane = hidden unit))   ->  H^T: lane = hidden unit,
+// yields the tile with lane = hidden unit j and registers = samples ("R-layout"), which IS the B operand of
+// dW2[o][j] += sum_s dY[o][s] H[j][s] and, for dH, the A operand of dW1[j][i] += sum_s dH[j][s] X[i][s].  Their partners
+// dY^T / X^T (lane = output / input unit, registers = samples) come from two wave-private LDS tiles written once per tile.
+// Only rb2's input gradient Q = W1[:, 16:32]^T dH contracts over hidden units again: dH makes one trip through an LDS tile
+// (ds_write_b128 rows, conflict-free ds_read_b32 columns).
 template <int IN>
 struct BwdSmem {
     float W1s[HS * (IN + 4)];     // [hidden j][input i]
     float W2Ts[HS * (IN + 4)];    // [hidden j][output o]
     float b1s[HS];
-    float tiles[kWaves * (2 * IN + 32) * LT];   // per wave: TX [IN][32] | TDY [IN][32] | TH [32][32]
+    float tiles[kWaves * (2 * IN + (IN == 32 ? 32 : 0)) * LT];   // per wave: TX [IN][32] | TDY [IN][32] | TH [32][32] (rb2)
 };
 static_assert(sizeof(BwdSmem<32>) <= 160 * 1024, "LDS");
 
 // dypre [net][n][IN] = dL / d(pre-activation of the block's output).  Writes this slice's weight-gradient partials into row
 // (net, grp * 8 + wave) of wpart and, for rb2 (IN == 32), qout[net][slice][n][16] = W1[slice][:, 16:32]^T dH.
-template <int IN>
+// NST = sample tiles of a chunk per pass.  rb2 keeps 128 accumulator registers per lane and the compiler spills ~70 more next
+// to a whole 32 x 32 chunk of H / dH (NST = 2), mostly outside the tile loop (27 scratch accesses per tile); measured
+// alternatives, all slower: half chunks (NST = 1: no fewer spills, twice the weight reads, 5.54 vs 5.10 ms), 4 waves x 512
+// registers with two tiles in flight (no spills, but ~270 AGPR <-> VGPR moves per tile: 5.53 ms).
+template <int IN, int NST>
 __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__ params, int n_nets, const float* __restrict__ obs,
                                                        const float* __restrict__ h1buf, const float* __restrict__ dypre,
                                                        long long n, int groups, float* __restrict__ wpart,
@@ -234,6 +257,8 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
     __shared__ __attribute__((aligned(16))) BwdSmem<IN> sm;
     constexpr int S1 = IN + 4, NB = IN / 16;
     constexpr bool NEED_DX = IN == 32;
+    constexpr bool PREFETCH = IN == 16;   // rb2 has no registers to spare for the next tile's rows
+    constexpr int TILE_F = (2 * IN + (IN == 32 ? 32 : 0)) * LT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const WG wg = decode_block(blockIdx.x, n_nets, groups);
     const float* __restrict__ pn = params + (wg.net_i ? rp::P_ACTOR : 0);
@@ -241,11 +266,11 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
     for (int k = tid; k < IN * HS; k += kThreads) sm.W2Ts[(k % HS) * S1 + (k / HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
     if (tid < HS) sm.b1s[tid] = pn[Blk<IN>::B1 + wg.sl * HS + tid];
     __syncthreads();
-    float* const TX = sm.tiles + wave * (2 * IN + 32) * LT;
+    float* const TX = sm.tiles + wave * TILE_F;
     float* const TDY = TX + IN * LT;
-    float* const TH = TDY + IN * LT;
-    const int wr = 4 * q * LT + l15;          // tile[row 16 b + 4 q + r][sample 16 st + l15]: + (16 b + r) * LT + 16 st
-    const int rd = l15 * LT + 8 * q;          // row 16 b + l15, samples 8 q .. 8 q + 7:        + 16 b * LT
+    float* const TH = TDY + IN * LT;          // rb2 only
+    const int wr = 4 * q * LT + l15;          // S-layout store: tile[row 16 b + 4 q + r][sample 16 st + l15]: + (16 b + r) * LT + 16 st
+    const int rr = l15 * LT + 4 * q;          // R-layout access: row 16 b + l15, samples 16 st + 4 q .. + 3:       + 16 b * LT + 16 st
 
     const float* __restrict__ h1n = IN == 32 ? h1buf + (size_t)wg.net_i * n * 16 : nullptr;
     const float* __restrict__ dyn = dypre + (size_t)wg.net_i * n * IN;
@@ -264,8 +289,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
         }
 
     const long long n_tiles = (n + 31) / 32, stride = (long long)groups * kWaves;
-    for (long long tile = (long long)wg.grp * kWaves + wave; tile < n_tiles; tile += stride) {
-        f32x4 X[NB][2], DY[NB][2];
+    auto load_tile = [&](f32x4 (&X)[NB][2], f32x4 (&DY)[NB][2], long long tile) {   // rows past n read as zeros: they add nothing
         load_x<IN>(X, obs, h1n, n, tile * 32, l15, q);
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -273,6 +297,11 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
 #pragma unroll
             for (int ob = 0; ob < NB; ++ob) DY[ob][st] = s < n ? v4(ld4(dyn + s * IN + 16 * ob + 4 * q)) : zero4();
         }
+    };
+    f32x4 X[NB][2], DY[NB][2];   // S-layout: lane = sample, registers = feature rows
+    long long tile = (long long)wg.grp * kWaves + wave;
+    load_tile(X, DY, tile);
+    for (; tile < n_tiles; tile += stride) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -283,93 +312,115 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
                     TDY[wr + (16 * b + r) * LT + 16 * st] = DY[b][st][r];
                 }
         f32x4 dXa[2] = {zero4(), zero4()};
+        f32x4 Xn[NB][2], DYn[NB][2];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            f32x4 H[2][2], dH[2][2];
-            hidden_chunk<IN>(sm.W1s, sm.b1s, c, X, H, l15, q);
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb) dH[jb][0] = dH[jb][1] = zero4();
-#pragma unroll
-            for (int ob = 0; ob < NB; ++ob) {
-                const f32x4 a0 = v4(ld4(sm.W2Ts + (c * 32 + l15) * S1 + 16 * ob + 4 * q));
-                const f32x4 a1 = v4(ld4(sm.W2Ts + (c * 32 + 16 + l15) * S1 + 16 * ob + 4 * q));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dH[0][0] = mfma16(a0[r], DY[ob][0][r], dH[0][0]);
-                    dH[0][1] = mfma16(a0[r], DY[ob][1][r], dH[0][1]);
-                    dH[1][0] = mfma16(a1[r], DY[ob][0][r], dH[1][0]);
-                    dH[1][1] = mfma16(a1[r], DY[ob][1][r], dH[1][1]);
-                }
-            }
-            wave_lds_fence();   // the previous chunk's reads of TH are done (in order), its stores may follow
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        TH[wr + (16 * jb + r) * LT + 16 * st] = H[jb][st][r];
-                        dH[jb][st][r] = dleaky(dH[jb][st][r], H[jb][st][r]);
-                    }
-            wave_lds_fence();
-            // dW2[o][j] += sum_s dY[o][s] H[j][s]
-            {
-                float hb[2][8];
+            for (int s0 = 0; s0 < 2; s0 += NST) {   // sample tiles s0 .. s0 + NST - 1 of the chunk
+                // (compiler only) tile rows are re-read per pass instead of being held in registers across passes, and a later
+                // pass's operands are not hoisted into this one
+                wave_lds_fence();
+                __builtin_amdgcn_sched_barrier(0);
+                // H^T (R-layout: lane = hidden unit 16 jb + l15 of the chunk, register r = sample 16 st + 4 q + r)
+                f32x4 H[2][NST], dH[2][NST];
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) {
-                    const float4 h0 = ld4(TH + rd + 16 * jb * LT), h1 = ld4(TH + rd + 16 * jb * LT + 4);
-                    hb[jb][0] = h0.x; hb[jb][1] = h0.y; hb[jb][2] = h0.z; hb[jb][3] = h0.w;
-                    hb[jb][4] = h1.x; hb[jb][5] = h1.y; hb[jb][6] = h1.z; hb[jb][7] = h1.w;
+                    const float bj = sm.b1s[c * 32 + 16 * jb + l15];
+#pragma unroll
+                    for (int k = 0; k < NST; ++k) H[jb][k] = f32x4{bj, bj, bj, bj};
                 }
 #pragma unroll
-                for (int ob = 0; ob < NB; ++ob) {
-                    const float4 d0 = ld4(TDY + rd + 16 * ob * LT), d1 = ld4(TDY + rd + 16 * ob * LT + 4);
-                    const float da[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                for (int b = 0; b < NB; ++b) {
+                    const f32x4 w0 = v4(ld4(sm.W1s + (c * 32 + l15) * S1 + 16 * b + 4 * q));
+                    const f32x4 w1 = v4(ld4(sm.W1s + (c * 32 + 16 + l15) * S1 + 16 * b + 4 * q));
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        aW2[c][ob][0] = mfma16(da[u], hb[0][u], aW2[c][ob][0]);
-                        aW2[c][ob][1] = mfma16(da[u], hb[1][u], aW2[c][ob][1]);
-                    }
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int k = 0; k < NST; ++k) {
+                            H[0][k] = mfma16(X[b][s0 + k][r], w0[r], H[0][k]);
+                            H[1][k] = mfma16(X[b][s0 + k][r], w1[r], H[1][k]);
+                        }
                 }
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) TH[wr + (16 * jb + r) * LT + 16 * st] = dH[jb][st][r];
-            wave_lds_fence();
-            // dW1[j][i] += sum_s dH[j][s] X[i][s] ; db1[j] += sum_s dH[j][s]
-            {
-                float ga[2][8];
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb) {
-                    const float4 g0 = ld4(TH + rd + 16 * jb * LT), g1 = ld4(TH + rd + 16 * jb * LT + 4);
-                    ga[jb][0] = g0.x; ga[jb][1] = g0.y; ga[jb][2] = g0.z; ga[jb][3] = g0.w;
-                    ga[jb][4] = g1.x; ga[jb][5] = g1.y; ga[jb][6] = g1.z; ga[jb][7] = g1.w;
-                    adb1[c][jb] += ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w));
-                }
-#pragma unroll
-                for (int ib = 0; ib < NB; ++ib) {
-                    const float4 x0 = ld4(TX + rd + 16 * ib * LT), x1 = ld4(TX + rd + 16 * ib * LT + 4);
-                    const float xb[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        aW1[c][0][ib] = mfma16(ga[0][u], xb[u], aW1[c][0][ib]);
-                        aW1[c][1][ib] = mfma16(ga[1][u], xb[u], aW1[c][1][ib]);
-                    }
-                }
-            }
-            if (NEED_DX) {   // Q[i][s] += sum_j W1[j][16 + i] dH[j][s]: A = a column of W1 per step (conflict-free ds_read_b32)
+                // dH^T = (dY^T W2[:, chunk]) . leaky'
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float a = sm.W1s[(c * 32 + 16 * jb + 4 * q + r) * S1 + 16 + l15];
-                        dXa[0] = mfma16(a, dH[jb][0][r], dXa[0]);
-                        dXa[1] = mfma16(a, dH[jb][1][r], dXa[1]);
+                    for (int k = 0; k < NST; ++k) dH[jb][k] = zero4();
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    const f32x4 w0 = v4(ld4(sm.W2Ts + (c * 32 + l15) * S1 + 16 * ob + 4 * q));
+                    const f32x4 w1 = v4(ld4(sm.W2Ts + (c * 32 + 16 + l15) * S1 + 16 * ob + 4 * q));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int k = 0; k < NST; ++k) {
+                            dH[0][k] = mfma16(DY[ob][s0 + k][r], w0[r], dH[0][k]);
+                            dH[1][k] = mfma16(DY[ob][s0 + k][r], w1[r], dH[1][k]);
+                        }
+                }
+                if (PREFETCH && c == NCH - 1 && s0 + NST == 2 && tile + stride < n_tiles)
+                    load_tile(Xn, DYn, tile + stride);   // X / DY are dead from here: the next tile's rows stream in
+                float db[2] = {0.f, 0.f};
+                __builtin_amdgcn_sched_barrier(0);   // one element-wise block per pass (see hidden_chunk)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int k = 0; k < NST; ++k)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // leaky(x) = x f, leaky'(x) = f, f = 1 (x > 0) or 0.2: compare + select + two multiplies
+                            const float f = H[jb][k][r] > 0.f ? 1.0f : 0.2f;
+                            H[jb][k][r] *= f;
+                            dH[jb][k][r] *= f;
+                            db[jb] += dH[jb][k][r];
+                        }
+                adb1[c][0] += db[0];
+                adb1[c][1] += db[1];
+                __builtin_amdgcn_sched_barrier(0);
+                if (NEED_DX) {   // dH rows to the tile (read back as columns below, behind the dW products)
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int k = 0; k < NST; ++k)
+                            *reinterpret_cast<float4*>(TH + rr + 16 * jb * LT + 16 * (s0 + k)) =
+                                make_float4(dH[jb][k][0], dH[jb][k][1], dH[jb][k][2], dH[jb][k][3]);
+                    wave_lds_fence();
+                }
+                // dW2[o][j] += sum_s dY[o][s] H[j][s]: A = dY^T from the tile, B = the H^T registers
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                    for (int k = 0; k < NST; ++k) {
+                        const f32x4 d = v4(ld4(TDY + rr + 16 * ob * LT + 16 * (s0 + k)));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            aW2[c][ob][0] = mfma16(d[r], H[0][k][r], aW2[c][ob][0]);
+                            aW2[c][ob][1] = mfma16(d[r], H[1][k][r], aW2[c][ob][1]);
+                        }
                     }
+                // dW1[j][i] += sum_s dH[j][s] X[i][s]: A = the dH^T registers, B = X^T from the tile
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                    for (int k = 0; k < NST; ++k) {
+                        const f32x4 x = v4(ld4(TX + rr + 16 * ib * LT + 16 * (s0 + k)));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            aW1[c][0][ib] = mfma16(dH[0][k][r], x[r], aW1[c][0][ib]);
+                            aW1[c][1][ib] = mfma16(dH[1][k][r], x[r], aW1[c][1][ib]);
+                        }
+                    }
+                if (NEED_DX) {   // Q[i][s] += sum_j W1[j][16 + i] dH[j][s]: A = a column of W1, B = a column of the dH tile, per step
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = sm.W1s[(c * 32 + 16 * jb + 4 * q + r) * S1 + 16 + l15];
+#pragma unroll
+                            for (int k = 0; k < NST; ++k)
+                                dXa[s0 + k] = mfma16(a, TH[(16 * jb + 4 * q + r) * LT + 16 * (s0 + k) + l15], dXa[s0 + k]);
+                        }
+                }
             }
         }
         if (NEED_DX) {
@@ -380,6 +431,14 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
             }
         }
         wave_lds_fence();   // the next tile's TX / TDY stores stay behind this tile's reads
+        if (PREFETCH) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) X[b][st] = Xn[b][st], DY[b][st] = DYn[b][st];
+        } else {
+            load_tile(X, DY, tile + stride);
+        }
     }
 
     // one partial-gradient row per WAVE (no cross-wave reduction here; resmlp_reduce sums the rows in a fixed order)
@@ -396,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
                     row[Blk<IN>::W2 + (16 * b + 4 * q + r) * rp::HID + j0 + l15] = aW2[c][b][jb][r];   // dW2[o][j]: lane n = j
                     row[Blk<IN>::W1 + (j0 + 4 * q + r) * IN + 16 * b + l15] = aW1[c][jb][b][r];        // dW1[j][i]: lane n = i
                 }
-            float v = adb1[c][jb];
+            float v = adb1[c][jb];   // lane (j, q) holds the sum over its samples: add the four sample groups
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             if (q == 0) row[Blk<IN>::B1 + j0 + l15] = v;
@@ -610,7 +669,7 @@ __global__ __launch_bounds__(kEThreads) void resmlp_e3(const float* __restrict__
 // step in place (ppo.py:116-117,381,392: betas (0.9, 0.999), eps 1e-8, no weight decay).
 constexpr int kRedGroups = 16;
 template <bool ADAM>
-__global__ __launch_bounds__(64 * kRedGroups) void resmlp_reduce(const float* __restrict__ wpart, int w_rows, const float* __restrict__ epart,
+__global__ __launch_bounds__(64 * kRedGroups) void resmlp_reduce(const float* __restrict__ wpart, int w_rows1, int w_rows2, const float* __restrict__ epart,
                                                                   int e_rows, float inv_n, float* __restrict__ grad, float* __restrict__ stats,
                                                                   float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
                                                                   float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
@@ -621,6 +680,7 @@ __global__ __launch_bounds__(64 * kRedGroups) void resmlp_reduce(const float* __
     // where parameter p lives: biases of the block outputs and the heads come from the streaming kernels' rows
     const bool from_e = (p >= rp::B2A && p < rp::B2A + 16) || p >= rp::B2B;
     const int ecol = p < rp::B2B ? EC_B2A + (p - rp::B2A) : EC_B2B + (p - rp::B2B);   // B2B.. -> b2b | wo1 | bo1 | wo2 | bo2, same order
+    const int w_rows = p < rp::W1B ? w_rows1 : w_rows2;   // rb1's and rb2's backward kernels run different numbers of waves
     const float* __restrict__ src = from_e ? epart + (size_t)net_i * e_rows * EP + ecol : wpart + (size_t)net_i * w_rows * PSTRIDE + p;
     const size_t pitch = from_e ? EP : PSTRIDE;
     const int rows = from_e ? e_rows : w_rows;
@@ -865,21 +925,21 @@ int loss_grad_impl(const char* name, bool adam, float* params, const float* obs,
     launch_forward(p, params, 0, 2, obs, n, st);
     hipLaunchKernelGGL(resmlp_e2<false>, dim3(p.e_blocks, 2), dim3(kEThreads), 0, st, (const float*)params, 0, obs, (const float*)p.h1,
                        (const float*)p.p2, act, logp_old, rtg, adv, (long long)n, var, clip, inv_n, p.dy2, p.epart, (float*)nullptr);
-    hipLaunchKernelGGL(resmlp_bwd<32>, dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
+    hipLaunchKernelGGL((resmlp_bwd<32, 2>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
                        (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb);
     hipLaunchKernelGGL(resmlp_e3, dim3(p.e_blocks, 2), dim3(kEThreads), 0, st, (const float*)p.h1, (const float*)p.qb,
                        (const float*)p.dy2, (long long)n, p.dy1, p.epart);
-    hipLaunchKernelGGL(resmlp_bwd<16>, dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)nullptr,
+    hipLaunchKernelGGL((resmlp_bwd<16, 2>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)nullptr,
                        (const float*)p.dy1, (long long)n, p.groups, p.wpart, (float*)nullptr);
     const int rblocks = (rp::P_ACTOR + rp::P_CRITIC + 63) / 64;
     if (adam) {
         const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
         const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
         hipLaunchKernelGGL(resmlp_reduce<true>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kWaves,
-                           (const float*)p.epart, p.e_blocks, inv_n, grad, stats, params, adam_m, adam_v, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+                           p.groups * kWaves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, params, adam_m, adam_v, lr, beta1, beta2, eps, bc1, bc2_sqrt);
     } else {
         hipLaunchKernelGGL(resmlp_reduce<false>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kWaves,
-                           (const float*)p.epart, p.e_blocks, inv_n, grad, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f,
+                           p.groups * kWaves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f,
                            0.f, 0.f, 0.f, 1.f, 1.f);
     }
     return launch_ok(name) ? 0 : -2;
