@@ -175,6 +175,20 @@ int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, i
                     float* out_dev, void* stream);
 
 /*
+ * Generalised advantage estimation -- the "GAE / return scan" BASELINE.json's north_star names; an EXTENSION: the reference
+ * has only compute_rtgs (ppo.py:643-671) and A = rtgs - V (ppo.py:277), which is this scan at lambda = 1.  Off by default
+ * (PPOConfig.gae_lambda = None).
+ *   value_dev [T,N] f32 = V(s_t) of the stored observations; last_value_dev [N] f32, nullable: V of the state after the last
+ *   row (NULL = the batch end is terminal, as in the reference, ppo.py:601,658); episode ends are always terminal (:552-553).
+ *     R[t] = rew[t] + (ended[t] ? 0 : gamma (1 - lam) V[t+1] + gamma lam R[t+1])          float64 accumulate
+ *     ret_dev [T,N] (nullable) = float32(R[t]) -- the lambda-return, the critic's target;   adv_dev [T,N] = float32(R[t]) - V[t]
+ * lam = 1 and last_value_dev = NULL: ret_dev is bit-identical to navsim_rtg_scan's output and adv_dev to rtgs - V.  Same
+ * kernel, same <= 1 ulp contract and the same NAVSIM_RTG_EXACT / N % 16 rule as navsim_rtg_scan.
+ */
+int navsim_gae_scan(const float* rew_dev, const uint8_t* ended_dev, const float* value_dev, const float* last_value_dev, int32_t T,
+                    int32_t N, double gamma, double lam, float* adv_dev, float* ret_dev, void* stream);
+
+/*
  * The hot loop of PPO.rollout (project_ppo/src/ppo.py:505-594) for the 16-64-64 policy, all n_steps steps in ONE launch:
  * per step PPO.get_action (ppo.py:673-706; what navppo_mlp64_act computes, include/navppo.h) followed by what navsim_step
  * computes, for every env, with the rows of step t written at offset t * N of each [n_steps, N, .] buffer.  A workgroup

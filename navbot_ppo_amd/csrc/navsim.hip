@@ -1226,8 +1226,16 @@ __global__ void spawn_obs_kernel(const float* __restrict__ best, int n, int belo
 // T > 512: super-chunks of 512 rows from the batch end, the carry between them is the stored float64 of pass 2.
 constexpr int kRtgCols = 16, kRtgChunks = 16, kRtgRows = 32, kRtgSuper = kRtgChunks * kRtgRows;
 
+//
+// GAE (north-star extension, off by default; navsim_gae_scan): the lambda-return obeys the same kind of recurrence,
+//   R[t] = (r[t] + gamma (1 - lambda) V[t+1]) + gamma lambda R[t+1]      behind an episode end / the batch end: R[t] = r[t]
+// (episode ends and the batch end are terminal as in ppo.py:552-553,658-666; last_value bootstraps the batch end only when
+// given), advantage A[t] = float32(R[t]) - V[t].  lambda = 1 without bootstrap: the additive term is r[t] + 0 and the factor
+// gamma * 1, i.e. the arithmetic of the return scan bit for bit, and A = rtg - V (ppo.py:277).
+template <bool GAE>
 __global__ __launch_bounds__(256) void rtg_kernel_split(const float* __restrict__ rew, const uint8_t* __restrict__ ended, int T, int N,
-                                                        double gamma, float* __restrict__ out) {
+                                                        double gamma, float* __restrict__ out, const float* __restrict__ value,
+                                                        const float* __restrict__ last_value, double lam, float* __restrict__ adv) {
     __shared__ double s_b[kRtgChunks][kRtgCols], s_a[kRtgChunks][kRtgCols], s_sup[kRtgCols];
     const int tid = threadIdx.x, col = tid & (kRtgCols - 1), c = tid >> 4;
     // Workgroups go round-robin over the 8 XCDs (one L2 each) while a 128-byte line holds the rewards of 2 column blocks and
@@ -1239,28 +1247,38 @@ __global__ __launch_bounds__(256) void rtg_kernel_split(const float* __restrict_
         q = ((y >> 3) * 8 + x) * 8 + (y & 7);
     }
     const size_t n = (size_t)q * kRtgCols + col;   // N % 16 == 0: all 16 columns exist
+    const double gl = GAE ? gamma * lam : gamma, gv = GAE ? gamma * (1.0 - lam) : 0.0;
     double gpow = 1.0;
 #pragma unroll
-    for (int u = 0; u < kRtgRows; ++u) gpow *= gamma;
-    double rsup = 0;  // ppo.py:660
+    for (int u = 0; u < kRtgRows; ++u) gpow *= gl;
+    double rsup = (GAE && last_value) ? (double)last_value[n] : 0.0;  // ppo.py:660 (GAE: R beyond the batch end = the bootstrap value)
     for (int t_hi = T; t_hi > 0; t_hi -= kRtgSuper) {
         // rows t0 .. t0 + 31 of this chunk; t < 0 only below the first row of the batch (the lowest super-chunk): loaded from
         // row 0 (any valid address), never stored, and nothing valid depends on them (the scan runs towards them)
         const int t0 = t_hi - kRtgSuper + c * kRtgRows;
         float r[kRtgRows];
         uint8_t e[kRtgRows];
+        float v[GAE ? kRtgRows + 1 : 1];   // GAE: V of rows t0 .. t0 + 32 (the row after the chunk; beyond the batch: last_value or 0)
+        if (GAE) {
+            const int tn = t0 + kRtgRows;
+            v[kRtgRows] = tn < T ? value[(size_t)max(tn, 0) * N + n] : (last_value ? last_value[n] : 0.f);
+        }
 #pragma unroll
         for (int u = kRtgRows - 1; u >= 0; --u) {   // requested in the order pass 1 consumes them
             const size_t k = (size_t)max(t0 + u, 0) * N + n;
             r[u] = rew[k];
             e[u] = ended[k];
+            if (GAE) v[u] = value[k];
         }
+        // The batch end is terminal like an episode end (ppo.py:601,658) unless last_value bootstraps it: then the last row's
+        // factor stays gamma lambda and R beyond it is last_value (rsup above), so R[T-1] = r + gamma (1-lambda) V_last + gamma lambda V_last
         double b = 0;
         bool any = false;
 #pragma unroll
         for (int u = kRtgRows - 1; u >= 0; --u) {
-            const double g = e[u] ? 0.0 : gamma;
-            b = (double)r[u] + b * g;
+            const double g = e[u] ? 0.0 : gl;
+            const double add = GAE ? (double)r[u] + (e[u] ? 0.0 : gv * (double)v[u + 1]) : (double)r[u];
+            b = add + b * g;
             any |= e[u] != 0;
         }
         s_b[c][col] = b;
@@ -1278,9 +1296,14 @@ __global__ __launch_bounds__(256) void rtg_kernel_split(const float* __restrict_
             if (k > c) R = bk[k] + ak[k] * R;
 #pragma unroll
         for (int u = kRtgRows - 1; u >= 0; --u) {
-            const double g = e[u] ? 0.0 : gamma;
-            R = (double)r[u] + R * g;   // ppo.py:665
-            if (t0 + u >= 0) out[(size_t)(t0 + u) * N + n] = (float)R;   // ppo.py:669
+            const double g = e[u] ? 0.0 : gl;
+            const double add = GAE ? (double)r[u] + (e[u] ? 0.0 : gv * (double)v[u + 1]) : (double)r[u];
+            R = add + R * g;   // ppo.py:665
+            if (t0 + u >= 0) {
+                const size_t k = (size_t)(t0 + u) * N + n;
+                if (out) out[k] = (float)R;   // ppo.py:669
+                if (GAE) adv[k] = (float)R - v[u];
+            }
         }
         if (t_hi > kRtgSuper) {   // uniform: another super-chunk follows
             if (c == 0) s_sup[col] = R;
@@ -1303,6 +1326,28 @@ __global__ void rtg_kernel_generic(const float* __restrict__ rew, const uint8_t*
         if (ended[k]) disc = 0;
         disc = (double)r + disc * gamma;  // ppo.py:665
         out[k] = (float)disc;             // ppo.py:669
+    }
+}
+
+// GAE, any N: thread = env column, reverse over T (the recurrence of rtg_kernel_split<true>, serially)
+__global__ void gae_kernel_generic(const float* __restrict__ rew, const uint8_t* __restrict__ ended, const float* __restrict__ value,
+                                   const float* __restrict__ last_value, int T, int N, double gamma, double lam,
+                                   float* __restrict__ adv, float* __restrict__ ret) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double gl = gamma * lam, gv = gamma * (1.0 - lam);
+    double R = last_value ? (double)last_value[n] : 0.0;
+    float vnext = last_value ? last_value[n] : 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t k = (size_t)t * N + n;
+        const bool e = ended[k] != 0;
+        const float vt = value[k];
+        const double g = e ? 0.0 : gl;
+        const double add = (double)rew[k] + (e ? 0.0 : gv * (double)vnext);
+        R = add + R * g;
+        if (ret) ret[k] = (float)R;
+        adv[k] = (float)R - vt;
+        vnext = vt;
     }
 }
 
@@ -1827,11 +1872,29 @@ int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, i
     const char* ex = std::getenv("NAVSIM_RTG_EXACT");
     const bool exact = ex && ex[0] == '1';
     if (N % kRtgCols == 0 && !exact)
-        hipLaunchKernelGGL(rtg_kernel_split, dim3(N / kRtgCols), dim3(256), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N, gamma,
-                           out_dev);
+        hipLaunchKernelGGL(rtg_kernel_split<false>, dim3(N / kRtgCols), dim3(256), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N, gamma,
+                           out_dev, (const float*)nullptr, (const float*)nullptr, 1.0, (float*)nullptr);
     else
         hipLaunchKernelGGL(rtg_kernel_generic, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N,
                            gamma, out_dev);
+    HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
+}
+
+int navsim_gae_scan(const float* rew_dev, const uint8_t* ended_dev, const float* value_dev, const float* last_value_dev, int32_t T,
+                    int32_t N, double gamma, double lam, float* adv_dev, float* ret_dev, void* stream) {
+    if (T < 0 || N < 0) return fail(NAVSIM_E_ARG, "navsim_gae_scan: negative size");
+    if (T == 0 || N == 0) return NAVSIM_OK;
+    if (!rew_dev || !ended_dev || !value_dev || !adv_dev) return fail(NAVSIM_E_ARG, "navsim_gae_scan: null buffer");
+    if (!(lam >= 0.0 && lam <= 1.0)) return fail(NAVSIM_E_ARG, "navsim_gae_scan: lambda outside [0, 1]");
+    const char* ex = std::getenv("NAVSIM_RTG_EXACT");
+    const bool exact = ex && ex[0] == '1';
+    if (N % kRtgCols == 0 && !exact)
+        hipLaunchKernelGGL(rtg_kernel_split<true>, dim3(N / kRtgCols), dim3(256), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N, gamma,
+                           ret_dev, value_dev, last_value_dev, lam, adv_dev);
+    else
+        hipLaunchKernelGGL(gae_kernel_generic, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew_dev, ended_dev, value_dev,
+                           last_value_dev, T, N, gamma, lam, adv_dev, ret_dev);
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;
 }

@@ -19,7 +19,7 @@ import torch
 from . import maps as _maps
 from ._native import NavsimCfg, NavsimError, check, lib
 
-__all__ = ["NavSim", "VecEnv", "Env", "NavsimError"]
+__all__ = ["NavSim", "VecEnv", "Env", "NavsimError", "rtg_scan", "gae_scan"]
 
 
 def _ptr(t):
@@ -167,6 +167,25 @@ def rtg_scan(rew, ended, gamma, out=None):
     with torch.cuda.device(rew.device):
         check(lib().navsim_rtg_scan(_ptr(rew), _ptr(ended), T, N, float(gamma), _ptr(out), _stream()), "navsim_rtg_scan")
     return out
+
+
+def gae_scan(rew, ended, value, gamma, lam, last_value=None, want_returns=True):
+    """GAE(lambda) on [T,N] device tensors (navsim_gae_scan): returns (adv, lambda_returns).  lam = 1 without `last_value`
+    is PPO.compute_rtgs followed by A = rtgs - V (ppo.py:277, 643-671), bit for bit."""
+    if not rew.is_cuda:
+        raise NavsimError("gae_scan needs device tensors; there is no CPU path")
+    T, N = rew.shape
+    rew, ended, value = rew.contiguous(), ended.contiguous(), value.contiguous()
+    assert rew.dtype == torch.float32 and ended.dtype == torch.uint8 and value.dtype == torch.float32
+    assert ended.shape == rew.shape == value.shape and (last_value is None or last_value.shape == (N,))
+    if last_value is not None:
+        last_value = last_value.to(torch.float32).contiguous()
+    adv = torch.empty_like(rew)
+    ret = torch.empty_like(rew) if want_returns else None
+    with torch.cuda.device(rew.device):
+        check(lib().navsim_gae_scan(_ptr(rew), _ptr(ended), _ptr(value), _ptr(last_value), T, N, float(gamma), float(lam),
+                                    _ptr(adv), _ptr(ret), _stream()), "navsim_gae_scan")
+    return adv, ret
 
 
 class VecEnv:

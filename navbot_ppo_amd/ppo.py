@@ -39,6 +39,8 @@ class PPOConfig:
     lr: float = 3e-4                       # main.py:472
     clip: float = 0.2                      # main.py:473
     policy: str = "resmlp512"              # reference nets; "mlp64x2" = BASELINE config 2
+    gae_lambda: float = None               # None = the reference's estimator A = rtgs - V (ppo.py:277); a number in [0, 1] turns
+                                           # on GAE(lambda) (navsim_gae_scan): advantages and critic targets from the lambda-return
     init_var: float = 0.8                  # ppo.py:123
     var_decay: float = 0.995               # ppo.py:695
     var_floor: float = 0.1                 # ppo.py:694
@@ -287,15 +289,22 @@ class PPOUpdater:
         if rc != 0:
             raise RuntimeError(f"{self.fused}_update_epoch failed: {L.navppo_last_error().decode()}")
 
-    def update(self, obs, acts, logp_old, rtg, var):
+    def value(self, obs):
+        """V = critic(obs).squeeze() (ppo.py:275) for [n, D] rows."""
+        with torch.no_grad():
+            if self.fused and obs.is_contiguous() and obs.data_ptr() % 16 == 0:
+                return self._fused_value(obs)
+            return self.critic(obs).squeeze(-1)
+
+    def update(self, obs, acts, logp_old, rtg, var, adv_raw=None, V0=None):
+        """adv_raw / V0: advantages (before normalisation) and values computed by the caller (GAE); default = the reference's
+        A = rtg - V (ppo.py:275-277)."""
         cfg, ctx = self.cfg, self.ctx
         world = ctx.world if ctx is not None else 1
         with torch.no_grad():
-            if self.fused and obs.is_contiguous() and obs.data_ptr() % 16 == 0:
-                V0 = self._fused_value(obs)
-            else:
-                V0 = self.critic(obs).squeeze(-1)
-            adv = normalise_advantages(rtg - V0, ctx)          # ppo.py:275-284
+            if V0 is None:
+                V0 = self.value(obs)
+            adv = normalise_advantages(rtg - V0 if adv_raw is None else adv_raw, ctx)          # ppo.py:275-284
         n_ep = cfg.n_updates_per_iteration
         flat_before = self.fp.flat.clone()                     # for the parameter-delta diagnostics of ppo.py:402-403
         a_loss = c_loss = torch.zeros((), device=obs.device)   # n_updates_per_iteration == 0: nothing to report
@@ -478,8 +487,16 @@ class PPOTrainer:
             self._graph.replay()
         else:
             self._rollout_body()
-        from .env import rtg_scan
-        rtg_scan(self.rew_buf, self.ended_buf, cfg.gamma, out=self.rtg_buf)  # ppo.py:619 -> 643-671
+        from .env import gae_scan, rtg_scan
+        self._gae = None
+        if cfg.gae_lambda is None:
+            rtg_scan(self.rew_buf, self.ended_buf, cfg.gamma, out=self.rtg_buf)  # ppo.py:619 -> 643-671
+        else:   # extension: the critic's values of the stored observations -> lambda-returns (critic targets) and advantages
+            T, N, D = cfg.rollout_len, self.env.N, self.env.D
+            V = self.updater.value(self.obs_buf[:T].reshape(T * N, D)).reshape(T, N)
+            adv, ret = gae_scan(self.rew_buf, self.ended_buf, V, cfg.gamma, cfg.gae_lambda)
+            self.rtg_buf.copy_(ret)
+            self._gae = (adv.reshape(T * N), V.reshape(T * N))
         self.env_steps += cfg.rollout_len * self.env.N
 
     def _decay_exploration(self):
@@ -541,7 +558,8 @@ class PPOTrainer:
         m = self._rollout_metrics_dev()
         stats = self.updater.update(self.obs_buf[:T].reshape(T * N, D), self.act_buf.reshape(T * N, 2),
                                     self.logp_buf.reshape(T * N), self.rtg_buf.reshape(T * N),
-                                    self.var_host if self.updater.fused else self.var)
+                                    self.var_host if self.updater.fused else self.var,
+                                    **({} if self._gae is None else dict(adv_raw=self._gae[0], V0=self._gae[1])))
         if cuda:
             ev[2].record()
             torch.cuda.synchronize(self.device)

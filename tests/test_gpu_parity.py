@@ -767,3 +767,63 @@ def test_g10_reference_rollout_through_the_env_class():
     check_against_g10(d, obs, rew, ended, flags, eplen, epret, eppath, rtg)
     assert int(env._sim.get_state()["rng_ctr"][0]) == int(d["rng_ctr_final"])
     env.close()
+
+
+def test_bench_strong_scaling_two_ranks_over_gloo():
+    """`bench.py --scaling strong`: the env total stays fixed (SURVEY.md 8d(i) read literally: 4096 envs on 1 / 2 / 4 / 8 GPUs),
+    every rank takes envs_total / N, and the line says so.  Two ranks on one GPU over gloo, as above; --no-extras skips the
+    roofline legs."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NAVBOT_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--scaling", "strong", "--envs-total", "1024", "--rollout", "64", "--epochs", "3", "--no-extras"]
+    out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    js = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert js["n_gpus"] == 2 and js["scaling"] == "strong"
+    assert js["config"]["n_envs_total"] == 1024 and js["config"]["n_envs_per_gpu"] == 512
+    assert js["value"] == pytest.approx(64 * 1024 / (js["ms_per_step"] * 1e-3), rel=1e-3)
+
+
+def _gae_ref(rew, ended, V, gamma, lam, last=None):
+    """float64 statement of GAE with the reference's terminal rule (episode ends and, without `last`, the batch end)."""
+    T, N = rew.shape
+    R = np.zeros((T, N))
+    nxt_R = np.zeros(N) if last is None else last.astype(np.float64)
+    nxt_V = np.zeros(N) if last is None else last.astype(np.float64)
+    for t in range(T - 1, -1, -1):
+        e = ended[t].astype(bool)
+        R[t] = rew[t].astype(np.float64) + np.where(e, 0.0, gamma * (1 - lam) * nxt_V + gamma * lam * nxt_R)
+        nxt_R, nxt_V = R[t], V[t].astype(np.float64)
+    return R
+
+
+@pytest.mark.parametrize("T,N", [(512, 4096), (700, 64), (33, 48), (90, 37)])
+def test_gae_scan(T, N, monkeypatch):
+    """navsim_gae_scan (extension; north_star "GAE / return scan"): lambda = 1 without bootstrap IS the reference's estimator --
+    returns bit-identical to navsim_rtg_scan (ppo.py:643-671), advantages bit-identical to rtgs - V (ppo.py:277); lambda < 1
+    and a bootstrapped batch end match a float64 oracle."""
+    from navbot_ppo_amd.env import gae_scan, rtg_scan
+    rng = np.random.default_rng(T * 1000 + N)
+    rew = (rng.standard_normal((T, N)) * 20).astype(np.float32)
+    ended = (rng.random((T, N)) < 0.02).astype(np.uint8)
+    V = (rng.standard_normal((T, N)) * 50).astype(np.float32)
+    last = (rng.standard_normal(N) * 50).astype(np.float32)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    for exact in ("0", "1"):
+        monkeypatch.setenv("NAVSIM_RTG_EXACT", exact)
+        rtg = rtg_scan(cu(rew), cu(ended), 0.99)
+        adv, ret = gae_scan(cu(rew), cu(ended), cu(V), 0.99, 1.0)
+        assert torch.equal(ret, rtg)
+        assert torch.equal(adv, rtg - cu(V))
+        for lam, lv in ((0.95, None), (0.9, last), (0.0, None), (1.0, last)):
+            adv, ret = gae_scan(cu(rew), cu(ended), cu(V), 0.99, lam, last_value=None if lv is None else cu(lv))
+            want = _gae_ref(rew, ended, V, 0.99, lam, lv)
+            np.testing.assert_allclose(ret.cpu().numpy(), want, rtol=2e-6, atol=2e-5)
+            np.testing.assert_allclose(adv.cpu().numpy(), want.astype(np.float32) - V, rtol=0, atol=3e-4)
+            adv2, none = gae_scan(cu(rew), cu(ended), cu(V), 0.99, lam, last_value=None if lv is None else cu(lv), want_returns=False)
+            assert none is None and torch.equal(adv2, adv)

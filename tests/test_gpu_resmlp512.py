@@ -265,3 +265,20 @@ def test_fused_resmlp512_multi_rank_epoch_equals_single_rank(tmp_path):
     np.testing.assert_allclose(r0["flat"].numpy(), up.fp.flat.cpu().numpy(), rtol=0, atol=3e-6)
     for k in ("grad_norm", "actor_grad_norm", "critic_grad_norm"):
         assert r0["stats"][k] == pytest.approx(st[k], rel=2e-3), k
+
+
+def test_trainer_with_gae_lambda():
+    """PPOConfig.gae_lambda (off by default): lambda = 1 reproduces the default iteration exactly (same advantages, same
+    critic targets -> same weights); lambda = 0.95 runs and trains on lambda-returns."""
+    from navbot_ppo_amd.env import VecEnv
+    flats = []
+    for lam in (None, 1.0, 0.95):
+        env = VecEnv(256, map="stage_1", max_episode_steps=40, seed=1)
+        cfg = ppo.PPOConfig(rollout_len=64, max_episode_steps=40, n_updates_per_iteration=3, policy="mlp64x2", seed=2, gae_lambda=lam)
+        tr = ppo.PPOTrainer(env, cfg)
+        lg = tr.iteration()
+        assert np.isfinite(lg["actor_loss"]) and np.isfinite(lg["critic_loss"])
+        flats.append(tr.updater.fp.flat.clone())
+        env.close()
+    assert torch.equal(flats[0], flats[1])
+    assert not torch.equal(flats[0], flats[2])
