@@ -17,17 +17,18 @@
 // units and a workgroup owns (net, slice, group of sample tiles): its slice of the weights sits in LDS (<= 37 KB), its slice
 // of the weight gradients in accumulator registers (<= 128 per lane) for the whole launch, and a WAVE owns a 32-sample
 // tile end to end (no workgroup barrier in the tile loop, as in ppo_mlp64.hip).  A residual block's output is a sum over the
-// hidden units, i.e. over the slices: each slice writes its partial [n, 16 | 32] sum to HBM and a small streaming kernel adds
-// the four partials and applies the element-wise part (residual, bias, LeakyReLU, heads, PPO loss, LeakyReLU').  Per epoch:
+// hidden units, i.e. over the slices: each slice writes its partial [n, 16 | 32] sum to HBM, and whoever needs the block's
+// output adds the four partials and applies the element-wise part (residual, bias, LeakyReLU ...) on the way in.  Per epoch:
 //   fwd<16>  P1[s] = W2a[:, s] leaky(W1a[s] x + b1a[s])                 (MFMA)      s = slice
-//   E1       h1 = leaky(x + b2a + sum_s P1[s])                           (stream)
-//   fwd<32>  P2[s] = W2b[:, s] leaky(W1b[s] X1 + b1b[s])                 (MFMA)
-//   E2       h2, heads, loss, dpre2 = dL/d(pre-activation of h2), d(heads), db2b, statistics      (stream)
+//   fwd<32>  h1 = leaky(x + b2a + sum_s P1[s]) ; P2[s] = W2b[:, s] leaky(W1b[s] [x, h1] + b1b[s])           (MFMA)
+//   E2       h2 = leaky([x, h1] + b2b + sum_s P2[s]), heads, PPO loss / MSE, dpre2 = dL/d(pre-activation of h2), and the
+//            sample sums d(heads), db2b, statistics                      (streaming kernel: 0.7 ms of an 11.3 ms epoch)
 //   bwd<32>  per slice: hidden recomputed, dH = W2b[:, s]^T dpre2 . leaky', dW2b[:, s] += dpre2 H^T, dW1b[s] += dH X1^T,
 //            db1b[s], Q[s] = W1b[s][:, 16:32]^T dH                       (MFMA)
-//   E3       dpre1 = (sum_s Q[s] + dpre2[16:32]) . leaky'(h1), db2a      (stream)
-//   bwd<16>  the same for rb1 (no input gradient)                        (MFMA)
+//   bwd<16>  dpre1 = (sum_s Q[s] + dpre2[16:32]) . leaky'(h1), db2a ; then the same for rb1 (no input gradient)   (MFMA)
 //   reduce   partial rows -> gradient (-> Adam in place)
+// (Round 3 history: h1 and dpre1 first had streaming kernels of their own, 0.25 + 0.44 ms per epoch; folded into the
+// consumers' tile prologues they cost ~0.1 ms of VALU time, redundantly in the four slice workgroups.)
 // The hidden activation is recomputed in the backward kernels (K = 16 / 32: 16 % more MFMA work) instead of being stored
 // (4 KB per sample and net).  MFMA work per sample and net: 2 x 155,648 MAC = 311 kFLOP -> 1.31 TFLOP per epoch at
 // BASELINE configs[1] = 8.3 ms at the 157.3 TF f32-MFMA peak.
@@ -37,7 +38,11 @@
 // (n = lane & 15, q = lane >> 4) holds rows 16 b + 4 q + r (r = 0..3) of sample 16 st + n -- which is both the C/D layout of
 // the MFMA and, register r taken as the B operand of step r, a legal k-pairing when the A operand (weights) is read
 // k-permuted: lane (m, q) fetches columns 16 b + 4 q .. + 3 of its row with ONE ds_read_b128.  Products that contract over
-// samples (the weight gradients) take both operands from wave-private LDS tiles stored [row][sample].
+// samples (the weight gradients) need the transposed tiles: see resmlp_bwd.
+//
+// What bounds these kernels (profiles/r03_resmlp512_*): f32-input MFMA runs on the SIMD's FMA lanes, so every VALU
+// instruction (4 cycles per wave) adds to the MFMA time instead of hiding under it, and the loop sustains ~2.2 GHz, not the
+// nominal 2.4: time ~ (32 cycles x MFMAs + 4 cycles x VALU) / 2.2 GHz, which the four MFMA kernels reach to 92-100 %.
 //
 // Arithmetic: float32; sums over hidden units are taken slice by slice and over samples tile by tile, so results agree with
 // PyTorch autograd to f32 round-off (tests: <= 2e-4 of each tensor's scale), not bit for bit.  Deterministic: no atomics.
@@ -74,7 +79,7 @@ constexpr int PSTRIDE = 50304;       // pitch of a partial-gradient row (>= P_AC
 constexpr int EP = 128;              // pitch of a streaming-kernel partial row
 constexpr int kEMaxBlocks = 1024, kEThreads = 256;
 // columns of a streaming-kernel partial row
-constexpr int EC_B2A = 0, EC_B2B = 16, EC_WO1 = 48, EC_BO1 = 80, EC_WO2 = 81, EC_BO2 = 113, EC_STAT = 120;
+constexpr int EC_B2B = 16, EC_WO1 = 48, EC_BO1 = 80, EC_WO2 = 81, EC_BO2 = 113, EC_STAT = 120;
 
 template <int IN> struct Blk;
 template <> struct Blk<16> { static constexpr int W1 = rp::W1A, B1 = rp::B1A, W2 = rp::W2A; };
@@ -168,10 +173,14 @@ struct FwdSmem {
 };
 
 // pout[net][slice][n][IN] = W2[:, slice] leaky(W1[slice] X + b1[slice])
+// IN == 32: rows 16..31 of the input are h1 = leaky(x + b2a + sum_s P1[s]) (net_actor.py:41-53), formed here from the four
+// partials of resmlp_fwd<16> (p1) instead of by a streaming kernel of its own (0.25 ms per epoch); the slice-0 workgroups
+// store it to h1buf for the kernels behind.
 template <int IN>
 __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__ params, int net_base, int n_nets,
-                                                       const float* __restrict__ obs, const float* __restrict__ h1buf,
-                                                       long long n, int groups, float* __restrict__ pout) {
+                                                       const float* __restrict__ obs, const float* __restrict__ p1,
+                                                       float* __restrict__ h1buf, long long n, int groups,
+                                                       float* __restrict__ pout) {
     __shared__ __attribute__((aligned(16))) FwdSmem<IN> sm;
     constexpr int S1 = IN + 4, S2 = HS + 4, NB = IN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -181,17 +190,45 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
     for (int k = tid; k < IN * HS; k += kThreads) sm.W2s[(k / HS) * S2 + (k % HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
     if (tid < HS) sm.b1s[tid] = pn[Blk<IN>::B1 + wg.sl * HS + tid];
     __syncthreads();
-    const float* __restrict__ h1n = IN == 32 ? h1buf + (size_t)wg.net_i * n * 16 : nullptr;
     float* __restrict__ po = pout + (size_t)(wg.net_i * NSL + wg.sl) * n * IN;
     const long long n_tiles = (n + 31) / 32, stride = (long long)groups * kWaves;
-    f32x4 Xn[NB][2];
+    // rb2: the four rb1 partials of this net and the output bias of rb1 (rows 4 q .. 4 q + 3 of the lane)
+    const float* __restrict__ pp = IN == 32 ? p1 + (size_t)wg.net_i * NSL * n * 16 : nullptr;
+    float* __restrict__ ho = (IN == 32 && wg.sl == 0) ? h1buf + (size_t)wg.net_i * n * 16 : nullptr;
+    f32x4 b2 = zero4();
+    if (IN == 32)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b2[r] = pn[rp::B2A + 4 * q + r];
+    f32x4 xn[2], pa[IN == 32 ? NSL : 1][2];   // the next tile's rows, requested one tile ahead
+    auto request = [&](long long t) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const long long s = t * 32 + 16 * st + l15;
+            const bool v = s < n;
+            xn[st] = v ? v4(ld4(obs + s * 16 + 4 * q)) : zero4();
+            if (IN == 32)
+#pragma unroll
+                for (int k = 0; k < NSL; ++k) pa[k][st] = v ? v4(ld4(pp + ((size_t)k * n + s) * 16 + 4 * q)) : zero4();
+        }
+    };
     long long tile = (long long)wg.grp * kWaves + wave;
-    if (tile < n_tiles) load_x<IN>(Xn, obs, h1n, n, tile * 32, l15, q);
+    if (tile < n_tiles) request(tile);
     for (; tile < n_tiles; tile += stride) {
         f32x4 X[NB][2];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) X[b][0] = Xn[b][0], X[b][1] = Xn[b][1];
-        if (tile + stride < n_tiles) load_x<IN>(Xn, obs, h1n, n, (tile + stride) * 32, l15, q);   // next tile streams in
+        for (int st = 0; st < 2; ++st) {
+            X[0][st] = xn[st];
+            if (IN == 32) {
+                // the arithmetic (and its order) of net_actor.py:41-53 summed slice by slice: (x + b) + ((p0 + p1) + (p2 + p3))
+                f32x4 h = (xn[st] + b2) + ((pa[0][st] + pa[IN == 32 ? 1 : 0][st]) + (pa[IN == 32 ? 2 : 0][st] + pa[IN == 32 ? 3 : 0][st]));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = leaky(h[r]);
+                X[NB - 1][st] = h;
+                const long long s = tile * 32 + 16 * st + l15;
+                if (ho && s < n) *reinterpret_cast<float4*>(ho + s * 16 + 4 * q) = make_float4(h[0], h[1], h[2], h[3]);
+            }
+        }
+        if (tile + stride < n_tiles) request(tile + stride);   // next tile streams in
         f32x4 Y[NB][2];
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) Y[ob][0] = Y[ob][1] = zero4();
@@ -243,8 +280,12 @@ struct BwdSmem {
 };
 static_assert(sizeof(BwdSmem<32>) <= 160 * 1024, "LDS");
 
-// dypre [net][n][IN] = dL / d(pre-activation of the block's output).  Writes this slice's weight-gradient partials into row
-// (net, grp * 8 + wave) of wpart and, for rb2 (IN == 32), qout[net][slice][n][16] = W1[slice][:, 16:32]^T dH.
+// dypre [net][n][32] = dL / d(pre-activation of h2) (the streaming kernel E2 writes it).  rb2 (IN == 32) uses it as is and
+// writes qout[net][slice][n][16] = W1[slice][:, 16:32]^T dH; rb1 (IN == 16) forms ITS output gradient on the way in,
+//   dpre1 = (sum_s Q[s] + dpre2[16:32]) . leaky'(h1)        (the residual path of rb2 + its hidden path, net_actor.py:41-53)
+// from qin (the four partials rb2's launch wrote), dypre and h1buf, and its slice-0 workgroups add up db2a = sum dpre1
+// (this was a streaming kernel of its own: 0.44 ms per epoch).  Both write this slice's weight-gradient partials into row
+// (net, grp * 8 + wave) of wpart.
 // NST = sample tiles of a chunk per pass.  rb2 keeps 128 accumulator registers per lane and the compiler spills ~70 more next
 // to a whole 32 x 32 chunk of H / dH (NST = 2), mostly outside the tile loop (27 scratch accesses per tile); measured
 // alternatives, all slower: half chunks (NST = 1: no fewer spills, twice the weight reads, 5.54 vs 5.10 ms), 4 waves x 512
@@ -253,7 +294,7 @@ template <int IN, int NST>
 __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__ params, int n_nets, const float* __restrict__ obs,
                                                        const float* __restrict__ h1buf, const float* __restrict__ dypre,
                                                        long long n, int groups, float* __restrict__ wpart,
-                                                       float* __restrict__ qout) {
+                                                       float* __restrict__ qout, const float* __restrict__ qin) {
     __shared__ __attribute__((aligned(16))) BwdSmem<IN> sm;
     constexpr int S1 = IN + 4, NB = IN / 16;
     constexpr bool NEED_DX = IN == 32;
@@ -272,9 +313,11 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
     const int wr = 4 * q * LT + l15;          // S-layout store: tile[row 16 b + 4 q + r][sample 16 st + l15]: + (16 b + r) * LT + 16 st
     const int rr = l15 * LT + 4 * q;          // R-layout access: row 16 b + l15, samples 16 st + 4 q .. + 3:       + 16 b * LT + 16 st
 
-    const float* __restrict__ h1n = IN == 32 ? h1buf + (size_t)wg.net_i * n * 16 : nullptr;
-    const float* __restrict__ dyn = dypre + (size_t)wg.net_i * n * IN;
+    const float* __restrict__ h1n = h1buf + (size_t)wg.net_i * n * 16;
+    const float* __restrict__ dyn = dypre + (size_t)wg.net_i * n * 32;
     float* __restrict__ qo = NEED_DX ? qout + (size_t)(wg.net_i * NSL + wg.sl) * n * 16 : nullptr;
+    const float* __restrict__ qq = NEED_DX ? nullptr : qin + (size_t)wg.net_i * NSL * n * 16;
+    f32x4 adb2 = zero4();   // rb1: db2a rows 4 q .. 4 q + 3, summed over this lane's samples
 
     f32x4 aW2[NCH][NB][2];   // dW2[o block][j block of chunk c]
     f32x4 aW1[NCH][2][NB];   // dW1[j block of chunk c][i block]
@@ -289,19 +332,50 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
         }
 
     const long long n_tiles = (n + 31) / 32, stride = (long long)groups * kWaves;
-    auto load_tile = [&](f32x4 (&X)[NB][2], f32x4 (&DY)[NB][2], long long tile) {   // rows past n read as zeros: they add nothing
-        load_x<IN>(X, obs, h1n, n, tile * 32, l15, q);
+    // raw rows of a tile (past n: zeros, they add nothing).  rb2: X = [x, h1], G = dpre2.  rb1: X = x, G[0] = dpre2[16:32],
+    // RQ = h1 and the four Q partials; finish() turns them into the block's output gradient.
+    struct Raw { f32x4 X[NB][2], G[NB][2], RQ[NEED_DX ? 1 : 1 + NSL][2]; };
+    auto request = [&](Raw& w, long long tile) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const long long s = tile * 32 + 16 * st + l15;
+            const bool v = s < n;
+            w.X[0][st] = v ? v4(ld4(obs + s * 16 + 4 * q)) : zero4();
+            if (NEED_DX) {
+                w.X[NB - 1][st] = v ? v4(ld4(h1n + s * 16 + 4 * q)) : zero4();
 #pragma unroll
-            for (int ob = 0; ob < NB; ++ob) DY[ob][st] = s < n ? v4(ld4(dyn + s * IN + 16 * ob + 4 * q)) : zero4();
+                for (int ob = 0; ob < NB; ++ob) w.G[ob][st] = v ? v4(ld4(dyn + s * 32 + 16 * ob + 4 * q)) : zero4();
+            } else {
+                w.G[0][st] = v ? v4(ld4(dyn + s * 32 + 16 + 4 * q)) : zero4();
+                w.RQ[0][st] = v ? v4(ld4(h1n + s * 16 + 4 * q)) : zero4();
+#pragma unroll
+                for (int k = 0; k < NSL; ++k) w.RQ[NEED_DX ? 0 : 1 + k][st] = v ? v4(ld4(qq + ((size_t)k * n + s) * 16 + 4 * q)) : zero4();
+            }
+        }
+    };
+    auto finish = [&](const Raw& w, f32x4 (&X)[NB][2], f32x4 (&DY)[NB][2]) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) X[b][st] = w.X[b][st];
+            if (NEED_DX) {
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) DY[ob][st] = w.G[ob][st];
+            } else {
+                f32x4 d = w.G[0][st] + ((w.RQ[NEED_DX ? 0 : 1][st] + w.RQ[NEED_DX ? 0 : 2][st]) + (w.RQ[NEED_DX ? 0 : 3][st] + w.RQ[NEED_DX ? 0 : 4][st]));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = dleaky(d[r], w.RQ[0][st][r]);
+                DY[0][st] = d;
+                adb2 += d;
+            }
         }
     };
     f32x4 X[NB][2], DY[NB][2];   // S-layout: lane = sample, registers = feature rows
     long long tile = (long long)wg.grp * kWaves + wave;
-    load_tile(X, DY, tile);
+    Raw raw;
+    request(raw, tile);
     for (; tile < n_tiles; tile += stride) {
+        finish(raw, X, DY);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -312,7 +386,6 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
                     TDY[wr + (16 * b + r) * LT + 16 * st] = DY[b][st][r];
                 }
         f32x4 dXa[2] = {zero4(), zero4()};
-        f32x4 Xn[NB][2], DYn[NB][2];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -358,8 +431,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
                             dH[1][k] = mfma16(DY[ob][s0 + k][r], w1[r], dH[1][k]);
                         }
                 }
-                if (PREFETCH && c == NCH - 1 && s0 + NST == 2 && tile + stride < n_tiles)
-                    load_tile(Xn, DYn, tile + stride);   // X / DY are dead from here: the next tile's rows stream in
+                if (PREFETCH && c == NCH - 1 && s0 + NST == 2) request(raw, tile + stride);   // X / DY are dead: the next tile streams in
                 float db[2] = {0.f, 0.f};
                 __builtin_amdgcn_sched_barrier(0);   // one element-wise block per pass (see hidden_chunk)
 #pragma unroll
@@ -431,14 +503,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
             }
         }
         wave_lds_fence();   // the next tile's TX / TDY stores stay behind this tile's reads
-        if (PREFETCH) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) X[b][st] = Xn[b][st], DY[b][st] = DYn[b][st];
-        } else {
-            load_tile(X, DY, tile + stride);
-        }
+        if (!PREFETCH) request(raw, tile + stride);
     }
 
     // one partial-gradient row per WAVE (no cross-wave reduction here; resmlp_reduce sums the rows in a fixed order)
@@ -460,34 +525,18 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
             v += __shfl_xor(v, 32, 64);
             if (q == 0) row[Blk<IN>::B1 + j0 + l15] = v;
         }
-}
-
-// ---------------------------------------------------------------- streaming kernels (element-wise + reductions over samples)
-// E1: h1 = leaky(x + b2a + sum_s P1[s])   -- thread = (sample, 4 outputs)
-__global__ __launch_bounds__(kEThreads) void resmlp_e1(const float* __restrict__ params, int net_base, const float* __restrict__ obs,
-                                                       const float* __restrict__ p1, long long n, float* __restrict__ h1buf) {
-    const int net_i = blockIdx.y;
-    const float* __restrict__ pn = params + ((net_base + net_i) ? rp::P_ACTOR : 0);
-    const int og = threadIdx.x & 3;
-    float b[4];
+    if (!NEED_DX && wg.sl == 0) {   // db2a: lane (sample, q) holds rows 4 q + r summed over its samples: add the 16 sample lanes
 #pragma unroll
-    for (int k = 0; k < 4; ++k) b[k] = pn[rp::B2A + 4 * og + k];
-    const float* __restrict__ pp = p1 + (size_t)net_i * NSL * n * 16;
-    float* __restrict__ ho = h1buf + (size_t)net_i * n * 16;
-    const long long total = n * 4, step = (long long)gridDim.x * kEThreads;
-    for (long long g = (long long)blockIdx.x * kEThreads + threadIdx.x; g < total; g += step) {
-        const long long o = g * 4;   // == s * 16 + 4 * og
-        const float4 x = ld4(obs + o), a0 = ld4(pp + o), a1 = ld4(pp + (size_t)n * 16 + o), a2 = ld4(pp + (size_t)2 * n * 16 + o),
-                     a3 = ld4(pp + (size_t)3 * n * 16 + o);
-        float4 h;
-        h.x = leaky((x.x + b[0]) + ((a0.x + a1.x) + (a2.x + a3.x)));
-        h.y = leaky((x.y + b[1]) + ((a0.y + a1.y) + (a2.y + a3.y)));
-        h.z = leaky((x.z + b[2]) + ((a0.z + a1.z) + (a2.z + a3.z)));
-        h.w = leaky((x.w + b[3]) + ((a0.w + a1.w) + (a2.w + a3.w)));
-        *reinterpret_cast<float4*>(ho + o) = h;
+        for (int r = 0; r < 4; ++r) {
+            float v = adb2[r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+            if (l15 == 0) row[rp::B2A + 4 * q + r] = v;
+        }
     }
 }
 
+// ---------------------------------------------------------------- streaming kernels (element-wise + reductions over samples)
 // block-wide sum of per-thread accumulators over the threads that share (tid & (LPS - 1)); result in row[col0 + 4 * og + k]
 template <int LPS, int NV>
 __device__ __forceinline__ void block_sum_to_row(float (&acc)[NV], float* red /* [kEThreads / 64][LPS][NV] */, float* __restrict__ row,
@@ -627,43 +676,6 @@ __global__ __launch_bounds__(kEThreads) void resmlp_e2(const float* __restrict__
     block_sum_to_row<8, 17>(acc, red, epart + ((size_t)net_i * gridDim.x + blockIdx.x) * EP, cols, strides, og0);
 }
 
-// E3: dpre1 = (sum_s Q[s] + dpre2[16:32]) . leaky'(h1) ; db2a   -- thread = (sample, 4 of the 16 units)
-__global__ __launch_bounds__(kEThreads) void resmlp_e3(const float* __restrict__ h1buf, const float* __restrict__ qbuf,
-                                                       const float* __restrict__ dy2, long long n, float* __restrict__ dy1,
-                                                       float* __restrict__ epart) {
-    __shared__ float red[(kEThreads / 64) * 4 * 4];
-    const int net_i = blockIdx.y;
-    const int og = threadIdx.x & 3;
-    const float* __restrict__ hn = h1buf + (size_t)net_i * n * 16;
-    const float* __restrict__ qq = qbuf + (size_t)net_i * NSL * n * 16;
-    const float* __restrict__ d2 = dy2 + (size_t)net_i * n * 32;
-    float* __restrict__ d1o = dy1 + (size_t)net_i * n * 16;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const long long total = n * 4, step = (long long)gridDim.x * kEThreads;
-    for (long long g = (long long)blockIdx.x * kEThreads + threadIdx.x; g < total; g += step) {
-        const long long s = g >> 2, o = g * 4;
-        const float4 h = ld4(hn + o), r = ld4(d2 + s * 32 + 16 + 4 * og);
-        const float4 a0 = ld4(qq + o), a1 = ld4(qq + (size_t)n * 16 + o), a2 = ld4(qq + (size_t)2 * n * 16 + o),
-                     a3 = ld4(qq + (size_t)3 * n * 16 + o);
-        float4 d;
-        d.x = dleaky(r.x + ((a0.x + a1.x) + (a2.x + a3.x)), h.x);
-        d.y = dleaky(r.y + ((a0.y + a1.y) + (a2.y + a3.y)), h.y);
-        d.z = dleaky(r.z + ((a0.z + a1.z) + (a2.z + a3.z)), h.z);
-        d.w = dleaky(r.w + ((a0.w + a1.w) + (a2.w + a3.w)), h.w);
-        acc[0] += d.x; acc[1] += d.y; acc[2] += d.z; acc[3] += d.w;
-        *reinterpret_cast<float4*>(d1o + o) = d;
-    }
-    __shared__ int cols[4], strides[4];
-    __shared__ bool og0[4];
-    if (threadIdx.x < 4) {
-        cols[threadIdx.x] = EC_B2A + threadIdx.x;
-        strides[threadIdx.x] = 4;
-        og0[threadIdx.x] = false;
-    }
-    __syncthreads();
-    block_sum_to_row<4, 4>(acc, red, epart + ((size_t)net_i * gridDim.x + blockIdx.x) * EP, cols, strides, og0);
-}
-
 // ---------------------------------------------------------------- partial rows -> gradient (-> Adam)
 // grad[q] = sum of the partial rows that hold parameter q, rows in a fixed order (deterministic); ADAM: torch.optim.Adam's
 // step in place (ppo.py:116-117,381,392: betas (0.9, 0.999), eps 1e-8, no weight decay).
@@ -678,8 +690,8 @@ __global__ __launch_bounds__(64 * kRedGroups) void resmlp_reduce(const float* __
     const bool valid = qi < rp::P_ACTOR + rp::P_CRITIC;
     const int net_i = qi < rp::P_ACTOR ? 0 : 1, p = qi - net_i * rp::P_ACTOR;
     // where parameter p lives: biases of the block outputs and the heads come from the streaming kernels' rows
-    const bool from_e = (p >= rp::B2A && p < rp::B2A + 16) || p >= rp::B2B;
-    const int ecol = p < rp::B2B ? EC_B2A + (p - rp::B2A) : EC_B2B + (p - rp::B2B);   // B2B.. -> b2b | wo1 | bo1 | wo2 | bo2, same order
+    const bool from_e = p >= rp::B2B;                 // b2b and the heads: summed over samples by the streaming kernel E2
+    const int ecol = EC_B2B + (p - rp::B2B);          // b2b | wo1 | bo1 | wo2 | bo2, same order as the parameters
     const int w_rows = p < rp::W1B ? w_rows1 : w_rows2;   // rb1's and rb2's backward kernels run different numbers of waves
     const float* __restrict__ src = from_e ? epart + (size_t)net_i * e_rows * EP + ecol : wpart + (size_t)net_i * w_rows * PSTRIDE + p;
     const size_t pitch = from_e ? EP : PSTRIDE;
@@ -900,10 +912,8 @@ bool launch_ok(const char* what) {
 // forward of `n_nets` nets starting at net_base (0 = actor, 1 = critic) up to the partial sums of rb2
 void launch_forward(const Plan& p, const float* params, int net_base, int n_nets, const float* obs, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(resmlp_fwd<16>, dim3(p.wgs), dim3(kThreads), 0, st, params, net_base, n_nets, obs, (const float*)nullptr,
-                       (long long)n, p.groups, p.p1);
-    hipLaunchKernelGGL(resmlp_e1, dim3(p.e_blocks, n_nets), dim3(kEThreads), 0, st, params, net_base, obs, (const float*)p.p1,
-                       (long long)n, p.h1);
-    hipLaunchKernelGGL(resmlp_fwd<32>, dim3(p.wgs), dim3(kThreads), 0, st, params, net_base, n_nets, obs, (const float*)p.h1,
+                       (float*)nullptr, (long long)n, p.groups, p.p1);
+    hipLaunchKernelGGL(resmlp_fwd<32>, dim3(p.wgs), dim3(kThreads), 0, st, params, net_base, n_nets, obs, (const float*)p.p1, p.h1,
                        (long long)n, p.groups, p.p2);
 }
 
@@ -926,11 +936,9 @@ int loss_grad_impl(const char* name, bool adam, float* params, const float* obs,
     hipLaunchKernelGGL(resmlp_e2<false>, dim3(p.e_blocks, 2), dim3(kEThreads), 0, st, (const float*)params, 0, obs, (const float*)p.h1,
                        (const float*)p.p2, act, logp_old, rtg, adv, (long long)n, var, clip, inv_n, p.dy2, p.epart, (float*)nullptr);
     hipLaunchKernelGGL((resmlp_bwd<32, 2>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
-                       (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb);
-    hipLaunchKernelGGL(resmlp_e3, dim3(p.e_blocks, 2), dim3(kEThreads), 0, st, (const float*)p.h1, (const float*)p.qb,
-                       (const float*)p.dy2, (long long)n, p.dy1, p.epart);
-    hipLaunchKernelGGL((resmlp_bwd<16, 2>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)nullptr,
-                       (const float*)p.dy1, (long long)n, p.groups, p.wpart, (float*)nullptr);
+                       (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb, (const float*)nullptr);
+    hipLaunchKernelGGL((resmlp_bwd<16, 2>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
+                       (const float*)p.dy2, (long long)n, p.groups, p.wpart, (float*)nullptr, (const float*)p.qb);
     const int rblocks = (rp::P_ACTOR + rp::P_CRITIC + 63) / 64;
     if (adam) {
         const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));

@@ -69,6 +69,10 @@ class NavSim:
 
     # -- world
     def set_map(self, seg, per_env=None):
+        """seg [S,4] (shared) or [N,S,4] (per env) float32 segments (ax, ay, bx, by).  The handle BORROWS the device tensor it
+        is given (kept alive here) -- except for shared maps of 65..4096 segments, of which navsim_set_map takes its own
+        Morton-ordered SNAPSHOT with tile bounding boxes (a blocking copy + host sort).  So: after editing a map tensor in
+        place (domain randomisation), call set_map again; never call it inside a stream capture or a hot loop."""
         seg = torch.as_tensor(np.asarray(seg, dtype=np.float32) if not torch.is_tensor(seg) else seg)
         seg = seg.to(device=self.device, dtype=torch.float32).contiguous()
         if per_env is None:

@@ -83,10 +83,16 @@ class DistCtx:
             kw = {"device_id": self.device} if backend == "nccl" else {}
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
         if self.enabled:
-            self.backend = dist.get_backend()
-            if self.device.type == "cuda" and not os.environ.get("NAVBOT_DIST_BACKEND"):
-                assert self.backend == "nccl", f"GPU ranks must talk RCCL (torch backend 'nccl'), got {self.backend!r}"
-            if self.backend == "nccl":
+            # a launcher may have created the group itself (backend=None or "cpu:gloo,cuda:nccl"): ask for the CUDA backend
+            try:
+                self.backend = dist.get_backend_config().get_device_backend_map().get("cuda", dist.get_backend())
+            except Exception:
+                self.backend = dist.get_backend()
+            if self.device.type == "cuda" and not os.environ.get("NAVBOT_DIST_BACKEND") and "nccl" not in str(self.backend):
+                import warnings
+                warnings.warn(f"GPU ranks should talk RCCL (torch backend 'nccl'); the process group uses {self.backend!r}")
+            if "nccl" in str(self.backend):
+                self.backend = "nccl"
                 try:
                     self.rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
                 except Exception:
@@ -464,8 +470,12 @@ class PPOTrainer:
         self.epret_buf.zero_()
         self.eplen_buf.zero_()
         self.env.sim.reset(self.obs_buf[0])  # ppo.py:486: every batch starts from a reset
+        sim = self.env.sim
+        # shared maps of 65..4096 segments carry tile bounding boxes (navsim_set_map) that only the per-step kernel's BOXES
+        # instantiation uses to skip whole tiles: there the hipGraph of per-step launches is the faster rollout
+        tile_boxes = (not getattr(sim, "per_env", False)) and 65 <= getattr(sim, "S", 0) <= 4096
         if (cfg.persistent_rollout and self.updater.fused_mlp64 and self.env.B == 10
-                and self.env.sim.obs_dtype == torch.float32):
+                and sim.obs_dtype == torch.float32 and not tile_boxes):
             self._persistent_rollout()
         elif cfg.use_graph and self.device.type == "cuda":
             if self._graph is not None and self._graph_gen != self.env.sim.generation:
