@@ -47,6 +47,15 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
                            float var, float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
 
 /*
+ * One net of navppo_mlp64_loss_grad (net 0 = actor: ppo.py:316-342,349; net 1 = critic: :343,386): writes that net's slice of
+ * grad_dev and its statistics only.  The multi-GPU epoch launches the actor's pass, starts the all-reduce of the actor's
+ * gradient slice, and runs the critic's pass while that all-reduce is in flight (same arguments as navppo_mlp64_loss_grad).
+ */
+int navppo_mlp64_loss_grad_net(int32_t net, const float* params_dev, const float* obs_dev, const float* act_dev,
+                               const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var,
+                               float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
+
+/*
  * torch.optim.Adam's step (defaults: no weight decay, no amsgrad) on a flat buffer with the gradient scaled first: the
  * multi-GPU epoch is navppo_mlp64_loss_grad -> all-reduce(sum) of grad_dev over RCCL -> navppo_adam_step(grad_scale = 1 / world).
  */

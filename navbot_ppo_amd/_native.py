@@ -57,6 +57,7 @@ SYMBOLS = [
     ("navppo_last_error", C.c_char_p, []),
     ("navppo_mlp64_workspace_bytes", C.c_size_t, []),
     ("navppo_mlp64_loss_grad", C.c_int, [_vp] * 6 + [C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
+    ("navppo_mlp64_loss_grad_net", C.c_int, [_i32] + [_vp] * 6 + [C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     ("navppo_adam_step", C.c_int, [_vp, _vp, _vp, _vp, C.c_int64] + [C.c_float] * 5 + [_i32, _vp]),
     ("navppo_mlp64_value", C.c_int, [_vp, _vp, C.c_int64, _vp, _vp]),
     ("navppo_episode_sums", C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),

@@ -533,14 +533,15 @@ __global__ __launch_bounds__(64 * kRedGroups) void reduce_adam(const float* __re
                                                    const float* __restrict__ partial_c, const float* __restrict__ stats_partial_c,
                                                    int n_blocks, float inv_n, float* __restrict__ grad, float* __restrict__ stats,
                                                    float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
-                                                   float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+                                                   float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+                                                   int q_begin = 0, int q_end = P_ACTOR + P_CRITIC) {
     __shared__ float part[kRedGroups][64];
-    const int lane = threadIdx.x & 63, q = blockIdx.x * 64 + lane, g = threadIdx.x >> 6;   // q: index into actor | critic
+    const int lane = threadIdx.x & 63, q = q_begin + blockIdx.x * 64 + lane, g = threadIdx.x >> 6;   // q: index into actor | critic
     const bool actor = q < P_ACTOR;
     const float* __restrict__ partial = actor ? partial_a : partial_c;
     const int P = actor ? P_ACTOR : P_CRITIC, p = actor ? q : q - P_ACTOR;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (q < P_ACTOR + P_CRITIC) {
+    if (q < q_end) {
         int b = g;
         for (; b + 3 * kRedGroups < n_blocks; b += 4 * kRedGroups) {   // the row reads of a (b, lane) pair are 256 B per wave
             s0 += partial[(size_t)b * P + p];
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(64 * kRedGroups) void reduce_adam(const float* __re
     }
     part[g][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (g == 0 && q < P_ACTOR + P_CRITIC) {
+    if (g == 0 && q < q_end) {
         float gr = 0.f;
 #pragma unroll
         for (int k = 0; k < kRedGroups; ++k) gr += part[k][lane];
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(64 * kRedGroups) void reduce_adam(const float* __re
             params[q] -= (lr / bc1) * (mm / denom);
         }
     }
-    if (blockIdx.x == 0 && g < 8 && (g & 3) < 3) {   // stats[0..2] actor, stats[4..6] critic: wave g sums statistic g over the rows
+    const bool net_here = (g < 4) ? (q_begin == 0) : (q_end > P_ACTOR);   // a one-net launch leaves the other net's statistics alone
+    if (blockIdx.x == 0 && g < 8 && (g & 3) < 3 && net_here) {   // stats[0..2] actor, stats[4..6] critic: wave g sums statistic g over the rows
         const float* sp = (g < 4) ? stats_partial_a : stats_partial_c;
         float s = 0.f;
         for (int b = lane; b < n_blocks; b += 64) s += sp[b * 4 + (g & 3)];
@@ -734,6 +736,49 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_loss_grad: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+int navppo_mlp64_loss_grad_net(int32_t net, const float* params_dev, const float* obs_dev, const float* act_dev,
+                               const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var,
+                               float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
+    if ((net != 0 && net != 1) || !params_dev || !obs_dev || !act_dev || !logp_old_dev || !rtg_dev || !adv_dev || !grad_dev ||
+        !stats_dev || !workspace_dev || n_samples < 1 || !(var > 0.f)) {
+        g_err = "navppo_mlp64_loss_grad_net: bad argument";
+        return -1;
+    }
+    if (((uintptr_t)obs_dev & 15) || ((uintptr_t)act_dev & 7)) {
+        g_err = "navppo_mlp64_loss_grad_net: obs must be 16-byte and act 8-byte aligned";
+        return -1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = reinterpret_cast<float*>(workspace_dev);
+    float* stats_partial = partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * NAVPPO_MLP64_ACTOR_PARAMS;
+    float* partial_c = partial + (size_t)kWMaxBlocks * P_ACTOR;
+    float* stats_partial_c = stats_partial + (size_t)kWMaxBlocks * 4;
+    const float inv_n = 1.0f / (float)n_samples;
+    const long long wtiles = (n_samples + 31) / 32;
+    const long long want = (wtiles + kWWaves - 1) / kWWaves;
+    const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
+    if (net == 0) {
+        hipLaunchKernelGGL((mlp64_pass_w<true>), dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev,
+                           adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, grad_dev, stats_dev, (float*)nullptr);
+        hipLaunchKernelGGL(reduce_adam<false>, dim3((P_ACTOR + 63) / 64), dim3(64 * kRedGroups), 0, st, partial, stats_partial, partial_c,
+                           stats_partial_c, blocks, inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 0,
+                           P_ACTOR);
+    } else {
+        hipLaunchKernelGGL((mlp64_pass_w<false>), dim3(blocks), dim3(kWThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev, logp_old_dev,
+                           rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial_c, stats_partial_c, grad_dev + P_ACTOR,
+                           stats_dev + 4, (float*)nullptr);
+        hipLaunchKernelGGL(reduce_adam<false>, dim3((P_CRITIC + 63) / 64), dim3(64 * kRedGroups), 0, st, partial, stats_partial, partial_c,
+                           stats_partial_c, blocks, inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f,
+                           P_ACTOR, P_ACTOR + P_CRITIC);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_err = std::string("navppo_mlp64_loss_grad_net: ") + hipGetErrorString(e);
         return -2;
     }
     return 0;

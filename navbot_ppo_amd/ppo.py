@@ -49,7 +49,8 @@ class PPOConfig:
     seed: int = 0
     use_graph: bool = True                 # capture the T-step rollout in one hipGraph
     persistent_rollout: bool = True        # mlp64x2 on GPU: all T steps in ONE launch (navsim_rollout_mlp64)
-    fused_update: bool = True              # mlp64x2 on GPU: fused HIP loss+gradient kernel (csrc/ppo_mlp64.hip)
+    fused_update: bool = True              # on GPU: fused HIP loss+gradient kernels (csrc/ppo_mlp64.hip, csrc/ppo_resmlp512.hip)
+    overlap_allreduce: bool = True         # multi-GPU, mlp64x2: the actor's gradient all-reduce runs under the critic's pass
     output_dir: str = ""                   # "" = no checkpoints / logs
     episode_csv_rows: int = 2000           # per-iteration cap on rows appended to <method>_train_episodes.csv (0 = off)
     tb_episode_rows: int = 256             # per-iteration cap on Episode_Rewards/train points in the TensorBoard file (0 = off)
@@ -251,6 +252,18 @@ class PPOUpdater:
         if rc != 0:
             raise RuntimeError(f"{self.fused}_loss_grad failed: {L.navppo_last_error().decode()}")
 
+    def _fused_loss_grad_net(self, net, obs, acts, logp_old, rtg, adv, var, stats):
+        """One net's half of _fused_loss_grad (navppo_mlp64_loss_grad_net): its slice of the flat gradient, its statistics."""
+        import ctypes as C
+        from ._native import lib
+        L = lib()
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        rc = L.navppo_mlp64_loss_grad_net(int(net), ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+                                          int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad), ptr(stats),
+                                          ptr(self._workspace(obs.shape[0])), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"navppo_mlp64_loss_grad_net failed: {L.navppo_last_error().decode()}")
+
     def _fused_adam(self, grad_scale):
         import ctypes as C
         from ._native import lib
@@ -324,7 +337,18 @@ class PPOUpdater:
         for ep in range(n_ep):                                 # ppo.py:305
             if self.fused:
                 # per-epoch diagnostics land in row ep of a device buffer: no extra launches inside the epoch loop
-                if world > 1:   # fused passes -> ONE all-reduce of the flat gradient (RCCL) -> scale + Adam in one launch
+                if world > 1 and self.fused_mlp64 and cfg.overlap_allreduce:
+                    # actor pass -> its gradient slice goes on the wire (RCCL's own stream) while the critic pass computes ->
+                    # the critic's slice -> both awaited -> scale + Adam in one launch
+                    n_a = self._n_actor
+                    self._fused_loss_grad_net(0, obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
+                    wa = dist.all_reduce(self.fp.grad[:n_a], op=dist.ReduceOp.SUM, async_op=True)
+                    self._fused_loss_grad_net(1, obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
+                    wc = dist.all_reduce(self.fp.grad[n_a:], op=dist.ReduceOp.SUM, async_op=True)
+                    wa.wait()
+                    wc.wait()
+                    self._fused_adam(1.0 / world)
+                elif world > 1:   # fused passes -> ONE all-reduce of the flat gradient (RCCL) -> scale + Adam in one launch
                     self._fused_loss_grad(obs, acts, logp_old, rtg, adv, var_f, stats=self._fhist[ep])
                     ctx.all_reduce_sum(self.fp.grad)
                     self._fused_adam(1.0 / world)

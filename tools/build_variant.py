@@ -17,5 +17,5 @@ open(src, "w").write(t)
 out = os.path.join(R, "build", f"libnavsim_{name}.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
                        "-shared", "-fvisibility=hidden", "-I", os.path.join(R, "include"), "-I", os.path.join(R, "navbot_ppo_amd/csrc"), src,
-                       os.path.join(R, "navbot_ppo_amd/csrc/ppo_mlp64.hip"), "-o", out])
+                       os.path.join(R, "navbot_ppo_amd/csrc/ppo_mlp64.hip"), os.path.join(R, "navbot_ppo_amd/csrc/ppo_resmlp512.hip"), "-o", out])
 print(out)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM-side traffic of the step kernel per launch (run on the GPU box through gpurun):
 rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (kernel-trace only), as MI355X_MICROARCH.md prescribes,
-for configs[2] (16384 envs, per-env S=128) and the beyond-L3 point (S=1024).  Writes gpurun_out/r02/pmc_traffic.json, tagged
+for configs[2] (16384 envs, per-env S=128) and the beyond-L3 point (S=1024).  Writes gpurun_out/<round>/pmc_traffic.json, tagged
 with the sha256 of csrc/navsim.hip so that bench.py only quotes it for the kernel it was measured on.
 Corrections (the guide's HBM section): counters are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
 (16 B / lane) coalesced stream -- the segment stream is >= 94 % of this kernel's reads -- so reads = 2 x FETCH_SIZE."""
@@ -20,12 +20,16 @@ def counter(ctr, flag):
     vals = vals[len(vals) // 4:]   # steady state
     return sum(vals) / len(vals)
 
-out = {"navsim_hip_sha256": hashlib.sha256(open(os.path.join(R, "navbot_ppo_amd/csrc/navsim.hip"), "rb").read()).hexdigest(),
+import datetime, socket
+RND = os.environ.get("ROUND", "r03")
+out = {"recorded_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ"), "recorded_on": socket.gethostname(),
+       "run_id": os.environ.get("PROF_RUN_ID", ""),   # tools/prof_all.sh: the same id is written next to the bench line of that call
+       "navsim_hip_sha256": hashlib.sha256(open(os.path.join(R, "navbot_ppo_amd/csrc/navsim.hip"), "rb").read()).hexdigest(),
        "_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; KiB; reads = 2 x FETCH_SIZE (gfx950 wide-stream correction)"}
 for key, flag, alg in (("cfg3", "--cfg3", 16384 * (134 + 16 * 128)), ("s1024", "--s=1024", 16384 * (134 + 16 * 1024))):
     f, w = counter("FETCH_SIZE", flag), counter("WRITE_SIZE", flag)
     out[key + "_step"] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "algorithmic_bytes_per_launch": alg}
     out[key + "_step_bytes_per_launch"] = int((2 * f + w) * 1024)
-os.makedirs(os.path.join(R, "gpurun_out/r02"), exist_ok=True)
-json.dump(out, open(os.path.join(R, "gpurun_out/r02/pmc_traffic.json"), "w"), indent=1)
+os.makedirs(os.path.join(R, "gpurun_out", RND), exist_ok=True)
+json.dump(out, open(os.path.join(R, "gpurun_out", RND, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -1,5 +1,5 @@
 import ctypes as C, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").getcwd())
 import torch
 from navbot_ppo_amd import nets, ppo
 dev = torch.device("cuda"); torch.manual_seed(0)
