@@ -88,11 +88,11 @@ template <> struct Blk<32> { static constexpr int W1 = rp::W1B, B1 = rp::B1B, W2
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ f32x4 v4(const float4 a) { return f32x4{a.x, a.y, a.z, a.w}; }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-// nn.LeakyReLU(0.2) (net_actor.py:38) = max(x, 0.2 x).  Three instructions (the compiler quiets a possible signalling NaN
-// with v_max x, x first).  A hand-written v_max_f32 in inline asm saves one of them (fwd<16> -5 %, fwd<32> -3 %), but
-// the hazard recogniser does not see an asm statement as a VALU write, so an MFMA that consumes the result next reads a
-// stale register (the rollout policy step did): not used.
-__device__ __forceinline__ float leaky(float x) { return fmaxf(x, 0.2f * x); }
+// nn.LeakyReLU(0.2) (net_actor.py:38) = max(x, 0.2 x) = the median of (x, 0.2 x, FLT_MAX-ish): v_mul + v_med3_f32, two
+// instructions.  fmaxf() costs three (the compiler quiets a possible signalling NaN with v_max x, x first; it also rewrites a
+// median against +inf into that max).  A hand-written v_max_f32 in inline asm is two as well, but the hazard recogniser does
+// not see an asm statement as a VALU write and the MFMA behind it read a stale register (the rollout policy step did).
+__device__ __forceinline__ float leaky(float x) { return __builtin_amdgcn_fmed3f(x, 0.2f * x, 3.0e38f); }
 __device__ __forceinline__ float dleaky(float g, float act) { return act > 0.f ? g : 0.2f * g; }   // sign(leaky(x)) == sign(x)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void wave_lds_fence() {
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
                 // H^T (R-layout: lane = hidden unit 16 jb + l15 of the chunk, register r = sample 16 st + 4 q + r)
                 f32x4 H[2][NST], dH[2][NST];
 #pragma unroll
-                for (int jb = 0; jb < 2; ++jb) {
+                for (int jb = 0; jb < 2; ++jb) {   // (the bias 8-fold in LDS, one ds_read_b128 per tile instead of 4 v_mov: measured no gain)
                     const float bj = sm.b1s[c * 32 + 16 * jb + l15];
 #pragma unroll
                     for (int k = 0; k < NST; ++k) H[jb][k] = f32x4{bj, bj, bj, bj};
