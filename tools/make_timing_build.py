@@ -10,8 +10,8 @@ def rep(a, b, n=1):
     assert a in t, a
     t = t.replace(a, b, n)
 rep("template <int NB, int EPB, int NW = 4>\nstruct StepSmem {",
-    "__device__ long long g_dbg[64 * 8];\n__device__ long long g_blk[8192 * 3];\n"
-    "#define STAMP(slot) do { if (blockIdx.x % 97 == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) g_dbg[((blockIdx.x / 97) % 8) * 64 + (threadIdx.x >> 6) * 8 + (slot)] = wall_clock64(); } while (0)\n"
+    "__device__ long long g_dbg[128 * 8];\n__device__ long long g_blk[8192 * 3];\n"
+    "#define STAMP(slot) do { if (blockIdx.x % 97 == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) g_dbg[((blockIdx.x / 97) % 8) * 128 + (threadIdx.x >> 6) * 8 + (slot)] = wall_clock64(); } while (0)\n"
     "template <int NB, int EPB, int NW = 4>\nstruct StepSmem {")
 rep("    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motion + sensor frame",
     "    STAMP(0);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) { g_blk[blockIdx.x * 3] = wall_clock64(); unsigned hw; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw)); unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc)); g_blk[blockIdx.x * 3 + 2] = ((long long)xcc << 32) | hw; }\n"
@@ -24,10 +24,10 @@ j = t.rfind("}\n\n", 0, idx)
 t = t[:j] + "    STAMP(7);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk[blockIdx.x * 3 + 1] = wall_clock64();\n" + t[j:]
 rep("int navsim_version(void) { return NAVSIM_ABI_VERSION; }",
     "int navsim_version(void) { return NAVSIM_ABI_VERSION; }\n"
-    "int navsim_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 512); }\n"
+    "int navsim_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 1024); }\n"
     "int navsim_blk_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(long long) * 8192 * 3); }")
 # policy-phase stamps of the persistent rollout kernel (last step wins): loop top, MFMA part done, after barrier 1, finish done
-rep("__device__ long long g_dbg[64 * 8];", "__device__ long long g_dbg[64 * 8];\n__device__ long long g_pol[8 * 8 * 4];\n"
+rep("__device__ long long g_dbg[128 * 8];", "__device__ long long g_dbg[128 * 8];\n__device__ long long g_pol[8 * 8 * 4];\n"
     "#define PSTAMP(slot) do { if (blockIdx.x % 97 == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) g_pol[((blockIdx.x / 97) % 8) * 32 + (threadIdx.x >> 6) * 4 + (slot)] = wall_clock64(); } while (0)")
 rep("        if (wave < 4) {\n            const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]",
     "        PSTAMP(0);\n        if (wave < 4) {\n            const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]")

@@ -19,9 +19,9 @@ if "--rollout" in sys.argv:   # the persistent rollout kernel: stamps of its LAS
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); tr._persistent_rollout(); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / T
-    buf = np.zeros(512, dtype=np.int64)
+    buf = np.zeros(1024, dtype=np.int64)
     L = _native.lib(); L.navsim_dbg_read.argtypes = [C.c_void_p]; L.navsim_dbg_read(buf.ctypes.data_as(C.c_void_p))
-    b = buf.reshape(8, 8, 8)
+    b = buf.reshape(8, 16, 8)
     print(f"persistent rollout: {us:.2f} us per step ({T} steps)")
     for blk in range(3):
         t0 = b[blk, :4, 0].min()
@@ -50,10 +50,10 @@ acts = torch.rand((N, 2), device="cuda"); acts[:, 1] = acts[:, 1] * 2 - 1
 for k in range(20): sim.step(acts, io.obs, io.reward, io.done, io.arrive, io.ended)
 torch.cuda.synchronize()
 sim.step(acts, io.obs, io.reward, io.done, io.arrive, io.ended); torch.cuda.synchronize()
-buf = np.zeros(512, dtype=np.int64)
+buf = np.zeros(1024, dtype=np.int64)
 L = _native.lib(); L.navsim_dbg_read.argtypes = [C.c_void_p]; L.navsim_dbg_read(buf.ctypes.data_as(C.c_void_p))
-b = buf.reshape(8, 8, 8)  # [sampled block][wave][slot]
-NWV = 8 if EPBv >= 32 else 4
+b = buf.reshape(8, 16, 8)  # [sampled block][wave][slot]
+NWV = 16 if EPBv >= 64 else (8 if EPBv >= 32 else 4)
 t0 = b[:, :NWV, 0][b[:, :NWV, 0] > 0].min()
 for blk in range(2):
     print(f"block sample {blk}")
