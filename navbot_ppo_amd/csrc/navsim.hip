@@ -432,7 +432,7 @@ __device__ __forceinline__ float write_lidar(float* row, const float* best, int 
 // NW: waves per workgroup (4; the persistent rollout kernel, one workgroup per CU, runs 8 for a shorter cast).
 // BOXES: shared map with tile bounding boxes (Params::tile_box): whole 64-segment tiles that lie behind the beam fan or out of
 // range are skipped without being loaded (the house map: 32 tiles, ~5 of them near any one pose).
-template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4, bool BOXES = false>
+template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4, bool BOXES = false, bool PAIR = false>
 __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>& sm, int& next_env,
                                           const float2* __restrict__ action, const float2* __restrict__ past_override,
                                           void* __restrict__ obs_out, float* __restrict__ reward,
@@ -441,11 +441,14 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
                                           int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out,
                                           const bool last_step = true) {
     static_assert(EPB <= 64 && EPB >= 4 && NB % 2 == 0, "EPB / NB");
+    static_assert(!(PAIR && BOXES), "tile boxes describe 64-segment tiles");
     constexpr int kThreads = 64 * NW;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // readfirstlane tells the compiler what it cannot see: the wave index is wave-uniform, so the work positions, the loop
+    // exits and every `wave < PW` test below live in SGPRs and scalar branches instead of VGPRs and exec-mask loops
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int base = blockIdx.x * EPB;
     constexpr int B = NB;       // host dispatch guarantees P.B == NB
     constexpr int D = B + 6;
@@ -494,20 +497,40 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     const int j0 = lane & ((1 << spl) - 1);
     const int n_items = (nloc + epp - 1) / epp;
     const int ntiles = (P.S + 63) >> 6;
+    // PAIR (maps of more than 64 segments, one env per pass): a pass takes 128 segments, two per lane (j and j + 64) -- the
+    // work-queue, address and loop instructions of a pass, about as many as its arithmetic, are paid once per 128 segments
+    const int ntl = PAIR ? (ntiles + 1) >> 1 : ntiles;   // passes per item
     struct Pos { int it, t; };
     auto grab = [&]() __attribute__((always_inline)) {
         int v = 0;
         if (lane == 0) v = atomicAdd(&next_env, 1);
         return __builtin_amdgcn_readfirstlane(v);
     };
+    // Requests are unconditional (a position past the end re-reads a clamped, valid address and is flagged invalid): the count of
+    // requests issued after any given one is then the same on every path, which is what lets `s_waitcnt vmcnt(n)` -- the counter
+    // retires in order -- wait for the OLDEST slot only and leave the two younger requests in flight.  With exec-masked loads the
+    // compiler had to assume the path that skipped them and waited for vmcnt(0) before every tile: no prefetch at all.
     auto ld = [&](const Pos p, float4& g, bool& v) __attribute__((always_inline)) {
         const int el = p.it * epp + sub, j = (p.t << 6) + j0;
         v = (p.it < n_items) && (el < nloc) && (j < P.S);
-        if (v) g = P.seg[(P.per_env ? (size_t)(base + el) * (size_t)P.S : (size_t)0) + (size_t)j];
+        g = P.seg[(P.per_env ? (size_t)(base + min(el, nloc - 1)) * (size_t)P.S : (size_t)0) + (size_t)min(j, P.S - 1)];
+    };
+    auto ld2 = [&](const Pos p, float4& ga, bool& va, float4& gb, bool& vb) __attribute__((always_inline)) {
+        const int j = (p.t << 7) + lane;
+        const bool item = (p.it < n_items) && (p.it < nloc);
+        va = item && (j < P.S);
+        vb = item && (j + 64 < P.S);
+        const float4* src = P.seg + (P.per_env ? (size_t)(base + min(p.it, nloc - 1)) * (size_t)P.S : (size_t)0);
+        ga = src[min(j, P.S - 1)];
+        gb = src[min(j + 64, P.S - 1)];
     };
     Pos p0 = {n_items, 0}, p1 = {n_items, 0}, p2 = {n_items, 0};
-    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
-    bool v0 = false, v1 = false, v2 = false;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0, g0b = g0, g1b = g0, g2b = g0;
+    bool v0 = false, v1 = false, v2 = false, v0b = false, v1b = false, v2b = false;
+    auto request = [&](const Pos p, float4& ga, bool& va, float4& gb, bool& vb) __attribute__((always_inline)) {
+        if constexpr (PAIR) ld2(p, ga, va, gb, vb);
+        else ld(p, ga, va);
+    };
 
     if (wave < PW) {
         // ---------------- pose lanes, part 1: motion + sensor frame
@@ -599,7 +622,7 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             }
         }
         // the ray waves' first three tiles are pre-assigned (requested before barrier A): 1, 2 or 3 items per ray wave
-        if (tid == 0) next_env = (NW - PW) * (ntiles == 1 ? 3 : (ntiles == 2 ? 2 : 1));
+        if (tid == 0) next_env = (NW - PW) * (ntl == 1 ? 3 : (ntl == 2 ? 2 : 1));
     }
     if (wave >= PW) {
         // ---------------- other waves, part 1: nothing here depends on the pose
@@ -613,11 +636,11 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
         constexpr int RW = NW - PW;
         const int r = wave - PW;
         p0 = Pos{r, 0};
-        p1 = (ntiles >= 2) ? Pos{r, 1} : Pos{r + RW, 0};
-        p2 = (ntiles >= 3) ? Pos{r, 2} : ((ntiles == 2) ? Pos{r + RW, 0} : Pos{r + 2 * RW, 0});
-        ld(p0, g0, v0);
-        ld(p1, g1, v1);
-        ld(p2, g2, v2);
+        p1 = (ntl >= 2) ? Pos{r, 1} : Pos{r + RW, 0};
+        p2 = (ntl >= 3) ? Pos{r, 2} : ((ntl == 2) ? Pos{r + RW, 0} : Pos{r + 2 * RW, 0});
+        request(p0, g0, v0, g0b, v0b);
+        request(p1, g1, v1, g1b, v1b);
+        request(p2, g2, v2, g2b, v2b);
     }
     __syncthreads();  // barrier A: origins / directions visible, work counter set
 
@@ -634,7 +657,9 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     // draw of :245-253.  Records live in HBM; kRecValid in the env's ep_step word says they match its draw counter.
     // A spec lane of an env whose flag is clear (it was reset, or its goal stream moved) recomputes and stores them.
     const bool spec = spec_lane && (P.auto_reset || (spec_c == 1));
-    if (own || spec) {
+    // (wave < PW is implied; spelt out so that the ray waves' path to the cast holds no request the compiler would have to
+    // count: their three tile requests stay the youngest ones and the first cull waits for vmcnt(2), not vmcnt(0))
+    if ((wave < PW) && (own || spec)) {
         const int e = own ? lane : spec_e;
         const int ie = base + e;
         if (own) {
@@ -783,33 +808,53 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             }
         };
         // stage A: cull + compaction of one tile (64 lanes = 64 segments, or 64 / epp segments of epp envs)
-        auto cull = [&](const Pos p, const float4 g, const bool v) __attribute__((always_inline)) {
-            const int el = min(p.it * epp + sub, nloc - 1);
-            const float2 o = sm.org[el], h = sm.hd[el];
+        auto keep_of = [&](const float4 g, const float2 o, const float2 h) __attribute__((always_inline)) -> bool {
             // endpoints in the robot frame (X ahead, Y left); float32 throughout: this decides only what is tested exactly
             const float ax = g.x - o.x, ay = g.y - o.y, bx = g.z - o.x, by = g.w - o.y;
             const float xa = fmaf(ax, h.x, ay * h.y), ya = fmaf(ay, h.x, -(ax * h.y));
             const float xb = fmaf(bx, h.x, by * h.y), yb = fmaf(by, h.x, -(bx * h.y));
             // behind: both endpoints inside the convex cone X < -1e-3 |Y|; the beams span +-(pi/2 + 1.2e-6)
             const bool behind = (fmaf(1e-3f, fabsf(ya), xa) < 0.f) && (fmaf(1e-3f, fabsf(yb), xb) < 0.f);
-            // far: distance from the sensor to the segment above 3.5 m (threshold 12.3 = (3.5 * 1.002)^2)
+            // far: distance from the sensor to the segment above 3.5 m (threshold 12.3 = (3.5 * 1.002)^2).  The closest point
+            // is a + t e with t = clamp(-a.e / e.e, 0, 1); the error of the hardware reciprocal moves it by < 1e-7 |e|, far
+            // inside the 7 mm margin for any segment shorter than 10 km; a zero-length segment gives t = 0 (0 x inf = NaN
+            // takes v_med3's minimum).  So the test stays conservative.
             const float ex = xb - xa, ey = yb - ya;
-            const float e2 = fmaf(ex, ex, ey * ey), ae = fmaf(xa, ex, ya * ey), be = ae + e2;
-            const float a2 = fmaf(xa, xa, ya * ya), b2 = fmaf(xb, xb, yb * yb), kl = fmaf(xa, yb, -(xb * ya));
-            const bool far = (ae >= 0.f) ? (a2 > 12.3f) : ((be <= 0.f) ? (b2 > 12.3f) : (kl * kl > 12.3f * e2));
-            const bool near = fminf(a2, b2) < 1e-6f;   // an endpoint within 1 mm of the sensor: angles are noise, keep
-            const bool keep = v && (near || !(behind || far));
+            const float e2 = fmaf(ex, ex, ey * ey), ae = fmaf(xa, ex, ya * ey);
+            const float t = __builtin_amdgcn_fmed3f(-ae * __builtin_amdgcn_rcpf(e2), 0.f, 1.f);
+            const float cx = fmaf(t, ex, xa), cy = fmaf(t, ey, ya);
+            const float d2 = fmaf(cx, cx, cy * cy);
+            // d2 < 1e-6: the segment passes within 1 mm of the sensor, where the angles are noise: keep
+            return (d2 < 1e-6f) || !(behind || (d2 > 12.3f));
+        };
+        auto push = [&](const float4 g, const unsigned el, const bool keep) __attribute__((always_inline)) {
             const unsigned long long bal = __ballot(keep);
             if (bal) {
                 const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
                 if (keep) {
                     const int slot = (qtail + off) & 127;
                     q4[slot] = g;
-                    qe[slot] = (unsigned)el;
+                    qe[slot] = el;
                 }
                 qtail += __popcll(bal);
                 if (qtail - qhead >= 64) flushA2(64);
             }
+        };
+        auto cull = [&](const Pos p, const float4 g, const bool v) __attribute__((always_inline)) {
+            const int el = min(p.it * epp + sub, nloc - 1);
+            const float2 o = sm.org[el], h = sm.hd[el];
+            push(g, (unsigned)el, v && keep_of(g, o, h));
+        };
+        auto cull2 = [&](const Pos p, const float4 ga, const bool va, const float4 gb, const bool vb) __attribute__((always_inline)) {
+            const int el = min(p.it, nloc - 1);
+            const float2 o = sm.org[el], h = sm.hd[el];
+            const bool ka = va && keep_of(ga, o, h), kb = vb && keep_of(gb, o, h);
+            push(ga, (unsigned)el, ka);   // at most 63 + 64 queued before either flush: the ring holds 128
+            push(gb, (unsigned)el, kb);
+        };
+        auto consume = [&](const Pos p, const float4 ga, const bool va, const float4 gb, const bool vb) __attribute__((always_inline)) {
+            if constexpr (PAIR) cull2(p, ga, va, gb, vb);
+            else cull(p, ga, va);
         };
         // BOXES: bit t of item_live(env) = tile t can matter for this env's pose: lane = tile, the same conservative range /
         // behind-the-fan tests as stage A applied to the tile's bounding box (all four corners inside the behind cone)
@@ -843,33 +888,33 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
                 if (rest) return Pos{p.it, (int)__builtin_ctzll(rest)};
                 return next_item();
             }
-            if (p.t + 1 < ntiles) return Pos{p.it, p.t + 1};
+            if (p.t + 1 < ntl) return Pos{p.it, p.t + 1};
             return Pos{grab(), 0};
         };
         if (wave < PW) {   // pose waves join when part 2 is done
             p0 = BOXES ? next_item() : Pos{grab(), 0};
-            ld(p0, g0, v0);
+            request(p0, g0, v0, g0b, v0b);
             p1 = advance(p0);
-            ld(p1, g1, v1);
+            request(p1, g1, v1, g1b, v1b);
             p2 = advance(p1);
-            ld(p2, g2, v2);
+            request(p2, g2, v2, g2b, v2b);
         } else if (BOXES) {   // ray waves: the live tiles of the item their last pre-assigned tile belongs to
             cur_live = (p2.it < n_items) ? item_live(p2.it) : 0ull;
         }
         // three tiles in flight; the slots take turns (a register rotation would have to wait for the load it moves)
         for (;;) {   // wave-uniform
             if (p0.it >= n_items) break;
-            cull(p0, g0, v0);
+            consume(p0, g0, v0, g0b, v0b);
             p0 = advance(p2);
-            ld(p0, g0, v0);
+            request(p0, g0, v0, g0b, v0b);
             if (p1.it >= n_items) break;
-            cull(p1, g1, v1);
+            consume(p1, g1, v1, g1b, v1b);
             p1 = advance(p0);
-            ld(p1, g1, v1);
+            request(p1, g1, v1, g1b, v1b);
             if (p2.it >= n_items) break;
-            cull(p2, g2, v2);
+            consume(p2, g2, v2, g2b, v2b);
             p2 = advance(p1);
-            ld(p2, g2, v2);
+            request(p2, g2, v2, g2b, v2b);
         }
         // The tail.  Stage A2 only filters, so when everything that is left fits one stage-B pass it is skipped: the stage-A
         // survivors join the stage-B queue directly (one pass of 206 VALU instead of 75 + 206; a small map never needs A2).
@@ -1008,7 +1053,7 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     }
 }
 
-template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false>
+template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, bool PAIR = false>
 __global__ __launch_bounds__(64 * NW) void step_kernel(Params P, const float2* __restrict__ action,
                                                         const float2* __restrict__ past_override,
                                                         void* __restrict__ obs_out, float* __restrict__ reward,
@@ -1017,7 +1062,7 @@ __global__ __launch_bounds__(64 * NW) void step_kernel(Params P, const float2* _
                                                         int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out) {
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
-    step_body<NB, EPB, SENS, false, NW, BOXES>(P, sm, next_env, action, past_override, obs_out, reward, done, arrive, ended, ep_return,
+    step_body<NB, EPB, SENS, false, NW, BOXES, PAIR>(P, sm, next_env, action, past_override, obs_out, reward, done, arrive, ended, ep_return,
                                     ep_length, ep_path_out);
 }
 
@@ -1054,7 +1099,7 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
     __shared__ float2 pol_z[4][16];   // policy phase: per-tile partial sums of the two output units
     __shared__ float2 pol_eps[16];    // ... and the step's action noise
     static_assert(NW >= 5 && EPB <= 16, "policy phase: waves 0-3 MFMA, wave 4 noise; one 16-env policy tile per workgroup");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int base = blockIdx.x * EPB;
     const int nloc = min(EPB, P.N - base);
     const size_t N = (size_t)P.N;
@@ -1373,6 +1418,7 @@ struct navsim {
 };
 
 int g_epb = 0;   // envs per workgroup: 0 = by shard size (below); NAVSIM_EPB = 8 | 16 | 32 | 64 forces one (tuning knob)
+bool g_pair_cast = true;   // NAVSIM_PAIR_CAST=0: 64-segment passes for every map (tuning knob)
 
 // Envs per workgroup.  Bigger workgroups make the float64 lanes of the geometry / rules phases denser (a wave instruction
 // costs the same with 16 or 64 active lanes) and start fewer workgroups, but need N / EPB >= the number of CUs to fill the
@@ -1392,11 +1438,16 @@ static void launch_step(const navsim* h, const float* action, const float* past,
     };
     const int epb = pick_epb(h->P.N);
     const bool boxes = h->P.tile_box != nullptr;   // shared map with tile bounding boxes (navsim_set_map)
+    // maps of 65+ segments without tile boxes (per-env maps; shared maps beyond 4096 segments): 128 segments per pass
+    const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
 #define NAVSIM_GO(EPB_, NW_)                                                                         \
     do {                                                                                             \
         if (boxes) {                                                                                 \
             if (sens) go(step_kernel<NB, EPB_, true, NW_, true>, EPB_, NW_);                         \
             else go(step_kernel<NB, EPB_, false, NW_, true>, EPB_, NW_);                             \
+        } else if (pair) {                                                                           \
+            if (sens) go(step_kernel<NB, EPB_, true, NW_, false, true>, EPB_, NW_);                  \
+            else go(step_kernel<NB, EPB_, false, NW_, false, true>, EPB_, NW_);                      \
         } else {                                                                                     \
             if (sens) go(step_kernel<NB, EPB_, true, NW_, false>, EPB_, NW_);                        \
             else go(step_kernel<NB, EPB_, false, NW_, false>, EPB_, NW_);                            \
@@ -1543,6 +1594,7 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
         const int v = std::atoi(e);
         if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) g_epb = v;   // 4: the persistent rollout kernel only
     }
+    if (const char* e = std::getenv("NAVSIM_PAIR_CAST")) g_pair_cast = std::atoi(e) != 0;
     navsim* h = new navsim();
     const int rc = init_handle(h, cfg);
     if (rc != NAVSIM_OK) {
