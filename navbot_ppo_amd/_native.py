@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnavsim.so")
+# NAVSIM_LIB: another build of the same library (tools/build_variant.py A/B timing); never a different implementation
+LIB_PATH = os.environ.get("NAVSIM_LIB") or os.path.join(_HERE, "libnavsim.so")
 
 NAVSIM_ABI_VERSION = 3
 

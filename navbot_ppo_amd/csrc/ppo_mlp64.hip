@@ -107,7 +107,7 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
     static_assert(!(FWD && ACTOR), "forward-only pass is the critic's");
     constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
     constexpr int NT = kWThreads;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15, kk = lane >> 4;
 
     (void)grad_zero;
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(kSumThreads) void episode_sums_partial(const uint8_
     for (int j = 0; j < 6; ++j)
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) v[j] += __shfl_xor(v[j], m, 64);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (lane == 0)
 #pragma unroll
         for (int j = 0; j < 6; ++j) red[wave][j] = v[j];

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
                                                        float* __restrict__ pout) {
     __shared__ __attribute__((aligned(16))) FwdSmem<IN> sm;
     constexpr int S1 = IN + 4, S2 = HS + 4, NB = IN / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, q = lane >> 4;
     const WG wg = decode_block(blockIdx.x, n_nets, groups);
     const float* __restrict__ pn = params + ((net_base + wg.net_i) ? rp::P_ACTOR : 0);
     for (int k = tid; k < HS * IN; k += kThreads) sm.W1s[(k / IN) * S1 + (k % IN)] = pn[Blk<IN>::W1 + (wg.sl * HS + k / IN) * IN + (k % IN)];
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
     constexpr bool NEED_DX = IN == 32;
     constexpr bool PREFETCH = IN == 16;   // rb2 has no registers to spare for the next tile's rows
     constexpr int TILE_F = (2 * IN + (IN == 32 ? 32 : 0)) * LT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, q = lane >> 4;
     const WG wg = decode_block(blockIdx.x, n_nets, groups);
     const float* __restrict__ pn = params + (wg.net_i ? rp::P_ACTOR : 0);
     for (int k = tid; k < HS * IN; k += kThreads) sm.W1s[(k / IN) * S1 + (k % IN)] = pn[Blk<IN>::W1 + (wg.sl * HS + k / IN) * IN + (k % IN)];
@@ -542,7 +542,7 @@ template <int LPS, int NV>
 __device__ __forceinline__ void block_sum_to_row(float (&acc)[NV], float* red /* [kEThreads / 64][LPS][NV] */, float* __restrict__ row,
                                                  const int* cols /* NV column bases; value v of group og -> cols[v] + og * stride[v] */,
                                                  const int* strides, const bool* og0_only) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         float x = acc[v];
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_act(const float* __restrict__
                                                        float* __restrict__ mean_out) {
     __shared__ __attribute__((aligned(16))) float part1[kWaves][256];
     __shared__ __attribute__((aligned(16))) float part2[kWaves][2][256];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, q = lane >> 4;
     const long long e = (long long)blockIdx.x * kActEnvs + l15;
     const bool valid = e < n;
     const int j0 = 64 * w;

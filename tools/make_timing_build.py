@@ -19,7 +19,7 @@ rep("    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motio
 rep("    __syncthreads();  // barrier A:", "    STAMP(1);\n    __syncthreads();  STAMP(2); // barrier A:")
 rep("    __syncthreads();  // barrier B:", "    STAMP(3);\n    __syncthreads();  STAMP(4); // barrier B:")
 rep("    __syncthreads();  // barrier C:", "    STAMP(5);\n    __syncthreads();  STAMP(6); // barrier C:")
-idx = t.index("template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false>\n__global__ __launch_bounds__(64 * NW) void step_kernel(")
+idx = t.index("template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, bool PAIR = false>\n__global__ __launch_bounds__(64 * NW) void step_kernel(")
 j = t.rfind("}\n\n", 0, idx)
 t = t[:j] + "    STAMP(7);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk[blockIdx.x * 3 + 1] = wall_clock64();\n" + t[j:]
 rep("int navsim_version(void) { return NAVSIM_ABI_VERSION; }",
