@@ -306,7 +306,7 @@ struct StepSmem {
     float noise[NB * EPB];       // [beam][env] standard-normal draws for the range noise (only written when sigma > 0)
     double sc[EPB][8][2];        // pose phase: (cos, sin) of the 6 substep angles, of theta and of theta/2, one per lane
     // env state parked by the part-1 lanes for the part-2/3 lanes
-    double sv_d[13][EPB];        // x, y, th, gx, gy, past_dist, dist, yaw, rel_theta, diff, ep_ret, step displacement, ep_path
+    double sv_d[13][EPB];        // x, y, th, gx, gy, past_dist, dist, (7-9 unused), ep_ret, step displacement, ep_path
     float2 sv_act[EPB], sv_pact[EPB];
     uint32_t sv_ctr[EPB];
     uint32_t sv_step[EPB];       // raw ep_step word (kRecValid | step)
@@ -671,7 +671,17 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             if (__builtin_expect(!exact, 0)) yaw = yaw_from_quat(sin(pth / 2), cos(pth / 2));
             goal_rel(px, py, tgx, tgy, yaw, rel_theta, diff);
             dist = hypot(tgx - px, tgy - py);  // environment_new.py:203 ; getGoalDistace, :116-120
-            sm.sv_d[6][e] = dist; sm.sv_d[7][e] = yaw; sm.sv_d[8][e] = rel_theta; sm.sv_d[9][e] = diff;
+            sm.sv_d[6][e] = dist;
+            // the six non-lidar entries of the observation row depend on the pose only: written here, under the cast, instead
+            // of in part 3 (the float64 division and the three exact constant divisions were a fifth of its dependent chain)
+            float* row = sm.obs + e * DP;
+            const float2 pa = sm.sv_pact[e];
+            row[B + 0] = pa.x;                          // environment_new.py:299-300
+            row[B + 1] = pa.y;
+            row[B + 2] = (float)(dist / P.diag);        // :301
+            row[B + 3] = (float)div_const(yaw, 360.0, 1.0 / 360.0);        // yaw / 360, rel_theta / 360, diff_angle / 180:
+            row[B + 4] = (float)div_const(rel_theta, 360.0, 1.0 / 360.0);  // correctly rounded over these operands' domains
+            row[B + 5] = (float)div_const(diff, 180.0, 1.0 / 180.0);       // (integers, k/100), tools/verify
         } else {
             const int c = spec_c;
             const size_t N = (size_t)P.N;
@@ -956,20 +966,14 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
         const int e = lane;
         const int i = base + e;
         x = sm.sv_d[0][e]; y = sm.sv_d[1][e]; th = sm.sv_d[2][e]; gx = sm.sv_d[3][e]; gy = sm.sv_d[4][e];
-        pdist = sm.sv_d[5][e]; dist = sm.sv_d[6][e]; yaw = sm.sv_d[7][e]; rel_theta = sm.sv_d[8][e];
-        diff = sm.sv_d[9][e]; ret0 = sm.sv_d[10][e];
+        pdist = sm.sv_d[5][e]; dist = sm.sv_d[6][e]; ret0 = sm.sv_d[10][e];
         double path = sm.sv_d[12][e];
         act = sm.sv_act[e]; pact = sm.sv_pact[e]; ctr = sm.sv_ctr[e];
         const uint32_t step0 = sm.sv_step[e] & kStepMask;
         float* row = sm.obs + e * DP;
         const float* noise = (sigma > 0.f) ? sm.noise + e : nullptr;
         const float mn = (SENS && sm.neg[e]) ? -INFINITY : __uint_as_float(sm.mn_bits[e]);
-        row[B + 0] = pact.x;                        // environment_new.py:299-300
-        row[B + 1] = pact.y;
-        row[B + 2] = (float)(dist / P.diag);        // :301
-        row[B + 3] = (float)div_const(yaw, 360.0, 1.0 / 360.0);        // yaw / 360, rel_theta / 360, diff_angle / 180:
-        row[B + 4] = (float)div_const(rel_theta, 360.0, 1.0 / 360.0);  // correctly rounded over these operands' domains
-        row[B + 5] = (float)div_const(diff, 180.0, 1.0 / 180.0);       // (integers, k/100), tools/verify
+        // row[B .. B + 5] (past action, dist / diag, yaw / 360, rel_theta / 360, diff / 180) were written in part 2
         const bool d = (0.2 > (double)mn) && ((double)mn > 0);  // environment_new.py:200
         const bool a = dist <= P.thr;                             // :204
         // setReward, :209-222
