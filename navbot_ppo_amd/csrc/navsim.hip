@@ -94,7 +94,7 @@ struct Params {
     const float* spawn_scan;  // [K][B] or [N][K][B] nearest hits (+inf = none) at the K start poses (K = 1: the cfg spawn pose)
     const float* spawn_obs;   // same shape: the noise-free lidar entries of the reset observation (sanitised scan / 3.5)
     const double* starts;     // [K][3] start poses (x, y, yaw)
-    const double* starts_sc;  // [K][2] (cos, sin)(yaw / 2) of the start poses, evaluated on the device
+    const double* starts_sc;  // [K] the integer-degree yaw of Env.getOdometry at each start pose, evaluated on the device
     const double* goals;      // [G][2] goal points; G == 0: uniform goal box + rejection rectangles
     int K, G;
     double min_dist, max_dist;
@@ -239,11 +239,14 @@ __device__ __forceinline__ float lidar_noise(uint32_t k0, uint32_t k1, uint64_t 
 
 // No early exit: the loop bounds and addresses are then wave-uniform (scalar loads from the constant cache, all
 // rectangles in flight at once) instead of one dependent L2 round trip per rectangle per lane.
-__device__ __forceinline__ bool goal_rejected(const Rects* __restrict__ R, int which, double gx, double gy) {
-    const int n = R->n[which];
+// (`R` is the workgroup's LDS copy in the step kernel -- from global memory every rectangle of every attempt was a
+// dependent scalar-load round trip on the one wave the whole workgroup ends up waiting for, 0.8 us per attempt with the
+// eight rectangles of stage_2 -- and the table in global memory in the reset kernel.)
+__device__ __forceinline__ bool goal_rejected(const Rects& R, int which, double gx, double gy) {
+    const int n = R.n[which];
     bool rej = false;
     for (int k = 0; k < n; ++k) {
-        const double* q = R->r[which][k];
+        const double* q = R.r[which][k];
         rej |= (q[0] <= gx) & (gx <= q[1]) & (q[2] <= gy) & (gy <= q[3]);
     }
     return rej;
@@ -251,7 +254,7 @@ __device__ __forceinline__ bool goal_rejected(const Rects* __restrict__ R, int w
 
 // goal ~ U(lo,hi)^2 with rejection (environment_new.py:337-345 reset, :245-253 respawn);
 // one Philox call per attempt, counter = (env id, draws so far).
-__device__ __forceinline__ void sample_goal(const Params& P, int i, int which, uint32_t& ctr, double& gx, double& gy) {
+__device__ __forceinline__ void sample_goal(const Params& P, const Rects& R, int i, int which, uint32_t& ctr, double& gx, double& gy) {
     const uint64_t gid = P.env_id_base + (uint64_t)i;
     gx = 0;
     gy = 0;
@@ -263,7 +266,7 @@ __device__ __forceinline__ void sample_goal(const Params& P, int i, int which, u
         const double uy = (double)((((uint64_t)r[2] << 32) | r[3]) >> 11) * 0x1.0p-53;
         gx = P.goal_lo + (P.goal_hi - P.goal_lo) * ux;
         gy = P.goal_lo + (P.goal_hi - P.goal_lo) * uy;
-        if (!goal_rejected(P.rects, which, gx, gy)) break;
+        if (!goal_rejected(R, which, gx, gy)) break;
     }
 }
 
@@ -272,10 +275,10 @@ __device__ __forceinline__ void sample_goal(const Params& P, int i, int which, u
 //   G  > 0  GoalSpawnSampler.sample_start_and_goal (project_ppo/src/spawn_goal_sampler.py:52-62): uniform picks from the
 //           start-pose and goal tables until min_dist <= |start - goal| <= max_dist, at most 100 attempts, then one
 //           unconditional pick.  One Philox call per attempt.
-__device__ __forceinline__ void sample_episode(const Params& P, int i, uint32_t& ctr, int& k, double& gx, double& gy) {
+__device__ __forceinline__ void sample_episode(const Params& P, const Rects& R, int i, uint32_t& ctr, int& k, double& gx, double& gy) {
     if (P.G == 0) {
         k = 0;
-        sample_goal(P, i, 0, ctr, gx, gy);
+        sample_goal(P, R, i, 0, ctr, gx, gy);
         return;
     }
     const uint64_t gid = P.env_id_base + (uint64_t)i;
@@ -327,6 +330,7 @@ struct StepSmem {
     float4 r4[NW][128];          // ... and of those whose angular extent holds at least one beam
     unsigned re[NW][128];
     float4 tbox[64];             // Params::tile_box, staged once per launch (BOXES)
+    Rects rects;                 // Params::rects, staged by the ray waves before barrier A (the spec lanes' goal rejection test)
     float2 act_l[EPB];           // persistent rollout: the action the policy phase chose for this step
     // persistent rollout: the envs' state lives here between the steps (HBM sees it before the first and after the last)
     double st_d[8][EPB];         // x, y, th, gx, gy, past_dist, ep_ret, ep_path
@@ -490,6 +494,30 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     const bool spec_lane = (kSpecTwoWaves ? (wave == PW - 2 || wave == PW - 1) : (wave == kSpecWave && sl >= 0)) &&
                            (spec_c >= 0) && (spec_c < n_rec) && (spec_e < EPB) && (spec_e < nloc);
 
+    // The spec lanes request the cached records at kernel entry, whether they will turn out current or not: the first of
+    // the two dependent round trips of the record path then runs under the pose phase instead of after barrier A, where the
+    // spec wave is the last one into the cast.
+    const bool spec = spec_lane && (P.auto_reset || (spec_c == 1));
+    double pf_rgx = 0, pf_rgy = 0, pf_g0 = 0, pf_g1 = 0, pf_g2 = 0;
+    float4 pf_tl = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 pf_ck = make_uint2(0u, 0u);
+    uint32_t pf_rctr = 0;
+    auto prefetch_records = [&]() __attribute__((always_inline)) {
+        if (spec) {   // (the persistent rollout calls this after barrier A: measured slower there at the top of the step)
+            const int ie = base + spec_e, c = spec_c;
+            const size_t N = (size_t)P.N;
+            if (c == 1) {
+                pf_rgx = P.rsp_g[ie]; pf_rgy = P.rsp_g[N + ie]; pf_rctr = P.rsp_ctr[ie];
+            }
+            if (P.auto_reset) {
+                const double* rg = P.rec_g + (size_t)c * 3 * N + ie;
+                pf_g0 = rg[0]; pf_g1 = rg[N]; pf_g2 = rg[2 * N];
+                pf_tl = P.rec_tail[(size_t)c * N + ie];
+                pf_ck = P.rec_ck[(size_t)c * N + ie];
+            }
+        }
+    };
+
     // ---- cast geometry: lane -> (env of the pass, segment of the tile)
     const int spl = P.seg_pack_log2;            // log2(lanes per env in one pass): 6, smaller when the map has <= 32 segments
     const int epp = 64 >> spl;                  // envs per pass
@@ -533,6 +561,7 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     };
 
     if (wave < PW) {
+        if (!PERSIST) prefetch_records();
         // ---------------- pose lanes, part 1: motion + sensor frame
         if (pose_lane) {
             double delta_s = 0, delta_theta = 0, arg = 0, x_old = 0, y_old = 0;
@@ -632,6 +661,10 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             sm.neg[tid - 64 * PW] = 0u;
         }
         if (BOXES && tid - 64 * PW < ntiles) sm.tbox[tid - 64 * PW] = P.tile_box[tid - 64 * PW];
+        static_assert(sizeof(Rects) % 8 == 0, "Rects is copied in 8-byte words");
+        if (!PERSIST)   // (the persistent rollout stages the table once, before its first step)
+            for (int k = tid - 64 * PW; k < (int)(sizeof(Rects) / 8); k += kThreads - 64 * PW)
+                reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
         // static positions k = 0, 1, 2 of ray wave r: item r + RW (k / ntiles), tile k % ntiles
         constexpr int RW = NW - PW;
         const int r = wave - PW;
@@ -656,7 +689,6 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     // timeout (and by arrival when respawn_on_arrive is off), record 1 for an end by arrival after the arrival re-spawn
     // draw of :245-253.  Records live in HBM; kRecValid in the env's ep_step word says they match its draw counter.
     // A spec lane of an env whose flag is clear (it was reset, or its goal stream moved) recomputes and stores them.
-    const bool spec = spec_lane && (P.auto_reset || (spec_c == 1));
     // (wave < PW is implied; spelt out so that the ray waves' path to the cast holds no request the compiler would have to
     // count: their three tile requests stay the youngest ones and the first cull waits for vmcnt(2), not vmcnt(0))
     if ((wave < PW) && (own || spec)) {
@@ -689,29 +721,43 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             float4 tl = make_float4(0.f, 0.f, 0.f, 0.f);
             uint32_t sctr = sm.sv_ctr[e], rctr = sctr;
             int sk = 0;
-            if (sm.sv_step[e] & kRecValid) {
+            // the scan every reset at start pose k observes: rows of NB floats are 8-byte aligned (NB even), all NB / 2 requests
+            // go out before the first is awaited (one memory latency instead of NB / 2)
+            float2 row[NB / 2];
+            auto request_row = [&](const int k) __attribute__((always_inline)) {
+                const float2* sp = reinterpret_cast<const float2*>((SENS ? P.spawn_scan : P.spawn_obs) +
+                                                                   ((P.per_env ? (size_t)ie * P.K : 0) + k) * B);
+#pragma unroll
+                for (int b = 0; b < NB / 2; ++b) row[b] = sp[b];
+            };
+            const bool current = (sm.sv_step[e] & kRecValid) != 0;
+            if (PERSIST && current) prefetch_records();
+            if (current) {   // the records requested at kernel entry; their start pose and scan row are requested here, ahead of
+                             // the recomputation the other lanes of the wave may have to go through
                 if (c == 1) {
-                    rgx = P.rsp_g[ie]; rgy = P.rsp_g[N + ie]; rctr = P.rsp_ctr[ie];
+                    rgx = pf_rgx; rgy = pf_rgy; rctr = pf_rctr;
                 }
                 if (P.auto_reset) {
-                    const double* rg = P.rec_g + (size_t)c * 3 * N + ie;
-                    tgx = rg[0]; tgy = rg[N]; rdist = rg[2 * N];
-                    tl = P.rec_tail[(size_t)c * N + ie];
-                    const uint2 ck = P.rec_ck[(size_t)c * N + ie];
-                    sctr = ck.x; sk = (int)ck.y;
+                    tgx = pf_g0; tgy = pf_g1; rdist = pf_g2;
+                    tl = pf_tl;
+                    sctr = pf_ck.x; sk = (int)pf_ck.y;
                     px = P.starts[3 * sk]; py = P.starts[3 * sk + 1]; pth = P.starts[3 * sk + 2];
+                    request_row(sk);
                 }
-            } else {
+            }
+            if (!current) {
                 if (c == 1) {
-                    sample_goal(P, ie, 1, sctr, rgx, rgy);
+                    sample_goal(P, sm.rects, ie, 1, sctr, rgx, rgy);
                     rctr = sctr;
                     P.rsp_g[ie] = rgx; P.rsp_g[N + ie] = rgy; P.rsp_ctr[ie] = rctr;
                 }
                 if (P.auto_reset) {
-                    sample_episode(P, ie, sctr, sk, tgx, tgy);
+                    sample_episode(P, sm.rects, ie, sctr, sk, tgx, tgy);
+                    request_row(sk);
                     px = P.starts[3 * sk]; py = P.starts[3 * sk + 1]; pth = P.starts[3 * sk + 2];
                     double ryaw, rrel, rdiff;
-                    goal_angles_q(px, py, P.starts_sc[2 * sk + 1], P.starts_sc[2 * sk], tgx, tgy, ryaw, rrel, rdiff);
+                    ryaw = P.starts_sc[sk];   // = yaw_from_quat((sin, cos)(pth / 2)), tabulated by starts_sc_kernel
+                    goal_rel(px, py, tgx, tgy, ryaw, rrel, rdiff);
                     rdist = hypot(tgx - px, tgy - py);
                     tl = make_float4((float)(rdist / P.diag), (float)(ryaw / 360), (float)(rrel / 360), (float)(rdiff / 180));
                     double* rg = P.rec_g + (size_t)c * 3 * N + ie;
@@ -720,10 +766,12 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
                     P.rec_ck[(size_t)c * N + ie] = make_uint2(sctr, (uint32_t)sk);
                 }
             }
-            if (P.auto_reset) {   // the scan every reset at start pose sk observes
-                const float* sp = (SENS ? P.spawn_scan : P.spawn_obs) + ((P.per_env ? (size_t)ie * P.K : 0) + sk) * B;
-#pragma unroll 2
-                for (int b = 0; b < NB; ++b) sm.sp_scan[c][e][b] = sp[b];
+            if (P.auto_reset) {
+#pragma unroll
+                for (int b = 0; b < NB / 2; ++b) {
+                    sm.sp_scan[c][e][2 * b] = row[b].x;
+                    sm.sp_scan[c][e][2 * b + 1] = row[b].y;
+                }
             }
             sm.sp_d[c][0][e] = px; sm.sp_d[c][1][e] = py; sm.sp_d[c][2][e] = pth; sm.sp_d[c][3][e] = tgx;
             sm.sp_d[c][4][e] = tgy; sm.sp_d[c][5][e] = rdist;
@@ -1117,6 +1165,8 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
         sm.st_ctr[e] = P.rng_ctr[i];
     }
     for (int k = tid; k < nloc * D; k += kThreads) sm.obs[(k / D) * DP + (k % D)] = R.obs_buf[(size_t)base * D + k];
+    for (int k = tid; k < (int)(sizeof(Rects) / 8); k += kThreads)   // the goal rejection rectangles, for all T steps
+        reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
     const uint32_t step0 = R.step_base ? *R.step_base : 0u;
     const float var = *R.var_ptr;
     __syncthreads();
@@ -1166,14 +1216,14 @@ __global__ void invalidate_records_kernel(int32_t* __restrict__ ep_step, int N) 
     if (i < N) ep_step[i] = (int32_t)((uint32_t)ep_step[i] & kStepMask);
 }
 
-// (cos, sin)(yaw / 2) of the start poses: the orientation quaternion goal_angles() derives from a yaw, tabulated with
-// the device's own cos / sin so that the step kernel's speculative lanes reproduce goal_angles(x, y, yaw, ...) bit for bit
+// The yaw of Env.getOdometry (environment_new.py:142-147) at every start pose, tabulated with the device's own sin / cos /
+// atan2 through the same device function the reset kernel calls, so that the step kernel's speculative lanes reproduce
+// goal_angles(x, y, yaw, ...) bit for bit without the quaternion round trip (an atan2 off the record path)
 __global__ void starts_sc_kernel(const double* __restrict__ starts, int K, double* __restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const double th = starts[3 * k + 2];
-    out[2 * k] = cos(th / 2);
-    out[2 * k + 1] = sin(th / 2);
+    out[k] = yaw_from_quat(sin(th / 2), cos(th / 2));
 }
 
 // ---------------------------------------------------------------- reset (Env.reset, masked)
@@ -1185,7 +1235,7 @@ __global__ void reset_kernel(Params P, const uint8_t* __restrict__ mask, void* _
     uint32_t ctr = P.rng_ctr[i];
     double gx, gy, yaw, rel_theta, diff;
     int k0;
-    sample_episode(P, i, ctr, k0, gx, gy);
+    sample_episode(P, *P.rects, i, ctr, k0, gx, gy);
     const double x = P.starts[3 * k0], y = P.starts[3 * k0 + 1], th = P.starts[3 * k0 + 2];
     goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
     const double dist = hypot(gx - x, gy - y);
@@ -1415,7 +1465,7 @@ struct navsim {
     float* spawn_scan_dev = nullptr;
     float* spawn_obs_dev = nullptr;
     double* starts_dev = nullptr;   // [K][3]
-    double* starts_sc_dev = nullptr;  // [K][2]
+    double* starts_sc_dev = nullptr;  // [K]
     double* goals_dev = nullptr;    // [G][2]
     const float* seg_dev = nullptr;
     bool has_map = false;
@@ -1481,7 +1531,7 @@ static int upload_starts(navsim* h, const double* starts_host, int K, hipStream_
     (void)hipFree(h->starts_sc_dev);
     h->starts_dev = h->starts_sc_dev = nullptr;
     HIP_TRY(hipMalloc(&h->starts_dev, sizeof(double) * 3 * K));
-    HIP_TRY(hipMalloc(&h->starts_sc_dev, sizeof(double) * 2 * K));
+    HIP_TRY(hipMalloc(&h->starts_sc_dev, sizeof(double) * K));
     HIP_TRY(hipMemcpy(h->starts_dev, starts_host, sizeof(double) * 3 * K, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(starts_sc_kernel, dim3((K + 63) / 64), dim3(64), 0, st, h->starts_dev, K, h->starts_sc_dev);
     HIP_TRY(hipGetLastError());

@@ -44,10 +44,14 @@ sim = NavSim(N, max_episode_steps=500, auto_reset=True, seed=0)
 if CFG2:
     sim.set_map(maps.stage_1(), per_env=False)
 else:
+    if os.environ.get("TS_RECTS", "stage_2") != "none":   # configs[2] as bench.py runs it: stage_2's goal rejection rectangles
+        rr, rs = maps.goal_rects(os.environ.get("TS_RECTS", "stage_2"))
+        sim.set_goal_rects(0, rr); sim.set_goal_rects(1, rs)
     sim.set_map(maps.replicate_per_env(maps.stage_2(), N, seed=0), per_env=True)
 io = sim.alloc_io(); sim.reset(io.obs)
 acts = torch.rand((N, 2), device="cuda"); acts[:, 1] = acts[:, 1] * 2 - 1
-for k in range(20): sim.step(acts, io.obs, io.reward, io.done, io.arrive, io.ended)
+acts2 = torch.rand((N, 2), device="cuda"); acts2[:, 1] = acts2[:, 1] * 2 - 1
+for k in range(int(os.environ.get("PT_WARM", "20"))): sim.step(acts if k % 2 == 0 else acts2, io.obs, io.reward, io.done, io.arrive, io.ended)
 torch.cuda.synchronize()
 sim.step(acts, io.obs, io.reward, io.done, io.arrive, io.ended); torch.cuda.synchronize()
 buf = np.zeros(1024, dtype=np.int64)
