@@ -561,8 +561,17 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     };
 
     if (wave < PW) {
-        if (!PERSIST) prefetch_records();
         // ---------------- pose lanes, part 1: motion + sensor frame
+        // the beam table entries of lane rr (beams rr, rr + 8, ...) are requested with the state: requested where they are
+        // used, behind the sincos, their round trip sat on the chain to barrier A
+        constexpr int kBeamIt = (NB + 7) / 8;
+        double beam_c[kBeamIt], beam_s[kBeamIt];
+#pragma unroll
+        for (int q = 0; q < kBeamIt; ++q) {
+            const int b = min(rr + 8 * q, NB - 1);
+            beam_c[q] = P.beam_cs[b];
+            beam_s[q] = P.beam_cs[NB + b];
+        }
         if (pose_lane) {
             double delta_s = 0, delta_theta = 0, arg = 0, x_old = 0, y_old = 0;
             if (el_pose < nloc) {
@@ -611,6 +620,9 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
                 }
                 if (rr >= 6) arg = th;
             }
+            // (behind the wheel arithmetic: the wait for the state loads is over, the sincos covers this round trip; issued
+            // ahead of the state loads the requests delayed the spec wave, and with it barrier A, by 0.5 us)
+            if (!PERSIST) prefetch_records();
             {
                 double sn, cs;
                 sincos(arg, &sn, &cs);   // one shared argument reduction
@@ -642,11 +654,14 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             }
             {
                 const double cth = sm.sc[el_pose][6][0], sth = sm.sc[el_pose][6][1];
-                for (int b = rr; b < B; b += 8) {
-                    const double bc = P.beam_cs[b], bs = P.beam_cs[B + b];
-                    const double c = cth * bc - sth * bs;
-                    const double s = sth * bc + cth * bs;
-                    sm.dir[b * EPB + el_pose] = make_float2((float)c, (float)s);
+#pragma unroll
+                for (int q = 0; q < kBeamIt; ++q) {
+                    const int b = rr + 8 * q;
+                    if (b < B) {
+                        const double c = cth * beam_c[q] - sth * beam_s[q];
+                        const double s = sth * beam_c[q] + cth * beam_s[q];
+                        sm.dir[b * EPB + el_pose] = make_float2((float)c, (float)s);
+                    }
                 }
             }
         }

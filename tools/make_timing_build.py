@@ -13,9 +13,9 @@ rep("template <int NB, int EPB, int NW = 4>\nstruct StepSmem {",
     "__device__ long long g_dbg[128 * 8];\n__device__ long long g_blk[8192 * 3];\n"
     "#define STAMP(slot) do { if (blockIdx.x % 97 == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) g_dbg[((blockIdx.x / 97) % 8) * 128 + (threadIdx.x >> 6) * 8 + (slot)] = wall_clock64(); } while (0)\n"
     "template <int NB, int EPB, int NW = 4>\nstruct StepSmem {")
-rep("    if (wave < PW) {\n        if (!PERSIST) prefetch_records();\n        // ---------------- pose lanes, part 1: motion + sensor frame",
+rep("    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motion + sensor frame\n",
     "    STAMP(0);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) { g_blk[blockIdx.x * 3] = wall_clock64(); unsigned hw; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw)); unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc)); g_blk[blockIdx.x * 3 + 2] = ((long long)xcc << 32) | hw; }\n"
-    "    if (wave < PW) {\n        if (!PERSIST) prefetch_records();\n        // ---------------- pose lanes, part 1: motion + sensor frame")
+    "    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motion + sensor frame")
 rep("    __syncthreads();  // barrier A:", "    STAMP(1);\n    __syncthreads();  STAMP(2); // barrier A:")
 rep("    __syncthreads();  // barrier B:", "    STAMP(3);\n    __syncthreads();  STAMP(4); // barrier B:")
 rep("    __syncthreads();  // barrier C:", "    STAMP(5);\n    __syncthreads();  STAMP(6); // barrier C:")
