@@ -307,7 +307,6 @@ struct StepSmem {
     unsigned rng[NB * EPB];      // [beam][env] nearest hit as float bits (non-negative floats order like uints)
     float obs[EPB * (NB + 7)];   // [env][B+6 (+1 pad: odd row stride, conflict-free)] the block's output tile
     float noise[NB * EPB];       // [beam][env] standard-normal draws for the range noise (only written when sigma > 0)
-    double sc[EPB][8][2];        // pose phase: (cos, sin) of the 6 substep angles, of theta and of theta/2, one per lane
     // env state parked by the part-1 lanes for the part-2/3 lanes
     double sv_d[13][EPB];        // x, y, th, gx, gy, past_dist, dist, (7-9 unused), ep_ret, step displacement, ep_path
     float2 sv_act[EPB], sv_pact[EPB];
@@ -464,35 +463,40 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     const float sigma = SENS ? P.sigma : 0.f;
     const int below_min = SENS ? P.below_min_mode : 0;
 
-    // Pose lanes: 8 lanes per env (lane r of the group evaluates ONE of the 7 sincos the step needs: the six substep
-    // headings and the final heading), so the pose phase costs one sincos latency instead of seven.
-    // Lane r == 0 of each group owns the env's float64 state across the phases.  EPB envs -> EPB/8 waves (0, 1).
-    constexpr int PW = (EPB + 7) / 8;          // pose waves
-    static_assert(PW < NW, "pose waves + at least one ray wave");
+    // Pose lanes: TWO lanes per env.  The step needs the heading's (cos, sin) at the six substep arguments th_k + dth/2 and at the
+    // final heading; lane 0 of the pair evaluates sincos(final heading), lane 1 sincos(dth / 2), and the six substep values follow
+    // by rotating back from the final heading (angle addition, explicit fma: |error| ~ 1e-15, i.e. 1e-17 m on the pose).  The beam
+    // directions and the sensor origin -- everything the scan's bits depend on -- come from the library sincos of the final heading,
+    // exactly as in the oracle.  Rounds 1-3 spent 8 lanes per env (one library sincos per substep and lane): 8 pose waves per 64
+    // envs, i.e. four times the float64 instruction issue for the same chain length; at configs[2] the pose phase was a fifth of the
+    // launch's vector-unit time and its second wave per SIMD reached barrier A 0.5 us behind the first.
+    // Lane 0 of each pair owns the env's float64 state across the phases.
+    constexpr int LPE = 2;                              // pose lanes per env
+    constexpr int PWP = (LPE * EPB + 63) / 64;          // pose waves
     double x = 0, y = 0, th = 0, gx = 0, gy = 0, pdist = 0, dist = 0, yaw = 0, rel_theta = 0, diff = 0, ret0 = 0, path0 = 0;
     float2 act = make_float2(0.f, 0.f), pact = make_float2(0.f, 0.f);
     uint32_t ctr = 0, stepw = 0;
-    const int el_pose = 8 * wave + (lane >> 3);  // env (local) this pose lane works for
-    const int rr = lane & 7;
-    const bool pose_lane = (wave < PW) && (el_pose < EPB);
+    const int el_pose = (64 / LPE) * wave + (lane / LPE);  // env (local) this pose lane works for
+    const int rr = lane % LPE;
+    const bool pose_lane = (wave < PWP) && (el_pose < EPB);
     const int i = base + el_pose;
-    // Parts 2 and 3 run lane-dense instead (a wave instruction costs the same with 8 or 64 active lanes, and the float64
-    // geometry is ~1000 of them): the goal geometry and the rules of ALL the block's envs on lanes 0..EPB-1 of wave 0,
-    // the next-episode records on n_rec EPB lanes of the last pose wave (the same wave, behind the owners, when
-    // there is only one).  State crosses from the part-1 lanes through LDS (sv_*).
+    // Parts 2 and 3 run lane-dense (a wave instruction costs the same with 8 or 64 active lanes, and the float64 geometry is
+    // ~1000 of them): the goal geometry and the rules of ALL the block's envs on lanes 0..EPB-1 of wave 0 (the "owners"); the
+    // next-episode records on 2 EPB "spec" lanes -- behind the owners in wave 0 for the small shapes, else on the waves that
+    // follow the pose waves (they have nothing else to do before barrier A, so their record requests leave at kernel entry).
+    // State crosses from the part-1 lanes through LDS (sv_*).  PW = the "front" waves: pose + spec; the others are ray waves.
     const bool own = (wave == 0) && (lane < nloc);            // lane = env for the geometry / rules lanes
-    constexpr int kSpecWave = PW - 1;
-    constexpr int kSpecLane0 = (PW == 1) ? EPB : 0;
+    constexpr int kSpecWave0 = (EPB <= 8) ? 0 : PWP;
+    constexpr int kSpecLane0 = (EPB <= 8) ? EPB : 0;
+    constexpr int PW = (EPB <= 8) ? 1 : PWP + (2 * EPB + 63) / 64;
+    static_assert(PW < NW, "front waves + at least one ray wave");
+    static_assert(kSpecLane0 + ((EPB <= 8) ? 2 * EPB : 0) <= 64, "spec lanes of the small shapes fit wave 0");
     const int n_rec = P.respawn ? 2 : 1;
-    // spec lanes: record spec_c of env spec_e.  Both records of every env share the last pose wave when they fit (2 EPB lanes),
-    // else (EPB = 64) record c takes pose wave PW - 2 + c
-    constexpr bool kSpecTwoWaves = (kSpecLane0 + 2 * EPB > 64);
-    static_assert(!kSpecTwoWaves || PW >= 2, "two spec waves");
-    const int sl = lane - kSpecLane0;
-    const int spec_c = kSpecTwoWaves ? wave - (PW - 2) : sl / EPB;
-    const int spec_e = kSpecTwoWaves ? lane : sl % EPB;
-    const bool spec_lane = (kSpecTwoWaves ? (wave == PW - 2 || wave == PW - 1) : (wave == kSpecWave && sl >= 0)) &&
-                           (spec_c >= 0) && (spec_c < n_rec) && (spec_e < EPB) && (spec_e < nloc);
+    // spec lanes: record spec_c of env spec_e
+    const int sl = (wave - kSpecWave0) * 64 + lane - kSpecLane0;
+    const int spec_c = sl / EPB;
+    const int spec_e = sl % EPB;
+    const bool spec_lane = (wave >= kSpecWave0) && (wave < PW) && (sl >= 0) && (spec_c < n_rec) && (spec_e < nloc);
 
     // The spec lanes request the cached records at kernel entry, whether they will turn out current or not: the first of
     // the two dependent round trips of the record path then runs under the pose phase instead of after barrier A, where the
@@ -500,7 +504,8 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     const bool spec = spec_lane && (P.auto_reset || (spec_c == 1));
     double pf_rgx = 0, pf_rgy = 0, pf_g0 = 0, pf_g1 = 0, pf_g2 = 0;
     float4 pf_tl = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint2 pf_ck = make_uint2(0u, 0u);
+    unsigned long long pf_ck = 0ull;   // (counter, start-pose index) kept as ONE 64-bit value until it is used: a uint2 was split
+                                       // right behind the load, which made the wave wait for the whole round trip there
     uint32_t pf_rctr = 0;
     auto prefetch_records = [&]() __attribute__((always_inline)) {
         if (spec) {   // (the persistent rollout calls this after barrier A: measured slower there at the top of the step)
@@ -513,7 +518,7 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
                 const double* rg = P.rec_g + (size_t)c * 3 * N + ie;
                 pf_g0 = rg[0]; pf_g1 = rg[N]; pf_g2 = rg[2 * N];
                 pf_tl = P.rec_tail[(size_t)c * N + ie];
-                pf_ck = P.rec_ck[(size_t)c * N + ie];
+                pf_ck = reinterpret_cast<const unsigned long long*>(P.rec_ck)[(size_t)c * N + ie];
             }
         }
     };
@@ -562,82 +567,96 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
 
     if (wave < PW) {
         // ---------------- pose lanes, part 1: motion + sensor frame
-        // the beam table entries of lane rr (beams rr, rr + 8, ...) are requested with the state: requested where they are
+        // spec lanes on a wave of their own: the cached records are requested at kernel entry
+        if constexpr (EPB > 8) { if (!PERSIST) prefetch_records(); }
+        // the beam table entries of lane rr (beams rr, rr + 2, ...) are requested with the state: requested where they are
         // used, behind the sincos, their round trip sat on the chain to barrier A
-        constexpr int kBeamIt = (NB + 7) / 8;
+        constexpr int kBeamIt = (NB + LPE - 1) / LPE;
         double beam_c[kBeamIt], beam_s[kBeamIt];
+        if (wave < PWP) {
 #pragma unroll
-        for (int q = 0; q < kBeamIt; ++q) {
-            const int b = min(rr + 8 * q, NB - 1);
-            beam_c[q] = P.beam_cs[b];
-            beam_s[q] = P.beam_cs[NB + b];
+            for (int q = 0; q < kBeamIt; ++q) {
+                const int b = min(rr + LPE * q, NB - 1);
+                beam_c[q] = P.beam_cs[b];
+                beam_s[q] = P.beam_cs[NB + b];
+            }
         }
+        double delta_s = 0, delta_theta = 0, arg = 0, x_old = 0, y_old = 0;
+        if (pose_lane && el_pose < nloc) {
+            if (PERSIST) {
+                const int e = el_pose;
+                th = sm.st_d[2][e];
+                act = sm.act_l[e];
+                ctr = sm.st_ctr[e];
+                stepw = sm.st_step[e];
+                if (rr == 0) {
+                    x = sm.st_d[0][e]; y = sm.st_d[1][e];
+                    gx = sm.st_d[3][e]; gy = sm.st_d[4][e]; pdist = sm.st_d[5][e];
+                    pact = sm.st_pact[e];
+                    ret0 = sm.st_d[6][e];
+                    path0 = sm.st_d[7][e];
+                }
+            } else {
+                th = P.th[i];
+                act = action[i];
+                ctr = P.rng_ctr[i];
+                stepw = (uint32_t)P.ep_step[i];
+                if (rr == 0) {
+                    x = P.x[i]; y = P.y[i];
+                    gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
+                    pact = past_override ? past_override[i] : P.past_action[i];
+                    ret0 = P.ep_ret[i];
+                    path0 = P.ep_path[i];
+                }
+            }
+            x_old = x; y_old = y;
+            // environment_new.py:273-278
+            const double v = (double)act.x / 4;
+            const double w = (double)act.y;
+            // turtlebot3_fake.cpp:117-118, :133-146, :154-155
+            const double vl = v - (w * kWheelSep / 2);
+            const double vr = v + (w * kWheelSep / 2);
+            const double dt = 1.0 / 30.0;
+            const double wl = vl / kWheelRadius, wr = vr / kWheelRadius;
+            const double wheel_l = wl * dt, wheel_r = wr * dt;
+            delta_s = kWheelRadius * (wheel_r + wheel_l) / 2.0;
+            delta_theta = kWheelRadius * (wheel_r - wheel_l) / kWheelSep;
+            // the heading after the step is th0 + kSubsteps additions of delta_theta (same roundings as the serial loop, :160)
+            for (int k = 0; k < kSubsteps; ++k) th += delta_theta;
+            arg = (rr == 0) ? th : (delta_theta / 2.0);
+        }
+        // spec lanes that share wave 0 with the pose lanes (small shapes): behind the wheel arithmetic -- the wait for the state
+        // loads is over, the sincos covers this round trip
+        if constexpr (EPB <= 8) { if (!PERSIST) prefetch_records(); }
         if (pose_lane) {
-            double delta_s = 0, delta_theta = 0, arg = 0, x_old = 0, y_old = 0;
-            if (el_pose < nloc) {
-                if (PERSIST) {
-                    const int e = el_pose;
-                    th = sm.st_d[2][e];
-                    act = sm.act_l[e];
-                    ctr = sm.st_ctr[e];
-                    stepw = sm.st_step[e];
-                    if (rr == 0) {
-                        x = sm.st_d[0][e]; y = sm.st_d[1][e];
-                        gx = sm.st_d[3][e]; gy = sm.st_d[4][e]; pdist = sm.st_d[5][e];
-                        pact = sm.st_pact[e];
-                        ret0 = sm.st_d[6][e];
-                        path0 = sm.st_d[7][e];
-                    }
-                } else {
-                    th = P.th[i];
-                    act = action[i];
-                    ctr = P.rng_ctr[i];
-                    stepw = (uint32_t)P.ep_step[i];
-                    if (rr == 0) {
-                        x = P.x[i]; y = P.y[i];
-                        gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
-                        pact = past_override ? past_override[i] : P.past_action[i];
-                        ret0 = P.ep_ret[i];
-                        path0 = P.ep_path[i];
-                    }
-                }
-                x_old = x; y_old = y;
-                // environment_new.py:273-278
-                const double v = (double)act.x / 4;
-                const double w = (double)act.y;
-                // turtlebot3_fake.cpp:117-118, :133-146, :154-155
-                const double vl = v - (w * kWheelSep / 2);
-                const double vr = v + (w * kWheelSep / 2);
-                const double dt = 1.0 / 30.0;
-                const double wl = vl / kWheelRadius, wr = vr / kWheelRadius;
-                const double wheel_l = wl * dt, wheel_r = wr * dt;
-                delta_s = kWheelRadius * (wheel_r + wheel_l) / 2.0;
-                delta_theta = kWheelRadius * (wheel_r - wheel_l) / kWheelSep;
-                // heading before substep k is th0 + k additions of delta_theta (same roundings as the serial loop)
-                for (int k = 0; k < kSubsteps; ++k) {
-                    if (k == rr) arg = th + (delta_theta / 2.0);  // :158-159 argument of substep rr
-                    th += delta_theta;                             // :160
-                }
-                if (rr >= 6) arg = th;
-            }
-            // (behind the wheel arithmetic: the wait for the state loads is over, the sincos covers this round trip; issued
-            // ahead of the state loads the requests delayed the spec wave, and with it barrier A, by 0.5 us)
-            if (!PERSIST) prefetch_records();
-            {
-                double sn, cs;
-                sincos(arg, &sn, &cs);   // one shared argument reduction
-                sm.sc[el_pose][rr][0] = cs;
-                sm.sc[el_pose][rr][1] = sn;
-            }
-            // same wave wrote what this lane reads next: LDS ops of a wave complete in order, no barrier needed
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            double sn, cs;
+            sincos(arg, &sn, &cs);
+            // the partner lane's pair through DPP (quad_perm [1, 0, 3, 2]): no LDS round trip on the chain to barrier A
+            auto swap1 = [](const double vv) __attribute__((always_inline)) {
+                const int lo = __builtin_amdgcn_mov_dpp(__double2loint(vv), 0xB1, 0xF, 0xF, true);
+                const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(vv), 0xB1, 0xF, 0xF, true);
+                return __hiloint2double(hi, lo);
+            };
+            const double pcs = swap1(cs), psn = swap1(sn);
+            const double cth = (rr == 0) ? cs : pcs, sth = (rr == 0) ? sn : psn;   // final heading
+            const double ch = (rr == 0) ? pcs : cs, sh = (rr == 0) ? psn : sn;     // half a substep's turn
             if (rr == 0) {
-                for (int k = 0; k < kSubsteps; ++k) {  // :158-159
-                    x += delta_s * sm.sc[el_pose][k][0];
-                    y += delta_s * sm.sc[el_pose][k][1];
+                // substep k integrates along th_k + dth / 2 = final heading - (kSubsteps - 1/2 - k) dth  (:158-159): rotate back
+                // by dth / 2 once, then by dth (double angle) per substep
+                const double cd = fma(ch, ch, -(sh * sh)), sd = 2.0 * (sh * ch);
+                double ck[kSubsteps], sk[kSubsteps];
+                ck[kSubsteps - 1] = fma(cth, ch, sth * sh);
+                sk[kSubsteps - 1] = fma(sth, ch, -(cth * sh));
+#pragma unroll
+                for (int k = kSubsteps - 2; k >= 0; --k) {
+                    ck[k] = fma(ck[k + 1], cd, sk[k + 1] * sd);
+                    sk[k] = fma(sk[k + 1], cd, -(ck[k + 1] * sd));
                 }
-                const double cth = sm.sc[el_pose][6][0], sth = sm.sc[el_pose][6][1];
+#pragma unroll
+                for (int k = 0; k < kSubsteps; ++k) {  // :158-159, in the serial loop's order
+                    x += delta_s * ck[k];
+                    y += delta_s * sk[k];
+                }
                 const double ox = x + kLidarX * cth;
                 const double oy = y + kLidarX * sth;
                 sm.org[el_pose] = make_float2((float)ox, (float)oy);
@@ -652,16 +671,13 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
                     sm.sv_act[e] = act; sm.sv_pact[e] = pact; sm.sv_ctr[e] = ctr; sm.sv_step[e] = stepw;
                 }
             }
-            {
-                const double cth = sm.sc[el_pose][6][0], sth = sm.sc[el_pose][6][1];
 #pragma unroll
-                for (int q = 0; q < kBeamIt; ++q) {
-                    const int b = rr + 8 * q;
-                    if (b < B) {
-                        const double c = cth * beam_c[q] - sth * beam_s[q];
-                        const double s = sth * beam_c[q] + cth * beam_s[q];
-                        sm.dir[b * EPB + el_pose] = make_float2((float)c, (float)s);
-                    }
+            for (int q = 0; q < kBeamIt; ++q) {
+                const int b = rr + LPE * q;
+                if (b < B) {
+                    const double c = cth * beam_c[q] - sth * beam_s[q];
+                    const double s = sth * beam_c[q] + cth * beam_s[q];
+                    sm.dir[b * EPB + el_pose] = make_float2((float)c, (float)s);
                 }
             }
         }
@@ -693,8 +709,8 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     __syncthreads();  // barrier A: origins / directions visible, work counter set
 
     if (sigma > 0.f && pose_lane && el_pose < nloc) {
-        // range noise for this step: lane rr draws beams rr, rr + 8, ... (off the critical path: the others ray-cast)
-        for (int b = rr; b < B; b += 8)
+        // range noise for this step: lane rr draws beams rr, rr + 2, ... (off the critical path: the others ray-cast)
+        for (int b = rr; b < B; b += LPE)
             sm.noise[b * EPB + el_pose] = lidar_noise(P.key0, P.key1, P.env_id_base + (uint64_t)i, ctr, stepw & kStepMask, b);
     }
     // ---------------- part 2 (the other waves are already ray-casting): goal geometry.
@@ -755,7 +771,7 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
                 if (P.auto_reset) {
                     tgx = pf_g0; tgy = pf_g1; rdist = pf_g2;
                     tl = pf_tl;
-                    sctr = pf_ck.x; sk = (int)pf_ck.y;
+                    sctr = (uint32_t)pf_ck; sk = (int)(uint32_t)(pf_ck >> 32);
                     px = P.starts[3 * sk]; py = P.starts[3 * sk + 1]; pth = P.starts[3 * sk + 2];
                     request_row(sk);
                 }
