@@ -29,6 +29,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -72,23 +73,30 @@ struct Rects {
 };
 
 struct Params {
-    int N, B, S, per_env, max_ep_steps, auto_reset, respawn, obs_f16, below_min_mode;
+    // The first 128 bytes hold what the first memory requests of a step launch need (the pose waves' state loads, the ray waves'
+    // first segment tiles): they arrive with the first round of scalar kernarg loads.  In declaration order the compiler reached
+    // the state pointers in its fourth dependent round, ~1 us into the launch.
+    int N, S, per_env;
+    int seg_pack_log2;        // cast: log2(lanes per env in one 64-lane pass) = 6, or log2(pow2ceil(S)) when S <= 32
+    const float4* seg;        // [S] or [N][S]
+    double *th, *x, *y, *gx, *gy, *past_dist, *ep_ret, *ep_path;
+    float2* past_action;
+    int32_t* ep_step;         // low 30 bits: steps taken in the episode; kRecValid: the records below are current
+    uint32_t* rng_ctr;
+    const double* beam_cs;    // [2][B]: cos(phi_b), sin(phi_b)
+    int B, respawn;
+    // ---- 128 bytes
+    int max_ep_steps, auto_reset, obs_f16, below_min_mode;
     float sigma;  // LiDAR range noise (0 = off)
     uint32_t key0, key1;
     uint64_t env_id_base;
     double thr, spawn_x, spawn_y, spawn_yaw, goal_lo, goal_hi, diag;
-    double *x, *y, *th, *gx, *gy, *past_dist, *ep_ret, *ep_path;
-    float2* past_action;
-    int32_t* ep_step;         // low 30 bits: steps taken in the episode; kRecValid: the records below are current
-    uint32_t* rng_ctr;
     // next-episode records, written by the step kernel when an env's goal stream has moved, read otherwise:
     double* rec_g;            // [2][3][N] goal x, y and start-to-goal distance
     float4* rec_tail;         // [2][N] the reset observation's (dist/diag, yaw/360, rel_theta/360, diff/180)
     uint2* rec_ck;            // [2][N] (draw counter after the reset, start-pose index)
     double* rsp_g;            // [2][N] the arrival re-spawn goal (respawn_on_arrive)
     uint32_t* rsp_ctr;        // [N] draw counter after the re-spawn draw
-    int seg_pack_log2;        // cast: log2(lanes per env in one 64-lane pass) = 6, or log2(pow2ceil(S)) when S <= 32
-    const float4* seg;        // [S] or [N][S]
     const float4* tile_box;   // shared maps of 65..4096 segments (kept in Morton order by navsim_set_map): per 64-segment tile
                               // the bounding box (xmin, ymin, xmax, ymax) of its segments; else null
     const float* spawn_scan;  // [K][B] or [N][K][B] nearest hits (+inf = none) at the K start poses (K = 1: the cfg spawn pose)
@@ -98,9 +106,9 @@ struct Params {
     const double* goals;      // [G][2] goal points; G == 0: uniform goal box + rejection rectangles
     int K, G;
     double min_dist, max_dist;
-    const double* beam_cs;    // [2][B]: cos(phi_b), sin(phi_b)
     const Rects* rects;
 };
+static_assert(offsetof(Params, max_ep_steps) == 128, "the hot head of Params");
 
 // ---------------------------------------------------------------- device helpers
 
@@ -254,7 +262,8 @@ __device__ __forceinline__ bool goal_rejected(const Rects& R, int which, double 
 
 // goal ~ U(lo,hi)^2 with rejection (environment_new.py:337-345 reset, :245-253 respawn);
 // one Philox call per attempt, counter = (env id, draws so far).
-__device__ __forceinline__ void sample_goal(const Params& P, const Rects& R, int i, int which, uint32_t& ctr, double& gx, double& gy) {
+template <class PRef>
+__device__ __forceinline__ void sample_goal(PRef P, const Rects& R, int i, int which, uint32_t& ctr, double& gx, double& gy) {
     const uint64_t gid = P.env_id_base + (uint64_t)i;
     gx = 0;
     gy = 0;
@@ -275,10 +284,11 @@ __device__ __forceinline__ void sample_goal(const Params& P, const Rects& R, int
 //   G  > 0  GoalSpawnSampler.sample_start_and_goal (project_ppo/src/spawn_goal_sampler.py:52-62): uniform picks from the
 //           start-pose and goal tables until min_dist <= |start - goal| <= max_dist, at most 100 attempts, then one
 //           unconditional pick.  One Philox call per attempt.
-__device__ __forceinline__ void sample_episode(const Params& P, const Rects& R, int i, uint32_t& ctr, int& k, double& gx, double& gy) {
+template <class PRef>
+__device__ __forceinline__ void sample_episode(PRef P, const Rects& R, int i, uint32_t& ctr, int& k, double& gx, double& gy) {
     if (P.G == 0) {
         k = 0;
-        sample_goal(P, R, i, 0, ctr, gx, gy);
+        sample_goal<PRef>(P, R, i, 0, ctr, gx, gy);
         return;
     }
     const uint64_t gid = P.env_id_base + (uint64_t)i;
@@ -435,14 +445,23 @@ __device__ __forceinline__ float write_lidar(float* row, const float* best, int 
 // NW: waves per workgroup (4; the persistent rollout kernel, one workgroup per CU, runs 8 for a shorter cast).
 // BOXES: shared map with tile bounding boxes (Params::tile_box): whole 64-segment tiles that lie behind the beam fan or out of
 // range are skipped without being loaded (the house map: 32 tiles, ~5 of them near any one pose).
-template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4, bool BOXES = false, bool PAIR = false>
-__device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>& sm, int& next_env,
-                                          const float2* __restrict__ action, const float2* __restrict__ past_override,
-                                          void* __restrict__ obs_out, float* __restrict__ reward,
-                                          uint8_t* __restrict__ done, uint8_t* __restrict__ arrive,
-                                          uint8_t* __restrict__ ended, float* __restrict__ ep_return,
-                                          int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out,
-                                          const bool last_step = true) {
+// PRef / IORef: how the parameter block and the I/O pointers are reached.  The persistent rollout passes plain references to its
+// own copies.  step_kernel passes references into the kernarg segment (constant address space) behind a compiler barrier: every
+// field is then a scalar load AT ITS USE.  As ordinary by-value kernel parameters all ~100 dwords were loaded and spilled to
+// VGPR lanes in the entry block (not enough SGPRs), in five dependent rounds, before the first state load could leave: 1.1 us.
+struct StepIO {
+    const float2* action;
+    const float2* past_override;
+    void* obs_out;
+    float* reward;
+    uint8_t *done, *arrive, *ended;
+    float* ep_return;
+    int32_t* ep_length;
+    float* ep_path_out;
+};
+template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4, bool BOXES = false, bool PAIR = false, class PRef = const Params&,
+          class IORef = const StepIO&>
+__device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int& next_env, IORef io, const bool last_step = true) {
     static_assert(EPB <= 64 && EPB >= 4 && NB % 2 == 0, "EPB / NB");
     static_assert(!(PAIR && BOXES), "tile boxes describe 64-segment tiles");
     constexpr int kThreads = 64 * NW;
@@ -458,11 +477,6 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     constexpr int DP = D + 1;   // padded LDS row stride
     const int nloc = min(EPB, P.N - base);  // envs in this block
     const unsigned kInfBits = 0x7f800000u;
-    // sensor-fidelity options (range noise, -inf below range_min) are compiled out of the default instantiation:
-    // carrying them as run-time branches cost 1.2 us per launch (28.2 -> 27.0 us, configs[2])
-    const float sigma = SENS ? P.sigma : 0.f;
-    const int below_min = SENS ? P.below_min_mode : 0;
-
     // Pose lanes: TWO lanes per env.  The step needs the heading's (cos, sin) at the six substep arguments th_k + dth/2 and at the
     // final heading; lane 0 of the pair evaluates sincos(final heading), lane 1 sincos(dth / 2), and the six substep values follow
     // by rotating back from the final heading (angle addition, explicit fma: |error| ~ 1e-15, i.e. 1e-17 m on the pose).  The beam
@@ -480,49 +494,11 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     const int rr = lane % LPE;
     const bool pose_lane = (wave < PWP) && (el_pose < EPB);
     const int i = base + el_pose;
-    // Parts 2 and 3 run lane-dense (a wave instruction costs the same with 8 or 64 active lanes, and the float64 geometry is
-    // ~1000 of them): the goal geometry and the rules of ALL the block's envs on lanes 0..EPB-1 of wave 0 (the "owners"); the
-    // next-episode records on 2 EPB "spec" lanes -- behind the owners in wave 0 for the small shapes, else on the waves that
-    // follow the pose waves (they have nothing else to do before barrier A, so their record requests leave at kernel entry).
-    // State crosses from the part-1 lanes through LDS (sv_*).  PW = the "front" waves: pose + spec; the others are ray waves.
-    const bool own = (wave == 0) && (lane < nloc);            // lane = env for the geometry / rules lanes
     constexpr int kSpecWave0 = (EPB <= 8) ? 0 : PWP;
     constexpr int kSpecLane0 = (EPB <= 8) ? EPB : 0;
-    constexpr int PW = (EPB <= 8) ? 1 : PWP + (2 * EPB + 63) / 64;
+    constexpr int PW = (EPB <= 8) ? 1 : PWP + (2 * EPB + 63) / 64;   // "front" waves: pose + spec; the others are ray waves
     static_assert(PW < NW, "front waves + at least one ray wave");
     static_assert(kSpecLane0 + ((EPB <= 8) ? 2 * EPB : 0) <= 64, "spec lanes of the small shapes fit wave 0");
-    const int n_rec = P.respawn ? 2 : 1;
-    // spec lanes: record spec_c of env spec_e
-    const int sl = (wave - kSpecWave0) * 64 + lane - kSpecLane0;
-    const int spec_c = sl / EPB;
-    const int spec_e = sl % EPB;
-    const bool spec_lane = (wave >= kSpecWave0) && (wave < PW) && (sl >= 0) && (spec_c < n_rec) && (spec_e < nloc);
-
-    // The spec lanes request the cached records at kernel entry, whether they will turn out current or not: the first of
-    // the two dependent round trips of the record path then runs under the pose phase instead of after barrier A, where the
-    // spec wave is the last one into the cast.
-    const bool spec = spec_lane && (P.auto_reset || (spec_c == 1));
-    double pf_rgx = 0, pf_rgy = 0, pf_g0 = 0, pf_g1 = 0, pf_g2 = 0;
-    float4 pf_tl = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned long long pf_ck = 0ull;   // (counter, start-pose index) kept as ONE 64-bit value until it is used: a uint2 was split
-                                       // right behind the load, which made the wave wait for the whole round trip there
-    uint32_t pf_rctr = 0;
-    auto prefetch_records = [&]() __attribute__((always_inline)) {
-        if (spec) {   // (the persistent rollout calls this after barrier A: measured slower there at the top of the step)
-            const int ie = base + spec_e, c = spec_c;
-            const size_t N = (size_t)P.N;
-            if (c == 1) {
-                pf_rgx = P.rsp_g[ie]; pf_rgy = P.rsp_g[N + ie]; pf_rctr = P.rsp_ctr[ie];
-            }
-            if (P.auto_reset) {
-                const double* rg = P.rec_g + (size_t)c * 3 * N + ie;
-                pf_g0 = rg[0]; pf_g1 = rg[N]; pf_g2 = rg[2 * N];
-                pf_tl = P.rec_tail[(size_t)c * N + ie];
-                pf_ck = reinterpret_cast<const unsigned long long*>(P.rec_ck)[(size_t)c * N + ie];
-            }
-        }
-    };
-
     // ---- cast geometry: lane -> (env of the pass, segment of the tile)
     const int spl = P.seg_pack_log2;            // log2(lanes per env in one pass): 6, smaller when the map has <= 32 segments
     const int epp = 64 >> spl;                  // envs per pass
@@ -565,22 +541,93 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
         else ld(p, ga, va);
     };
 
+    // ---------------- the first memory requests of the launch, ahead of everything else: what they need sits in the first 128
+    // bytes of Params, i.e. in the first round of scalar kernarg loads (the rest of the set-up below costs three more rounds)
+    if (wave >= PW) {
+        // ray waves: static positions k = 0, 1, 2 of ray wave r: item r + RW (k / ntiles), tile k % ntiles
+        constexpr int RW = NW - PW;
+        const int r = wave - PW;
+        p0 = Pos{r, 0};
+        p1 = (ntl >= 2) ? Pos{r, 1} : Pos{r + RW, 0};
+        p2 = (ntl >= 3) ? Pos{r, 2} : ((ntl == 2) ? Pos{r + RW, 0} : Pos{r + 2 * RW, 0});
+        request(p0, g0, v0, g0b, v0b);
+        request(p1, g1, v1, g1b, v1b);
+        request(p2, g2, v2, g2b, v2b);
+    }
+    // pose waves: the beam table entries of lane rr (beams rr, rr + 2, ...) are requested with the state: requested where they
+    // are used, behind the sincos, their round trip sat on the chain to barrier A
+    constexpr int kBeamIt = (NB + LPE - 1) / LPE;
+    double beam_c[kBeamIt], beam_s[kBeamIt];
+    if (wave < PWP) {
+        if (!PERSIST && pose_lane && el_pose < nloc) {
+            th = P.th[i];
+            act = io.action[i];
+            ctr = P.rng_ctr[i];
+            stepw = (uint32_t)P.ep_step[i];
+            if (rr == 0) {
+                x = P.x[i]; y = P.y[i];
+                gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
+                pact = io.past_override ? io.past_override[i] : P.past_action[i];
+                ret0 = P.ep_ret[i];
+                path0 = P.ep_path[i];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kBeamIt; ++q) {
+            const int b = min(rr + LPE * q, NB - 1);
+            beam_c[q] = P.beam_cs[b];
+            beam_s[q] = P.beam_cs[NB + b];
+        }
+    }
+
+    // sensor-fidelity options (range noise, -inf below range_min) are compiled out of the default instantiation:
+    // carrying them as run-time branches cost 1.2 us per launch (28.2 -> 27.0 us, configs[2])
+    const float sigma = SENS ? P.sigma : 0.f;
+    const int below_min = SENS ? P.below_min_mode : 0;
+
+
+    // Parts 2 and 3 run lane-dense (a wave instruction costs the same with 8 or 64 active lanes, and the float64 geometry is
+    // ~1000 of them): the goal geometry and the rules of ALL the block's envs on lanes 0..EPB-1 of wave 0 (the "owners"); the
+    // next-episode records on 2 EPB "spec" lanes -- behind the owners in wave 0 for the small shapes, else on the waves that
+    // follow the pose waves (they have nothing else to do before barrier A, so their record requests leave at kernel entry).
+    // State crosses from the part-1 lanes through LDS (sv_*).  PW = the "front" waves: pose + spec; the others are ray waves.
+    const bool own = (wave == 0) && (lane < nloc);            // lane = env for the geometry / rules lanes
+    const int n_rec = P.respawn ? 2 : 1;
+    // spec lanes: record spec_c of env spec_e
+    const int sl = (wave - kSpecWave0) * 64 + lane - kSpecLane0;
+    const int spec_c = sl / EPB;
+    const int spec_e = sl % EPB;
+    const bool spec_lane = (wave >= kSpecWave0) && (wave < PW) && (sl >= 0) && (spec_c < n_rec) && (spec_e < nloc);
+
+    // The spec lanes request the cached records at kernel entry, whether they will turn out current or not: the first of
+    // the two dependent round trips of the record path then runs under the pose phase instead of after barrier A, where the
+    // spec wave is the last one into the cast.
+    const bool spec = spec_lane && (P.auto_reset || (spec_c == 1));
+    double pf_rgx = 0, pf_rgy = 0, pf_g0 = 0, pf_g1 = 0, pf_g2 = 0;
+    float4 pf_tl = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned long long pf_ck = 0ull;   // (counter, start-pose index) kept as ONE 64-bit value until it is used: a uint2 was split
+                                       // right behind the load, which made the wave wait for the whole round trip there
+    uint32_t pf_rctr = 0;
+    auto prefetch_records = [&]() __attribute__((always_inline)) {
+        if (spec) {   // (the persistent rollout calls this after barrier A: measured slower there at the top of the step)
+            const int ie = base + spec_e, c = spec_c;
+            const size_t N = (size_t)P.N;
+            if (c == 1) {
+                pf_rgx = P.rsp_g[ie]; pf_rgy = P.rsp_g[N + ie]; pf_rctr = P.rsp_ctr[ie];
+            }
+            if (P.auto_reset) {
+                const double* rg = P.rec_g + (size_t)c * 3 * N + ie;
+                pf_g0 = rg[0]; pf_g1 = rg[N]; pf_g2 = rg[2 * N];
+                pf_tl = P.rec_tail[(size_t)c * N + ie];
+                pf_ck = reinterpret_cast<const unsigned long long*>(P.rec_ck)[(size_t)c * N + ie];
+            }
+        }
+    };
+
     if (wave < PW) {
         // ---------------- pose lanes, part 1: motion + sensor frame
         // spec lanes on a wave of their own: the cached records are requested at kernel entry
         if constexpr (EPB > 8) { if (!PERSIST) prefetch_records(); }
-        // the beam table entries of lane rr (beams rr, rr + 2, ...) are requested with the state: requested where they are
-        // used, behind the sincos, their round trip sat on the chain to barrier A
-        constexpr int kBeamIt = (NB + LPE - 1) / LPE;
-        double beam_c[kBeamIt], beam_s[kBeamIt];
-        if (wave < PWP) {
-#pragma unroll
-            for (int q = 0; q < kBeamIt; ++q) {
-                const int b = min(rr + LPE * q, NB - 1);
-                beam_c[q] = P.beam_cs[b];
-                beam_s[q] = P.beam_cs[NB + b];
-            }
-        }
         double delta_s = 0, delta_theta = 0, arg = 0, x_old = 0, y_old = 0;
         if (pose_lane && el_pose < nloc) {
             if (PERSIST) {
@@ -595,18 +642,6 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
                     pact = sm.st_pact[e];
                     ret0 = sm.st_d[6][e];
                     path0 = sm.st_d[7][e];
-                }
-            } else {
-                th = P.th[i];
-                act = action[i];
-                ctr = P.rng_ctr[i];
-                stepw = (uint32_t)P.ep_step[i];
-                if (rr == 0) {
-                    x = P.x[i]; y = P.y[i];
-                    gx = P.gx[i]; gy = P.gy[i]; pdist = P.past_dist[i];
-                    pact = past_override ? past_override[i] : P.past_action[i];
-                    ret0 = P.ep_ret[i];
-                    path0 = P.ep_path[i];
                 }
             }
             x_old = x; y_old = y;
@@ -685,26 +720,31 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
         if (tid == 0) next_env = (NW - PW) * (ntl == 1 ? 3 : (ntl == 2 ? 2 : 1));
     }
     if (wave >= PW) {
-        // ---------------- other waves, part 1: nothing here depends on the pose
+        // ---------------- other waves, part 1 (their tile requests went out at the top): LDS traffic under that round trip
         for (int k = tid - 64 * PW; k < NB * EPB; k += kThreads - 64 * PW) sm.rng[k] = kInfBits;
         if (tid - 64 * PW < EPB) {
             sm.mn_bits[tid - 64 * PW] = kInfBits;
             sm.neg[tid - 64 * PW] = 0u;
         }
-        if (BOXES && tid - 64 * PW < ntiles) sm.tbox[tid - 64 * PW] = P.tile_box[tid - 64 * PW];
-        static_assert(sizeof(Rects) % 8 == 0, "Rects is copied in 8-byte words");
-        if (!PERSIST)   // (the persistent rollout stages the table once, before its first step)
-            for (int k = tid - 64 * PW; k < (int)(sizeof(Rects) / 8); k += kThreads - 64 * PW)
-                reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
-        // static positions k = 0, 1, 2 of ray wave r: item r + RW (k / ntiles), tile k % ntiles
-        constexpr int RW = NW - PW;
-        const int r = wave - PW;
-        p0 = Pos{r, 0};
-        p1 = (ntl >= 2) ? Pos{r, 1} : Pos{r + RW, 0};
-        p2 = (ntl >= 3) ? Pos{r, 2} : ((ntl == 2) ? Pos{r + RW, 0} : Pos{r + 2 * RW, 0});
-        request(p0, g0, v0, g0b, v0b);
-        request(p1, g1, v1, g1b, v1b);
-        request(p2, g2, v2, g2b, v2b);
+    }
+    // the goal rejection rectangles (the spec lanes' recompute path reads them after barrier A) and the tile boxes: staged by the
+    // waves behind the pose waves -- spec waves where the shape has them (their only other work before barrier A is the record
+    // request), else the ray waves, behind their tile requests.  A ray wave that waits for this round trip also waits for its
+    // three tiles (the counter retires in order), which is why the big shapes keep it off them.  (The persistent rollout stages
+    // the rectangles once, before its first step.)
+    if (wave >= PWP) {
+        constexpr int kStageThreads = 64 * (NW - PWP);
+        const int st = tid - 64 * PWP;
+        constexpr bool kOnFront = (PW > PWP);   // staging waves = the front waves behind the pose waves
+        const bool mine = kOnFront ? (wave < PW) : true;
+        constexpr int kStride = kOnFront ? 64 * (PW - PWP) : kStageThreads;
+        if (mine) {
+            if (BOXES) for (int k = st; k < ntiles; k += kStride) sm.tbox[k] = P.tile_box[k];
+            static_assert(sizeof(Rects) % 8 == 0, "Rects is copied in 8-byte words");
+            if (!PERSIST)
+                for (int k = st; k < (int)(sizeof(Rects) / 8); k += kStride)
+                    reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
+        }
     }
     __syncthreads();  // barrier A: origins / directions visible, work counter set
 
@@ -778,12 +818,12 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
             }
             if (!current) {
                 if (c == 1) {
-                    sample_goal(P, sm.rects, ie, 1, sctr, rgx, rgy);
+                    sample_goal<PRef>(P, sm.rects, ie, 1, sctr, rgx, rgy);
                     rctr = sctr;
                     P.rsp_g[ie] = rgx; P.rsp_g[N + ie] = rgy; P.rsp_ctr[ie] = rctr;
                 }
                 if (P.auto_reset) {
-                    sample_episode(P, sm.rects, ie, sctr, sk, tgx, tgy);
+                    sample_episode<PRef>(P, sm.rects, ie, sctr, sk, tgx, tgy);
                     request_row(sk);
                     px = P.starts[3 * sk]; py = P.starts[3 * sk + 1]; pth = P.starts[3 * sk + 2];
                     double ryaw, rrel, rdiff;
@@ -1071,14 +1111,14 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
         double ret = ret0 + r;
         const bool timeout = (P.max_ep_steps > 0) && ((int)step >= P.max_ep_steps);  // ppo.py:552
         const bool end = d || a || timeout;
-        reward[i] = (float)r;
-        done[i] = d ? 1 : 0;
-        arrive[i] = a ? 1 : 0;
-        if (ended) ended[i] = end ? 1 : 0;
+        io.reward[i] = (float)r;
+        io.done[i] = d ? 1 : 0;
+        io.arrive[i] = a ? 1 : 0;
+        if (io.ended) io.ended[i] = end ? 1 : 0;
         if (end) {
-            if (ep_return) ep_return[i] = (float)ret;
-            if (ep_length) ep_length[i] = (int32_t)step;
-            if (ep_path_out) ep_path_out[i] = (float)path;   // ppo.py:533-537: the final step's displacement is never added
+            if (io.ep_return) io.ep_return[i] = (float)ret;
+            if (io.ep_length) io.ep_length[i] = (int32_t)step;
+            if (io.ep_path_out) io.ep_path_out[i] = (float)path;   // ppo.py:533-537: the final step's displacement is never added
         }
         path += sm.sv_d[11][e];
         float2 next_pact = act;  // ppo.py:543
@@ -1128,25 +1168,34 @@ __device__ __forceinline__ void step_body(const Params& P, StepSmem<NB, EPB, NW>
     // ---------------- coalesced store of the block's observation tile
     const int n_out = nloc * D;
     if (P.obs_f16) {
-        __half* o = reinterpret_cast<__half*>(obs_out) + (size_t)base * D;
+        __half* o = reinterpret_cast<__half*>(io.obs_out) + (size_t)base * D;
         for (int k = tid; k < n_out; k += kThreads) o[k] = __float2half_rn(sm.obs[(k / D) * DP + (k % D)]);
     } else {
-        float* o = reinterpret_cast<float*>(obs_out) + (size_t)base * D;
+        float* o = reinterpret_cast<float*>(io.obs_out) + (size_t)base * D;
         for (int k = tid; k < n_out; k += kThreads) o[k] = sm.obs[(k / D) * DP + (k % D)];
     }
 }
 
+// The kernarg segment of step_kernel as the compiler lays it out (members at their natural alignment, in order).
+struct StepKArgs {
+    Params P;
+    StepIO io;
+};
+typedef const StepKArgs __attribute__((address_space(4))) * StepKArgsPtr;
+
 template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, bool PAIR = false>
-__global__ __launch_bounds__(64 * NW) void step_kernel(Params P, const float2* __restrict__ action,
-                                                        const float2* __restrict__ past_override,
-                                                        void* __restrict__ obs_out, float* __restrict__ reward,
-                                                        uint8_t* __restrict__ done, uint8_t* __restrict__ arrive,
-                                                        uint8_t* __restrict__ ended, float* __restrict__ ep_return,
-                                                        int32_t* __restrict__ ep_length, float* __restrict__ ep_path_out) {
+__global__ __launch_bounds__(64 * NW) void step_kernel(Params, const float2* __restrict__, const float2* __restrict__, void* __restrict__,
+                                                        float* __restrict__, uint8_t* __restrict__, uint8_t* __restrict__,
+                                                        uint8_t* __restrict__, float* __restrict__, int32_t* __restrict__,
+                                                        float* __restrict__) {
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
-    step_body<NB, EPB, SENS, false, NW, BOXES, PAIR>(P, sm, next_env, action, past_override, obs_out, reward, done, arrive, ended, ep_return,
-                                    ep_length, ep_path_out);
+    // the parameters are read through the kernarg segment pointer (see step_body); the named parameters above only give the
+    // launch its signature
+    StepKArgsPtr A = (StepKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(A));
+    step_body<NB, EPB, SENS, false, NW, BOXES, PAIR, const Params __attribute__((address_space(4)))&,
+              const StepIO __attribute__((address_space(4)))&>(A->P, sm, next_env, A->io);
 }
 
 // ---------------------------------------------------------------- the persistent rollout kernel (PPO.rollout, ppo.py:463-641)
@@ -1233,10 +1282,10 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
             R.logp_buf[tn + base + e] = o.logp;
         }
         __syncthreads();
-        step_body<NB, EPB, SENS, true, NW>(P, sm, next_env, nullptr, nullptr, R.obs_buf + (tn + N) * D, R.reward + tn, R.done + tn,
-                                       R.arrive + tn, R.ended + tn, R.ep_return ? R.ep_return + tn : nullptr,
-                                       R.ep_length ? R.ep_length + tn : nullptr, R.ep_path ? R.ep_path + tn : nullptr,
-                                       t == R.T - 1);
+        const StepIO io = {nullptr, nullptr, R.obs_buf + (tn + N) * D, R.reward + tn, R.done + tn, R.arrive + tn, R.ended + tn,
+                           R.ep_return ? R.ep_return + tn : nullptr, R.ep_length ? R.ep_length + tn : nullptr,
+                           R.ep_path ? R.ep_path + tn : nullptr};
+        step_body<NB, EPB, SENS, true, NW>(P, sm, next_env, io, t == R.T - 1);
         // the observation tile of step t + 1 is in sm.obs; its store only reads it, like the next policy phase
     }
 }
@@ -1266,7 +1315,7 @@ __global__ void reset_kernel(Params P, const uint8_t* __restrict__ mask, void* _
     uint32_t ctr = P.rng_ctr[i];
     double gx, gy, yaw, rel_theta, diff;
     int k0;
-    sample_episode(P, *P.rects, i, ctr, k0, gx, gy);
+    sample_episode<const Params&>(P, *P.rects, i, ctr, k0, gx, gy);
     const double x = P.starts[3 * k0], y = P.starts[3 * k0 + 1], th = P.starts[3 * k0 + 2];
     goal_angles(x, y, th, gx, gy, yaw, rel_theta, diff);
     const double dist = hypot(gx - x, gy - y);
