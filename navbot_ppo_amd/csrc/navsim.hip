@@ -36,6 +36,7 @@
 #include <cstring>
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -341,6 +342,7 @@ struct StepSmem {
     float4 tbox[64];             // Params::tile_box, staged once per launch (BOXES)
     Rects rects;                 // Params::rects, staged by the ray waves before barrier A (the spec lanes' goal rejection test)
     float2 act_l[EPB];           // persistent rollout: the action the policy phase chose for this step
+    double beam[2 * NB];         // Params::beam_cs, staged by the pose waves (persistent rollout: once)
     // persistent rollout: the envs' state lives here between the steps (HBM sees it before the first and after the last)
     double st_d[8][EPB];         // x, y, th, gx, gy, past_dist, ep_ret, ep_path
     float2 st_pact[EPB];
@@ -477,7 +479,7 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     constexpr int DP = D + 1;   // padded LDS row stride
     const int nloc = min(EPB, P.N - base);  // envs in this block
     const unsigned kInfBits = 0x7f800000u;
-    // Pose lanes: TWO lanes per env.  The step needs the heading's (cos, sin) at the six substep arguments th_k + dth/2 and at the
+    // Pose lanes: TWO lanes per env (four in the small shapes).  The step needs the heading's (cos, sin) at the six substep arguments th_k + dth/2 and at the
     // final heading; lane 0 of the pair evaluates sincos(final heading), lane 1 sincos(dth / 2), and the six substep values follow
     // by rotating back from the final heading (angle addition, explicit fma: |error| ~ 1e-15, i.e. 1e-17 m on the pose).  The beam
     // directions and the sensor origin -- everything the scan's bits depend on -- come from the library sincos of the final heading,
@@ -485,7 +487,8 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     // envs, i.e. four times the float64 instruction issue for the same chain length; at configs[2] the pose phase was a fifth of the
     // launch's vector-unit time and its second wave per SIMD reached barrier A 0.5 us behind the first.
     // Lane 0 of each pair owns the env's float64 state across the phases.
-    constexpr int LPE = 2;                              // pose lanes per env
+    constexpr int LPE = (EPB <= 16) ? 4 : 2;            // pose lanes per env (lanes 2, 3 of a quad only share the beam directions:
+                                                        // the small shapes are latency chains, the big ones issue-bound)
     constexpr int PWP = (LPE * EPB + 63) / 64;          // pose waves
     double x = 0, y = 0, th = 0, gx = 0, gy = 0, pdist = 0, dist = 0, yaw = 0, rel_theta = 0, diff = 0, ret0 = 0, path0 = 0;
     float2 act = make_float2(0.f, 0.f), pact = make_float2(0.f, 0.f);
@@ -505,7 +508,11 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     const int sub = lane >> spl;
     const int j0 = lane & ((1 << spl) - 1);
     const int n_items = (nloc + epp - 1) / epp;
-    const int ntiles = (P.S + 63) >> 6;
+    // (locals: read through the kernarg segment, P's fields are scalar loads at every use -- these sit in the cast loop)
+    const int S = P.S;
+    const bool per_env = P.per_env != 0;
+    const float4* const segs = P.seg;
+    const int ntiles = (S + 63) >> 6;
     // PAIR (maps of more than 64 segments, one env per pass): a pass takes 128 segments, two per lane (j and j + 64) -- the
     // work-queue, address and loop instructions of a pass, about as many as its arithmetic, are paid once per 128 segments
     const int ntl = PAIR ? (ntiles + 1) >> 1 : ntiles;   // passes per item
@@ -521,17 +528,17 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     // compiler had to assume the path that skipped them and waited for vmcnt(0) before every tile: no prefetch at all.
     auto ld = [&](const Pos p, float4& g, bool& v) __attribute__((always_inline)) {
         const int el = p.it * epp + sub, j = (p.t << 6) + j0;
-        v = (p.it < n_items) && (el < nloc) && (j < P.S);
-        g = P.seg[(P.per_env ? (size_t)(base + min(el, nloc - 1)) * (size_t)P.S : (size_t)0) + (size_t)min(j, P.S - 1)];
+        v = (p.it < n_items) && (el < nloc) && (j < S);
+        g = segs[(per_env ? (size_t)(base + min(el, nloc - 1)) * (size_t)S : (size_t)0) + (size_t)min(j, S - 1)];
     };
     auto ld2 = [&](const Pos p, float4& ga, bool& va, float4& gb, bool& vb) __attribute__((always_inline)) {
         const int j = (p.t << 7) + lane;
         const bool item = (p.it < n_items) && (p.it < nloc);
-        va = item && (j < P.S);
-        vb = item && (j + 64 < P.S);
-        const float4* src = P.seg + (P.per_env ? (size_t)(base + min(p.it, nloc - 1)) * (size_t)P.S : (size_t)0);
-        ga = src[min(j, P.S - 1)];
-        gb = src[min(j + 64, P.S - 1)];
+        va = item && (j < S);
+        vb = item && (j + 64 < S);
+        const float4* src = segs + (per_env ? (size_t)(base + min(p.it, nloc - 1)) * (size_t)S : (size_t)0);
+        ga = src[min(j, S - 1)];
+        gb = src[min(j + 64, S - 1)];
     };
     Pos p0 = {n_items, 0}, p1 = {n_items, 0}, p2 = {n_items, 0};
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0, g0b = g0, g1b = g0, g2b = g0;
@@ -554,10 +561,11 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         request(p1, g1, v1, g1b, v1b);
         request(p2, g2, v2, g2b, v2b);
     }
-    // pose waves: the beam table entries of lane rr (beams rr, rr + 2, ...) are requested with the state: requested where they
-    // are used, behind the sincos, their round trip sat on the chain to barrier A
-    constexpr int kBeamIt = (NB + LPE - 1) / LPE;
-    double beam_c[kBeamIt], beam_s[kBeamIt];
+    // pose waves: the beam table goes through LDS (lane k requests entry k here, right behind the state; written to LDS behind the
+    // sincos, read back per beam): held in registers per lane it
+    // cost 4 NB / LPE VGPRs from here to the end of part 1.  (The persistent rollout stages it once, before its first step.)
+    constexpr int kBeamLd = (2 * NB + 63) / 64;
+    double beam_ld[kBeamLd];
     if (wave < PWP) {
         if (!PERSIST && pose_lane && el_pose < nloc) {
             th = P.th[i];
@@ -572,11 +580,9 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
                 path0 = P.ep_path[i];
             }
         }
+        if (!PERSIST) {
 #pragma unroll
-        for (int q = 0; q < kBeamIt; ++q) {
-            const int b = min(rr + LPE * q, NB - 1);
-            beam_c[q] = P.beam_cs[b];
-            beam_s[q] = P.beam_cs[NB + b];
+            for (int q = 0; q < kBeamLd; ++q) beam_ld[q] = P.beam_cs[min(lane + 64 * q, 2 * NB - 1)];
         }
     }
 
@@ -628,7 +634,7 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         // ---------------- pose lanes, part 1: motion + sensor frame
         // spec lanes on a wave of their own: the cached records are requested at kernel entry
         if constexpr (EPB > 8) { if (!PERSIST) prefetch_records(); }
-        double delta_s = 0, delta_theta = 0, arg = 0, x_old = 0, y_old = 0;
+        double delta_s = 0, delta_theta = 0, arg = 0;
         if (pose_lane && el_pose < nloc) {
             if (PERSIST) {
                 const int e = el_pose;
@@ -644,7 +650,6 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
                     path0 = sm.st_d[7][e];
                 }
             }
-            x_old = x; y_old = y;
             // environment_new.py:273-278
             const double v = (double)act.x / 4;
             const double w = (double)act.y;
@@ -663,55 +668,76 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         // spec lanes that share wave 0 with the pose lanes (small shapes): behind the wheel arithmetic -- the wait for the state
         // loads is over, the sincos covers this round trip
         if constexpr (EPB <= 8) { if (!PERSIST) prefetch_records(); }
+        double cth = 1.0, sth = 0.0;
         if (pose_lane) {
             double sn, cs;
             sincos(arg, &sn, &cs);
-            // the partner lane's pair through DPP (quad_perm [1, 0, 3, 2]): no LDS round trip on the chain to barrier A
-            auto swap1 = [](const double vv) __attribute__((always_inline)) {
-                const int lo = __builtin_amdgcn_mov_dpp(__double2loint(vv), 0xB1, 0xF, 0xF, true);
-                const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(vv), 0xB1, 0xF, 0xF, true);
+            // lane 0's and lane 1's pair to every lane of the env's group through DPP quad permutes: no LDS round trip on the
+            // chain to barrier A
+            auto bcast = [](const double vv, auto sel) __attribute__((always_inline)) {
+                constexpr int kCtrl = (LPE == 4) ? (decltype(sel)::value ? 0x55 : 0x00)     // quad_perm [k, k, k, k]
+                                                 : (decltype(sel)::value ? 0xF5 : 0xA0);    // quad_perm [k, k, 2 + k, 2 + k]
+                const int lo = __builtin_amdgcn_mov_dpp(__double2loint(vv), kCtrl, 0xF, 0xF, true);
+                const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(vv), kCtrl, 0xF, 0xF, true);
                 return __hiloint2double(hi, lo);
             };
-            const double pcs = swap1(cs), psn = swap1(sn);
-            const double cth = (rr == 0) ? cs : pcs, sth = (rr == 0) ? sn : psn;   // final heading
-            const double ch = (rr == 0) ? pcs : cs, sh = (rr == 0) ? psn : sn;     // half a substep's turn
+            cth = bcast(cs, std::integral_constant<int, 0>{});   // final heading
+            sth = bcast(sn, std::integral_constant<int, 0>{});
+            const double ch = bcast(cs, std::integral_constant<int, 1>{}), sh = bcast(sn, std::integral_constant<int, 1>{});    // half a substep's turn
             if (rr == 0) {
                 // substep k integrates along th_k + dth / 2 = final heading - (kSubsteps - 1/2 - k) dth  (:158-159): rotate back
-                // by dth / 2 once, then by dth (double angle) per substep
+                // by dth / 2 once, then by dth (double angle) per substep; the displacements are summed as they come, last substep
+                // first (the serial loop's order would keep all six pairs alive)
                 const double cd = fma(ch, ch, -(sh * sh)), sd = 2.0 * (sh * ch);
-                double ck[kSubsteps], sk[kSubsteps];
-                ck[kSubsteps - 1] = fma(cth, ch, sth * sh);
-                sk[kSubsteps - 1] = fma(sth, ch, -(cth * sh));
+                double c = fma(cth, ch, sth * sh), s = fma(sth, ch, -(cth * sh));
+                double dx = delta_s * c, dy = delta_s * s;
 #pragma unroll
                 for (int k = kSubsteps - 2; k >= 0; --k) {
-                    ck[k] = fma(ck[k + 1], cd, sk[k + 1] * sd);
-                    sk[k] = fma(sk[k + 1], cd, -(ck[k + 1] * sd));
+                    const double c1 = fma(c, cd, s * sd);
+                    s = fma(s, cd, -(c * sd));
+                    c = c1;
+                    dx += delta_s * c;
+                    dy += delta_s * s;
                 }
-#pragma unroll
-                for (int k = 0; k < kSubsteps; ++k) {  // :158-159, in the serial loop's order
-                    x += delta_s * ck[k];
-                    y += delta_s * sk[k];
-                }
+                x += dx;
+                y += dy;
                 const double ox = x + kLidarX * cth;
                 const double oy = y + kLidarX * sth;
                 sm.org[el_pose] = make_float2((float)ox, (float)oy);
                 sm.hd[el_pose] = make_float2((float)cth, (float)sth);
                 if (el_pose < nloc) {  // hand the env over to its geometry / rules lane
                     const int e = el_pose;
-                    const double mx = x - x_old, my = y - y_old;
                     sm.sv_d[0][e] = x; sm.sv_d[1][e] = y; sm.sv_d[2][e] = th; sm.sv_d[3][e] = gx; sm.sv_d[4][e] = gy;
                     sm.sv_d[5][e] = pdist; sm.sv_d[10][e] = ret0;
-                    sm.sv_d[11][e] = sqrt(mx * mx + my * my);   // np.linalg.norm(curr_pos - prev_pos), ppo.py:536-537
+                    sm.sv_d[11][e] = sqrt(dx * dx + dy * dy);   // np.linalg.norm(curr_pos - prev_pos), ppo.py:536-537
                     sm.sv_d[12][e] = path0;
                     sm.sv_act[e] = act; sm.sv_pact[e] = pact; sm.sv_ctr[e] = ctr; sm.sv_step[e] = stepw;
                 }
             }
+        }
+        if (!PERSIST && wave < PWP) {
+#pragma unroll
+            for (int q = 0; q < kBeamLd; ++q)
+                if (lane + 64 * q < 2 * NB) sm.beam[lane + 64 * q] = beam_ld[q];
+        }
+        if (pose_lane) {
+            // the table entries just written by this wave (LDS operations of a wave complete in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int kBeamIt = (NB + LPE - 1) / LPE;
+            double bc[kBeamIt], bs[kBeamIt];
+#pragma unroll
+            for (int q = 0; q < kBeamIt; ++q) {   // all reads first: one LDS latency
+                const int b = min(rr + LPE * q, NB - 1);
+                bc[q] = sm.beam[b];
+                bs[q] = sm.beam[NB + b];
+            }
 #pragma unroll
             for (int q = 0; q < kBeamIt; ++q) {
                 const int b = rr + LPE * q;
-                if (b < B) {
-                    const double c = cth * beam_c[q] - sth * beam_s[q];
-                    const double s = sth * beam_c[q] + cth * beam_s[q];
+                if (b < NB) {
+                    const double c = cth * bc[q] - sth * bs[q];
+                    const double s = sth * bc[q] + cth * bs[q];
                     sm.dir[b * EPB + el_pose] = make_float2((float)c, (float)s);
                 }
             }
@@ -1245,6 +1271,7 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
         sm.st_ctr[e] = P.rng_ctr[i];
     }
     for (int k = tid; k < nloc * D; k += kThreads) sm.obs[(k / D) * DP + (k % D)] = R.obs_buf[(size_t)base * D + k];
+    for (int k = tid; k < 2 * NB; k += kThreads) sm.beam[k] = P.beam_cs[k];
     for (int k = tid; k < (int)(sizeof(Rects) / 8); k += kThreads)   // the goal rejection rectangles, for all T steps
         reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
     const uint32_t step0 = R.step_base ? *R.step_base : 0u;
