@@ -207,6 +207,19 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
                          float* ep_return_dev, int32_t* ep_length_dev, float* ep_path_dev, const float* var_dev,
                          uint64_t act_seed, const uint32_t* step_base_dev, int32_t n_steps, void* stream);
 
+/*
+ * Env.getOdometry()  (environment_new.py:138-181) on its own, for n independent samples -- the odometry callback's arithmetic
+ * exactly as the reference runs it, general quaternion included (the step kernel applies the same device functions to the
+ * yaw-only quaternion of its planar pose):
+ *   yaw        = round(degrees(atan2(2 (qx qy + qw qz), 1 - 2 (qy^2 + qz^2)))), + 360 if negative        (:142-147)
+ *   rel_theta  = round(degrees(8-case quadrant angle of round(goal - pos, 1)), 2)                           (:149-169)
+ *   diff_angle = round(wrap(yaw - rel_theta) to [-180, 180], 2)                                              (:170-176)
+ * x_dev, y_dev [n] f64; quat_dev [n,4] f64 (qx, qy, qz, qw); goal_dev [n,2] f64; out_dev [n,3] f64 (yaw, rel_theta,
+ * diff_angle).  Python round() semantics (half to even on the decimal value) are reproduced exactly.
+ */
+int navsim_odometry(int32_t n, const double* x_dev, const double* y_dev, const double* quat_dev, const double* goal_dev,
+                    double* out_dev, void* stream);
+
 /* LiDAR only (no state change): ranges_dev [N,B] f32 raw scan (inf = no return) for poses
  * pose_dev [N,3] f64.  Used by tests and by map tooling (spawn_goal_sampler-style validation). */
 int navsim_raycast(navsim_t* h, const double* pose_dev, float* ranges_dev, void* stream);

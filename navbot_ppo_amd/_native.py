@@ -53,6 +53,7 @@ SYMBOLS = [
     ("navsim_rtg_scan", C.c_int, [_vp, _vp, _i32, _i32, _d, _vp, _vp]),
     ("navsim_gae_scan", C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _d, _d, _vp, _vp, _vp]),
     ("navsim_raycast", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("navsim_odometry", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("navsim_rollout_mlp64", C.c_int, [_vp] * 13 + [C.c_uint64, _vp, _i32, _vp]),
     # include/navppo.h
     ("navppo_last_error", C.c_char_p, []),

@@ -140,13 +140,13 @@ __device__ __forceinline__ double py_round(double x, double s, double inv_s) {
 }
 
 // yaw of Env.getOdometry, environment_new.py:142-147, for the yaw-only quaternion (qz, qw) = (sin, cos)(theta / 2)
-__device__ __forceinline__ double yaw_from_quat(double qz, double qw) {
+__device__ __forceinline__ double yaw_from_quat4(double qx, double qy, double qz, double qw) {
     const double rad2deg = 180.0 / 3.14159265358979323846;
-    const double qx = 0.0, qy = 0.0;
     double yaw = rint(atan2(2 * (qx * qy + qw * qz), 1 - 2 * (qy * qy + qz * qz)) * rad2deg);  // :142
     if (!(yaw >= 0)) yaw = yaw + 360;                                                            // :144-147
     return yaw + 0.0;   // Python's round() returns the int 0 for -0.4: no negative zero
 }
+__device__ __forceinline__ double yaw_from_quat(double qz, double qw) { return yaw_from_quat4(0.0, 0.0, qz, qw); }
 
 // The same integer without the quaternion round trip: atan2(sin th, cos th) is th wrapped to (-pi, pi], so the yaw is
 // rint(th in degrees, wrapped to [-180, 180]).  The two routes differ by < 1e-9 degree for |th| < 1e7 rad, so they round
@@ -1317,6 +1317,17 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
     }
 }
 
+// Env.getOdometry (environment_new.py:138-181) for n independent (position, orientation quaternion, goal) triples
+__global__ void odometry_kernel(int n, const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ q,
+                                const double* __restrict__ goal, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double yaw = yaw_from_quat4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
+    double rel, diff;
+    goal_rel(px[i], py[i], goal[2 * i], goal[2 * i + 1], yaw, rel, diff);
+    out[3 * i] = yaw; out[3 * i + 1] = rel; out[3 * i + 2] = diff;
+}
+
 // clears kRecValid of every env: the cached next-episode records no longer match (tables / rectangles / counters changed)
 __global__ void invalidate_records_kernel(int32_t* __restrict__ ep_step, int N) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1986,6 +1997,17 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
         if (sens) hipLaunchKernelGGL((rollout_kernel<16, true, kRollWaves>), grid, block, 0, st, h->P, R);
         else hipLaunchKernelGGL((rollout_kernel<16, false, kRollWaves>), grid, block, 0, st, h->P, R);
     }
+    HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
+}
+
+int navsim_odometry(int32_t n, const double* x_dev, const double* y_dev, const double* quat_dev, const double* goal_dev,
+                    double* out_dev, void* stream) {
+    if (n < 0 || (n > 0 && (!x_dev || !y_dev || !quat_dev || !goal_dev || !out_dev)))
+        return fail(NAVSIM_E_ARG, "navsim_odometry: bad argument");
+    if (n == 0) return NAVSIM_OK;
+    hipLaunchKernelGGL(odometry_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, x_dev, y_dev, quat_dev,
+                       goal_dev, out_dev);
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;
 }

@@ -173,6 +173,20 @@ def rtg_scan(rew, ended, gamma, out=None):
     return out
 
 
+def odometry(x, y, quat, goal):
+    """Env.getOdometry (environment_new.py:138-181) for n samples on the device: x, y [n], quat [n,4] = (qx, qy, qz, qw),
+    goal [n,2], all float64 -> [n,3] float64 (yaw, rel_theta, diff_angle); see navsim_odometry."""
+    if not x.is_cuda:
+        raise NavsimError("odometry needs device tensors; there is no CPU path")
+    x, y, quat, goal = (t.to(torch.float64).contiguous() for t in (x, y, quat, goal))
+    n = x.shape[0]
+    assert y.shape == (n,) and quat.shape == (n, 4) and goal.shape == (n, 2)
+    out = torch.empty((n, 3), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().navsim_odometry(n, _ptr(x), _ptr(y), _ptr(quat), _ptr(goal), _ptr(out), _stream()), "navsim_odometry")
+    return out
+
+
 def gae_scan(rew, ended, value, gamma, lam, last_value=None, want_returns=True):
     """GAE(lambda) on [T,N] device tensors (navsim_gae_scan): returns (adv, lambda_returns).  lam = 1 without `last_value`
     is PPO.compute_rtgs followed by A = rtgs - V (ppo.py:277, 643-671), bit for bit."""

@@ -218,6 +218,22 @@ def test_g1_goal_angles_through_the_kernel():
     assert np.all(o[:, :10] == 1.0)  # +inf -> 3.5 -> 1.0
 
 
+def test_g1_get_odometry_on_the_device_all_cases():
+    """a-3 in full: every reference getOdometry golden (G1: 2307 cases incl. general quaternions, exact half-degree yaw
+    ties, quadrant edges, dx == 0 / dy == 0, wrap-around) through navsim_odometry -- the device functions the step kernel
+    uses -- bit for bit (environment_new.py:138-181)."""
+    from navbot_ppo_amd.env import odometry
+    d = np.load(os.path.join(G, "g1_odometry.npz"))
+    inp, out = d["inp"], d["out"]
+    dev = torch.device("cuda:0")
+    got = odometry(torch.from_numpy(inp[:, 0].copy()).to(dev), torch.from_numpy(inp[:, 1].copy()).to(dev),
+                   torch.from_numpy(inp[:, 2:6].copy()).to(dev), torch.from_numpy(inp[:, 6:8].copy()).to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, out)
+    assert not np.signbit(got).any() or (got[np.signbit(got)] != 0).all()   # Python's round() never yields -0.0 for the yaw
+    assert odometry(torch.zeros(0, device=dev), torch.zeros(0, device=dev), torch.zeros((0, 4), device=dev),
+                    torch.zeros((0, 2), device=dev)).shape == (0, 3)
+
+
 def assert_rtg_close(got, ref):
     """The return scan's contract on the T-split path (N % 16 == 0): every float32 within ONE ulp of ppo.py:660-669, and
     all but a vanishing share identical (a differing carry rounding moves a store with probability ~2e-8 per element)."""
