@@ -3,7 +3,9 @@
 per-block start/end/placement records (read back by tools/phase_timing.py)."""
 import os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-t = open(os.path.join(R, "navbot_ppo_amd/csrc/navsim.hip")).read()
+SRC = os.environ.get("NAVSIM_SRC", os.path.join(R, "navbot_ppo_amd/csrc/navsim.hip"))   # another revision of the kernel file
+OUT = os.environ.get("NAVSIM_TIMING_OUT", "libnavsim_timing.so")
+t = open(SRC).read()
 extra_flags = sys.argv[1:]
 def rep(a, b, n=1):
     global t
@@ -15,10 +17,13 @@ rep("template <int NB, int EPB, int NW = 4>\nstruct StepSmem {",
     "template <int NB, int EPB, int NW = 4>\nstruct StepSmem {")
 rep("    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motion + sensor frame\n",
     "    STAMP(0);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) { g_blk[blockIdx.x * 3] = wall_clock64(); unsigned hw; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw)); unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc)); g_blk[blockIdx.x * 3 + 2] = ((long long)xcc << 32) | hw; }\n"
-    "    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motion + sensor frame")
+    "    if (wave < PW) {\n        // ---------------- pose lanes, part 1: motion + sensor frame\n")
 rep("    __syncthreads();  // barrier A:", "    STAMP(1);\n    __syncthreads();  STAMP(2); // barrier A:")
 rep("    __syncthreads();  // barrier B:", "    STAMP(3);\n    __syncthreads();  STAMP(4); // barrier B:")
-rep("    __syncthreads();  // barrier C:", "    STAMP(5);\n    __syncthreads();  STAMP(6); // barrier C:")
+rep("    __syncthreads();  // barrier C:", "    STAMP(5);\n    __syncthreads();  // barrier C:")
+# slot 6: the wave has seen the exact pose published (front waves: before part 2; ray waves: at their first stage-B pass)
+if "            pose_ok = true;\n" in t:
+    rep("            pose_ok = true;\n", "            pose_ok = true;\n            STAMP(6);\n")
 idx = t.index("template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, bool PAIR = false>\n__global__ __launch_bounds__(64 * NW) void step_kernel(")
 j = t.rfind("}\n\n", 0, idx)
 t = t[:j] + "    STAMP(7);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk[blockIdx.x * 3 + 1] = wall_clock64();\n" + t[j:]
@@ -40,7 +45,7 @@ if "--lb4" in extra_flags:
     rep("__global__ __launch_bounds__(kThreads) void step_kernel", "__global__ __launch_bounds__(kThreads, 4) void step_kernel")
 os.makedirs(os.path.join(R, "build"), exist_ok=True)
 open("/tmp/navsim_timing.hip", "w").write(t)
-out = os.path.join(R, "build", "libnavsim_timing.so")
+out = os.path.join(R, "build", OUT)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
                        "-fvisibility=hidden", "-I", os.path.join(R, "include"), "-I", os.path.join(R, "navbot_ppo_amd/csrc"), "/tmp/navsim_timing.hip",
                        os.path.join(R, "navbot_ppo_amd/csrc/ppo_mlp64.hip"), os.path.join(R, "navbot_ppo_amd/csrc/ppo_resmlp512.hip"), "-o", out])

@@ -8,7 +8,7 @@ CFG2 = "--cfg2" in sys.argv
 _args = [a for a in sys.argv[1:] if not a.startswith("--")]
 _native.LIB_PATH = os.path.abspath(_args[0] if _args else "build/libnavsim_timing.so")
 from navbot_ppo_amd.env import NavSim
-names = ["start", "pre-A", "post-A", "pre-B", "post-B", "pre-C", "post-C", "end"]
+names = ["start", "pre-A", "post-A", "pre-B", "post-B", "pre-C", "pose-seen", "end"]
 if "--rollout" in sys.argv:   # the persistent rollout kernel: stamps of its LAST step + the whole launch
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
