@@ -259,6 +259,8 @@ def main():
     ap.add_argument("--policy", default="mlp64x2")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline legs")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="N > 1, mlp64x2: the two-stage per-net pipeline instead of one all-reduce of the flat gradient per epoch")
     args = ap.parse_args()
 
     from navbot_ppo_amd import ppo
@@ -280,7 +282,8 @@ def main():
     env = VecEnv(n_local, map="stage_1", n_beams=10, max_episode_steps=500, auto_reset=True, seed=0, env_id_base=lo,
                  device=ctx.device)
     cfg = ppo.PPOConfig(rollout_len=args.rollout, max_episode_steps=500, n_updates_per_iteration=args.epochs,
-                        policy=args.policy, use_graph=not args.no_graph, seed=0)
+                        policy=args.policy, use_graph=not args.no_graph, seed=0,
+                        overlap_allreduce=args.overlap_allreduce)
     trainer = ppo.PPOTrainer(env, cfg, ctx)
 
     for _ in range(args.warmup):

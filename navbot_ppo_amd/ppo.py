@@ -50,7 +50,11 @@ class PPOConfig:
     use_graph: bool = True                 # capture the T-step rollout in one hipGraph
     persistent_rollout: bool = True        # mlp64x2 on GPU: all T steps in ONE launch (navsim_rollout_mlp64)
     fused_update: bool = True              # on GPU: fused HIP loss+gradient kernels (csrc/ppo_mlp64.hip, csrc/ppo_resmlp512.hip)
-    overlap_allreduce: bool = True         # multi-GPU, mlp64x2: the actor's gradient all-reduce runs under the critic's pass
+    # multi-GPU, mlp64x2: False = fused passes of both nets -> ONE all-reduce of the flat gradient -> Adam (the default: at one
+    # RCCL rank this path costs 9-24 us per epoch over the single-GPU epoch, the per-net pipeline below 59-74 us, because two
+    # pass launches pay the ramp / staging / reduction of the fused one twice -- more than a 43 KB all-reduce costs on the wire);
+    # True = two-stage pipeline, each net's all-reduce under the other net's pass (_pipelined_epochs): hides the wire entirely
+    overlap_allreduce: bool = False
     output_dir: str = ""                   # "" = no checkpoints / logs
     episode_csv_rows: int = 2000           # per-iteration cap on rows appended to <method>_train_episodes.csv (0 = off)
     tb_episode_rows: int = 256             # per-iteration cap on Episode_Rewards/train points in the TensorBoard file (0 = off)
@@ -65,7 +69,10 @@ class DistCtx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.enabled = self.world > 1
+        # NAVBOT_DIST_FORCE=1: a single rank still creates its process group and sends every collective through the backend --
+        # on a one-GPU box this is how the RCCL branch (init with device_id, all-reduces on RCCL's stream, the overlap of the
+        # actor's all-reduce with the critic pass, navppo_adam_step's 1/world scale) is executed at all
+        self.enabled = self.world > 1 or os.environ.get("NAVBOT_DIST_FORCE") == "1"
         if device is None:
             if torch.cuda.is_available():
                 device = torch.device(f"cuda:{self.local_rank % torch.cuda.device_count()}")
@@ -264,17 +271,48 @@ class PPOUpdater:
         if rc != 0:
             raise RuntimeError(f"navppo_mlp64_loss_grad_net failed: {L.navppo_last_error().decode()}")
 
-    def _fused_adam(self, grad_scale):
+    def _fused_adam(self, grad_scale, lo=0, n=None, step=None):
+        """Scale + Adam on the flat buffer, or on the slice [lo, lo + n) at optimiser step `step` (one net of the pipelined epoch)."""
         import ctypes as C
         from ._native import lib
         L = lib()
-        ptr = lambda t: C.c_void_p(t.data_ptr())
-        self._adam_t += 1
-        rc = L.navppo_adam_step(ptr(self.fp.flat), ptr(self.fp.grad), ptr(self._adam_m), ptr(self._adam_v), int(self.fp.numel),
-                                float(grad_scale), float(self.cfg.lr), 0.9, 0.999, 1e-8, int(self._adam_t),
-                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        ptr = lambda t: C.c_void_p(t.data_ptr() + 4 * lo)
+        if step is None:
+            self._adam_t += 1
+            step = self._adam_t
+        rc = L.navppo_adam_step(ptr(self.fp.flat), ptr(self.fp.grad), ptr(self._adam_m), ptr(self._adam_v),
+                                int(self.fp.numel - lo if n is None else n), float(grad_scale), float(self.cfg.lr), 0.9, 0.999, 1e-8,
+                                int(step), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise RuntimeError(f"navppo_adam_step failed: {L.navppo_last_error().decode()}")
+
+    def _pipelined_epochs(self, n_ep, world, obs, acts, logp_old, rtg, adv, var_f):
+        """The multi-GPU epochs of the 2x64 heads as a two-stage pipeline.  Actor and critic are disjoint nets whose losses share
+        nothing inside the epoch loop (the advantages are fixed before it, ppo.py:275-284), so each net's all-reduce (RCCL's own
+        stream) runs under the OTHER net's pass -- the actor's under the critic's pass of the same epoch, the critic's under the
+        actor's pass of the next one -- and neither the wire time nor the cross-stream hand-over is on the compute stream's
+        critical path.  Same kernels on the same data as the unpipelined order: the weights are bit-identical."""
+        n_a = self._n_actor
+        n_c = self.fp.numel - n_a
+        t0 = self._adam_t
+        wa = wc = None
+        for ep in range(n_ep):
+            if wa is not None:   # epoch ep - 1's actor gradient has arrived (long ago: it had the critic's pass to do so)
+                wa.wait()
+                self._fused_adam(1.0 / world, 0, n_a, t0 + ep)
+            self._fused_loss_grad_net(0, obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
+            wa = dist.all_reduce(self.fp.grad[:n_a], op=dist.ReduceOp.SUM, async_op=True)
+            if wc is not None:
+                wc.wait()
+                self._fused_adam(1.0 / world, n_a, n_c, t0 + ep)
+            self._fused_loss_grad_net(1, obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
+            wc = dist.all_reduce(self.fp.grad[n_a:], op=dist.ReduceOp.SUM, async_op=True)
+        if wa is not None:
+            wa.wait()
+            self._fused_adam(1.0 / world, 0, n_a, t0 + n_ep)
+            wc.wait()
+            self._fused_adam(1.0 / world, n_a, n_c, t0 + n_ep)
+        self._adam_t = t0 + n_ep
 
     def _fused_value(self, obs):
         """V = critic(obs).squeeze() (ppo.py:275) by the forward half of the critic's fused pass."""
@@ -320,6 +358,7 @@ class PPOUpdater:
         A = rtg - V (ppo.py:275-277)."""
         cfg, ctx = self.cfg, self.ctx
         world = ctx.world if ctx is not None else 1
+        multi = ctx is not None and ctx.enabled   # collectives run (world > 1, or one rank forced through the backend)
         with torch.no_grad():
             if V0 is None:
                 V0 = self.value(obs)
@@ -334,21 +373,15 @@ class PPOUpdater:
             obs, acts, logp_old, rtg, adv = (t.contiguous() for t in (obs, acts, logp_old, rtg, adv))
             if self._fhist.shape[0] < n_ep:
                 self._fhist = torch.zeros((n_ep, 8), dtype=torch.float32, device=self.device)
+        pipelined = self.fused and multi and self.fused_mlp64 and cfg.overlap_allreduce
+        if pipelined:
+            self._pipelined_epochs(n_ep, world, obs, acts, logp_old, rtg, adv, var_f)
         for ep in range(n_ep):                                 # ppo.py:305
             if self.fused:
                 # per-epoch diagnostics land in row ep of a device buffer: no extra launches inside the epoch loop
-                if world > 1 and self.fused_mlp64 and cfg.overlap_allreduce:
-                    # actor pass -> its gradient slice goes on the wire (RCCL's own stream) while the critic pass computes ->
-                    # the critic's slice -> both awaited -> scale + Adam in one launch
-                    n_a = self._n_actor
-                    self._fused_loss_grad_net(0, obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
-                    wa = dist.all_reduce(self.fp.grad[:n_a], op=dist.ReduceOp.SUM, async_op=True)
-                    self._fused_loss_grad_net(1, obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
-                    wc = dist.all_reduce(self.fp.grad[n_a:], op=dist.ReduceOp.SUM, async_op=True)
-                    wa.wait()
-                    wc.wait()
-                    self._fused_adam(1.0 / world)
-                elif world > 1:   # fused passes -> ONE all-reduce of the flat gradient (RCCL) -> scale + Adam in one launch
+                if pipelined:
+                    pass   # all epochs ran above; only the diagnostics of the last one are gathered below
+                elif multi:   # fused passes -> ONE all-reduce of the flat gradient (RCCL) -> scale + Adam in one launch
                     self._fused_loss_grad(obs, acts, logp_old, rtg, adv, var_f, stats=self._fhist[ep])
                     ctx.all_reduce_sum(self.fp.grad)
                     self._fused_adam(1.0 / world)
@@ -367,7 +400,7 @@ class PPOUpdater:
             a_loss, c_loss, ratios, logp, _ = ppo_losses(self.actor, self.critic, obs, acts, logp_old, rtg, adv, var, cfg.clip)
             self.fp.grad.zero_()
             (a_loss + c_loss).backward()                       # disjoint nets: same grads as the two backward()s of :349,:386
-            if world > 1:
+            if multi:
                 ctx.all_reduce_sum(self.fp.grad)
                 self.fp.grad.div_(world)
             self.opt.step()                                    # ppo.py:381,392
@@ -378,13 +411,13 @@ class PPOUpdater:
                                     ((ratios.detach() - 1).abs() > cfg.clip).float().mean(),
                                     self.fp.grad.norm(), V0.mean()])
         acc = acc / max(n_ep, 1)
-        if ctx is not None and world > 1:
+        if multi:
             ctx.all_reduce_sum(acc)
             acc = acc / world
         n_a = self.fp.module_numel[0]
         d = self.fp.flat - flat_before
         extra = torch.stack(torch._foreach_norm([self.fp.grad[:n_a], self.fp.grad[n_a:], d[:n_a], d[n_a:]]))
-        if self.fused and world > 1:
+        if self.fused and multi:
             extra = extra * extra.new_tensor([1.0 / world, 1.0 / world, 1.0, 1.0])   # norms of the MEAN gradient, as on one GPU
         self.stats = dict(zip(["actor_loss", "critic_loss", "approx_kl", "clip_frac", "grad_norm", "value_mean",
                                "actor_grad_norm", "critic_grad_norm", "actor_param_delta", "critic_param_delta"],

@@ -287,7 +287,7 @@ def test_fused_value_matches_pytorch_critic():
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
 
 
-def _dp_gpu_worker(rank, world, port, path):
+def _dp_gpu_worker(rank, world, port, path, overlap=False):
     import os
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       NAVBOT_DIST_BACKEND="gloo")   # RCCL refuses two ranks on one device: gloo carries the all-reduce here
@@ -297,7 +297,8 @@ def _dp_gpu_worker(rank, world, port, path):
     torch.manual_seed(100 + rank)
     a, c = nets.make_policy("mlp64x2")
     a.cuda(), c.cuda()
-    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(n_updates_per_iteration=5, policy="mlp64x2"), ctx, torch.device("cuda:0"))
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(n_updates_per_iteration=5, policy="mlp64x2", overlap_allreduce=overlap), ctx,
+                        torch.device("cuda:0"))
     assert up.fused_mlp64
     lo, hi = ctx.shard(512)
     cu = lambda k: torch.from_numpy(d[k][lo:hi]).cuda()
@@ -307,9 +308,11 @@ def _dp_gpu_worker(rank, world, port, path):
     torch.distributed.destroy_process_group()
 
 
-def test_fused_multi_rank_epoch_equals_single_rank(tmp_path):
-    """The N > 1 update path on the GPU (fused passes -> one all-reduce of the flat gradient -> scale + Adam kernel) with two
-    ranks on shards of the G7 batch == the single-rank path (fused passes + in-kernel Adam) on the whole batch."""
+@pytest.mark.parametrize("overlap", [False, True])
+def test_fused_multi_rank_epoch_equals_single_rank(tmp_path, overlap):
+    """The N > 1 update path on the GPU (fused passes -> one all-reduce of the flat gradient -> scale + Adam kernel; overlap: the
+    two-stage per-net pipeline, each net's all-reduce under the other net's pass) with two ranks on shards of the G7 batch == the
+    single-rank path (fused passes + in-kernel Adam) on the whole batch."""
     import socket
     import torch.multiprocessing as mp
     from navbot_ppo_amd import nets, ppo
@@ -318,7 +321,7 @@ def test_fused_multi_rank_epoch_equals_single_rank(tmp_path):
     port = s.getsockname()[1]
     s.close()
     path = str(tmp_path / "dpg")
-    mp.spawn(_dp_gpu_worker, args=(2, port, path), nprocs=2, join=True)
+    mp.spawn(_dp_gpu_worker, args=(2, port, path, overlap), nprocs=2, join=True)
     r0, r1 = torch.load(path + ".0"), torch.load(path + ".1")
     assert torch.equal(r0["flat"], r1["flat"])
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_update.npz"))
@@ -329,6 +332,80 @@ def test_fused_multi_rank_epoch_equals_single_rank(tmp_path):
     cu = lambda k: torch.from_numpy(d[k]).cuda()
     up.update(cu("obs"), cu("acts"), cu("logp"), cu("rtgs"), torch.tensor(0.8, device="cuda"))
     np.testing.assert_allclose(r0["flat"].numpy(), up.fp.flat.cpu().numpy(), rtol=0, atol=3e-6)
+
+
+def _rccl_one_rank_worker(rank, port, path, policy, overlap):
+    import os
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NAVBOT_DIST_FORCE="1")
+    os.environ.pop("NAVBOT_DIST_BACKEND", None)
+    from navbot_ppo_amd import nets, ppo
+    ctx = ppo.DistCtx(device="cuda:0")
+    assert ctx.enabled and ctx.backend == "nccl" and ctx.rccl_version, (ctx.enabled, ctx.backend, ctx.rccl_version)
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_update.npz"))
+    torch.manual_seed(100)
+    a, c = nets.make_policy(policy)
+    a.cuda(), c.cuda()
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(n_updates_per_iteration=5, policy=policy, overlap_allreduce=overlap), ctx,
+                        torch.device("cuda:0"))
+    assert up.fused_mlp64 or up.fused_resmlp512
+    cu = lambda k: torch.from_numpy(d[k]).cuda()
+    stats = up.update(cu("obs"), cu("acts"), cu("logp"), cu("rtgs"), torch.tensor(0.8, device="cuda"))
+    t = torch.tensor([3.0, 5.0], device="cuda")
+    ctx.all_reduce_max(t), ctx.broadcast(t), ctx.barrier()
+    torch.cuda.synchronize()
+    torch.save({"flat": up.fp.flat.cpu(), "rccl": ctx.rccl_version, "grad_norm": float(stats.get("grad_norm", 0.0))}, path)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy,overlap", [("mlp64x2", False), ("mlp64x2", True), ("resmlp512", False)])
+def test_update_through_rccl_single_rank(tmp_path, policy, overlap):
+    """The multi-GPU update path with torch's `nccl` backend (= RCCL) really executing: one rank (a one-GPU box; RCCL refuses
+    two ranks on one device), process group created with device_id, fused passes -> one all-reduce of the flat gradient (with
+    overlap: the per-net pipeline, each net's all-reduce under the other net's pass) -> navppo_adam_step, plus max-reduce /
+    broadcast / barrier.  Must equal the single-process path (fused passes + in-kernel Adam) on the same batch."""
+    import socket
+    import torch.multiprocessing as mp
+    from navbot_ppo_amd import nets, ppo
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    path = str(tmp_path / "rccl1.pt")
+    mp.spawn(_rccl_one_rank_worker, args=(port, path, policy, overlap), nprocs=1, join=True)
+    r = torch.load(path)
+    assert r["rccl"] and r["rccl"] != "unknown"
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_update.npz"))
+    torch.manual_seed(100)
+    a, c = nets.make_policy(policy)
+    a.cuda(), c.cuda()
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(n_updates_per_iteration=5, policy=policy), None, torch.device("cuda:0"))
+    cu = lambda k: torch.from_numpy(d[k]).cuda()
+    stats = up.update(cu("obs"), cu("acts"), cu("logp"), cu("rtgs"), torch.tensor(0.8, device="cuda"))
+    np.testing.assert_allclose(r["flat"].numpy(), up.fp.flat.cpu().numpy(), rtol=0, atol=3e-6)
+    if "grad_norm" in stats:
+        np.testing.assert_allclose(r["grad_norm"], float(stats["grad_norm"]), rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_over_rccl(tmp_path):
+    """bench.py launched the way the driver launches N > 1 (torch.distributed.run), with one rank forced through RCCL: the
+    whole N > 1 code path of the bench (DistCtx over nccl, barriers, max-over-ranks timing, per-epoch all-reduces) runs on the
+    GPU and prints the contract line with rccl_ranks = 1."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NAVBOT_DIST_FORCE="1")
+    env.pop("NAVBOT_DIST_BACKEND", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--no-extras"], capture_output=True, text=True, env=env, timeout=600, cwd=repo)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["dist_backend"] == "nccl" and r["rccl_ranks"] == 1 and r["rccl_version"], r
+    assert r["n_gpus"] == 1 and r["value"] > 1e6
 
 
 @pytest.mark.gpu
