@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NAVSIM_ABI_VERSION 3
+#define NAVSIM_ABI_VERSION 4
 
 #define NAVSIM_OK 0
 #define NAVSIM_E_ARG (-1)   /* bad argument / unsupported configuration */
@@ -206,6 +206,21 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
                          float* logp_buf_dev, float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,
                          float* ep_return_dev, int32_t* ep_length_dev, float* ep_path_dev, const float* var_dev,
                          uint64_t act_seed, const uint32_t* step_base_dev, int32_t n_steps, void* stream);
+
+/*
+ * n_steps calls of navsim_step with the actions of a tape, in ONE launch: the step loop of PPO.rollout (ppo.py:505-594) or of the
+ * evaluation loop (main.py:176-235) when the actions do not depend on the observations being produced -- a recorded tape, a
+ * scripted or random policy, an open-loop controller.  A workgroup keeps its envs for the whole tape (their state stays on chip
+ * between the steps), so the launch ramp, the state round trips and the kernel boundaries of n_steps launches are paid once.
+ *   actions_dev [n_steps, N, 2] f32 (8-byte aligned); row t is the `action_dev` of step t (past_action = the action executed before)
+ *   obs_dev     [n_steps, N, B+6] f32 (f16 if cfg.obs_f16): the observation AFTER step t, as navsim_step writes it
+ *   reward_dev / done_dev / arrive_dev / ended_dev (nullable)  [n_steps, N]
+ *   ep_return_dev / ep_length_dev / ep_path_dev  [n_steps, N], nullable, written where ended (as in navsim_step)
+ * Every row is bit-identical to what n_steps navsim_step calls write; the handle's state afterwards is the same too.
+ */
+int navsim_step_seq(navsim_t* h, const float* actions_dev, int32_t n_steps, void* obs_dev, float* reward_dev, uint8_t* done_dev,
+                    uint8_t* arrive_dev, uint8_t* ended_dev, float* ep_return_dev, int32_t* ep_length_dev, float* ep_path_dev,
+                    void* stream);
 
 /*
  * Env.getOdometry()  (environment_new.py:138-181) on its own, for n independent samples -- the odometry callback's arithmetic

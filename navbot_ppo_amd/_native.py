@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NAVSIM_LIB: another build of the same library (tools/build_variant.py A/B timing); never a different implementation
 LIB_PATH = os.environ.get("NAVSIM_LIB") or os.path.join(_HERE, "libnavsim.so")
 
-NAVSIM_ABI_VERSION = 3
+NAVSIM_ABI_VERSION = 4
 
 
 class NavsimError(RuntimeError):
@@ -55,6 +55,7 @@ SYMBOLS = [
     ("navsim_raycast", C.c_int, [_vp, _vp, _vp, _vp]),
     ("navsim_odometry", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("navsim_rollout_mlp64", C.c_int, [_vp] * 13 + [C.c_uint64, _vp, _i32, _vp]),
+    ("navsim_step_seq", C.c_int, [_vp, _vp, _i32] + [_vp] * 9),
     # include/navppo.h
     ("navppo_last_error", C.c_char_p, []),
     ("navppo_mlp64_workspace_bytes", C.c_size_t, []),

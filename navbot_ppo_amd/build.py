@@ -32,14 +32,42 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build_native(force=False, verbose=False):
-    if not force and not needs_build():
+# per-source flags.  navsim.hip: its persistent kernels (rollout_kernel, steps_kernel) inline the whole step body into a loop over
+# steps, and MachineLICM then hoists every 64-bit constant the body materialises (the float64 polynomial coefficients of sincos,
+# atan, ...) out of that loop and keeps them in registers across it: 200-256 VGPRs and scratch spills in the 16-wave shape,
+# against 82-101 VGPRs (two workgroups per CU) with the pass off.  The single-step kernels have no such loop and do not change.
+EXTRA_FLAGS = {"navsim.hip": ["-mllvm", "-disable-machine-licm"]}
+
+
+def build_native(force=False, verbose=False, navsim_src=None, out=None, extra=()):
+    """navsim_src / out / extra: dev tools build variants of csrc/navsim.hip (patched copies, instrumented builds) as another
+    library with exactly the product's flags."""
+    if navsim_src is None and not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-I", INC] + SRCS + ["-o", LIB]
+    tag = "" if navsim_src is None else "_" + os.path.splitext(os.path.basename(out))[0]
+    objdir = os.path.join(REPO, "build", "obj" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    procs, objs = [], []
+    srcs = SRCS if navsim_src is None else [navsim_src] + SRCS[1:]
+    lib_out = LIB if out is None else out
+    for k, src in enumerate(srcs):   # the sources compile side by side
+        obj = os.path.join(objdir, os.path.basename(SRCS[k]) + ".o")
+        per_src = [] if os.environ.get("NAVSIM_NO_EXTRA_FLAGS") == "1" else EXTRA_FLAGS.get(os.path.basename(SRCS[k]), [])   # (A/B builds)
+        cmd = ([hipcc()] + compile_flags + per_src + (list(extra) if k == 0 else []) +
+               ["-I", INC, "-I", os.path.join(HERE, "csrc"), "-c", src, "-o", obj])
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", lib_out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib_out
 
 
 if __name__ == "__main__":

@@ -447,6 +447,8 @@ __device__ __forceinline__ float write_lidar(float* row, const float* best, int 
 // NW: waves per workgroup (4; the persistent rollout kernel, one workgroup per CU, runs 8 for a shorter cast).
 // BOXES: shared map with tile bounding boxes (Params::tile_box): whole 64-segment tiles that lie behind the beam fan or out of
 // range are skipped without being loaded (the house map: 32 tiles, ~5 of them near any one pose).
+// row0: element offset of this step's row in the [T, N] output buffers `io` points at (navsim_step_seq: t N; the pointers are
+// then read from the kernarg segment at their use instead of living in SGPRs through the body; 0 elsewhere).
 // PRef / IORef: how the parameter block and the I/O pointers are reached.  The persistent rollout passes plain references to its
 // own copies.  step_kernel passes references into the kernarg segment (constant address space) behind a compiler barrier: every
 // field is then a scalar load AT ITS USE.  As ordinary by-value kernel parameters all ~100 dwords were loaded and spilled to
@@ -463,7 +465,8 @@ struct StepIO {
 };
 template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4, bool BOXES = false, bool PAIR = false, class PRef = const Params&,
           class IORef = const StepIO&>
-__device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int& next_env, IORef io, const bool last_step = true) {
+__device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int& next_env, IORef io, const bool last_step = true,
+                                          const size_t row0 = 0) {
     static_assert(EPB <= 64 && EPB >= 4 && NB % 2 == 0, "EPB / NB");
     static_assert(!(PAIR && BOXES), "tile boxes describe 64-segment tiles");
     constexpr int kThreads = 64 * NW;
@@ -1137,14 +1140,14 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         double ret = ret0 + r;
         const bool timeout = (P.max_ep_steps > 0) && ((int)step >= P.max_ep_steps);  // ppo.py:552
         const bool end = d || a || timeout;
-        io.reward[i] = (float)r;
-        io.done[i] = d ? 1 : 0;
-        io.arrive[i] = a ? 1 : 0;
-        if (io.ended) io.ended[i] = end ? 1 : 0;
+        io.reward[row0 + i] = (float)r;
+        io.done[row0 + i] = d ? 1 : 0;
+        io.arrive[row0 + i] = a ? 1 : 0;
+        if (io.ended) io.ended[row0 + i] = end ? 1 : 0;
         if (end) {
-            if (io.ep_return) io.ep_return[i] = (float)ret;
-            if (io.ep_length) io.ep_length[i] = (int32_t)step;
-            if (io.ep_path_out) io.ep_path_out[i] = (float)path;   // ppo.py:533-537: the final step's displacement is never added
+            if (io.ep_return) io.ep_return[row0 + i] = (float)ret;
+            if (io.ep_length) io.ep_length[row0 + i] = (int32_t)step;
+            if (io.ep_path_out) io.ep_path_out[row0 + i] = (float)path;   // ppo.py:533-537: the final step's displacement is never added
         }
         path += sm.sv_d[11][e];
         float2 next_pact = act;  // ppo.py:543
@@ -1194,10 +1197,10 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     // ---------------- coalesced store of the block's observation tile
     const int n_out = nloc * D;
     if (P.obs_f16) {
-        __half* o = reinterpret_cast<__half*>(io.obs_out) + (size_t)base * D;
+        __half* o = reinterpret_cast<__half*>(io.obs_out) + (row0 + (size_t)base) * D;
         for (int k = tid; k < n_out; k += kThreads) o[k] = __float2half_rn(sm.obs[(k / D) * DP + (k % D)]);
     } else {
-        float* o = reinterpret_cast<float*>(io.obs_out) + (size_t)base * D;
+        float* o = reinterpret_cast<float*>(io.obs_out) + (row0 + (size_t)base) * D;
         for (int k = tid; k < n_out; k += kThreads) o[k] = sm.obs[(k / D) * DP + (k % D)];
     }
 }
@@ -1314,6 +1317,66 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
                            R.ep_path ? R.ep_path + tn : nullptr};
         step_body<NB, EPB, SENS, true, NW>(P, sm, next_env, io, t == R.T - 1);
         // the observation tile of step t + 1 is in sm.obs; its store only reads it, like the next policy phase
+    }
+}
+
+// ---------------------------------------------------------------- n steps of an action tape in ONE launch (navsim_step_seq)
+// The step loop of PPO.rollout / the evaluation loop (ppo.py:505-594, main.py:176-235) when the actions are already known -- a
+// recorded tape, a scripted or random policy: a workgroup keeps its envs for all n steps, their state lives in LDS between the
+// steps (HBM sees it before the first and after the last), and the steps follow each other with workgroup barriers only.  What a
+// step kernel launch pays around its cast -- the launch ramp of 256 x 16 waves, the kernarg and state round trips ahead of the
+// pose, the boundary between two graph nodes -- is paid once per tape; the segment stream of step t + 1 is requested while the
+// pose of step t + 1 is computed.  Same step_body, same workgroup shapes as step_kernel: the rows are bit-identical to n
+// navsim_step calls.  (Built with MachineLICM off, navbot_ppo_amd/build.py: the pass hoists the float64 constants of the whole
+// step body out of the step loop and holds them in 60+ registers across it -- spills in the 16-wave shape, 11.3 instead of 9.4 us
+// per step at configs[2].)
+struct SeqArgs {
+    StepIO io;   // the [T, N, .] buffers: action = the tape, obs_out [T, N, B + 6] (f32 or f16), reward / flags / episode statistics
+                 // [T, N] (nullable as in navsim_step); step_body addresses row t through its row0 argument
+    int T;
+};
+struct SeqKArgs {
+    Params P;
+    SeqArgs R;
+};
+typedef const SeqKArgs __attribute__((address_space(4))) * SeqKArgsPtr;
+
+template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, bool PAIR = false>
+__global__ __launch_bounds__(64 * NW) void steps_kernel(Params, SeqArgs) {
+    __shared__ StepSmem<NB, EPB, NW> sm;
+    __shared__ int next_env;
+    // parameters through the kernarg segment pointer, as in step_kernel (scalar loads at each use, no spilled SGPRs)
+    SeqKArgsPtr A = (SeqKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(A));
+    const Params __attribute__((address_space(4)))& P = A->P;
+    const SeqArgs __attribute__((address_space(4)))& R = A->R;
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * EPB;
+    const int nloc = min(EPB, P.N - base);
+    const int T = R.T;
+    float2 a_next = make_float2(0.f, 0.f);
+    if (tid < nloc) {   // the envs' state: HBM -> LDS for the whole tape; the first action
+        const int e = tid, i = base + e;
+        a_next = R.io.action[i];
+        sm.st_d[0][e] = P.x[i]; sm.st_d[1][e] = P.y[i]; sm.st_d[2][e] = P.th[i]; sm.st_d[3][e] = P.gx[i]; sm.st_d[4][e] = P.gy[i];
+        sm.st_d[5][e] = P.past_dist[i]; sm.st_d[6][e] = P.ep_ret[i]; sm.st_d[7][e] = P.ep_path[i];
+        sm.st_pact[e] = P.past_action[i];
+        sm.st_step[e] = (uint32_t)P.ep_step[i];
+        sm.st_ctr[e] = P.rng_ctr[i];
+    }
+    for (int k = tid; k < 2 * NB; k += 64 * NW) sm.beam[k] = P.beam_cs[k];
+    for (int k = tid; k < (int)(sizeof(Rects) / 8); k += 64 * NW)
+        reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
+    for (int t = 0; t < T; ++t) {
+        const size_t N = (size_t)P.N;
+        const size_t tn = (size_t)t * N;
+        if (tid < nloc) {
+            sm.act_l[tid] = a_next;
+            if (t + 1 < T) a_next = R.io.action[tn + N + base + tid];   // lands under this step
+        }
+        __syncthreads();
+        step_body<NB, EPB, SENS, true, NW, BOXES, PAIR, const Params __attribute__((address_space(4)))&,
+                  const StepIO __attribute__((address_space(4)))&>(P, sm, next_env, R.io, t == T - 1, tn);
     }
 }
 
@@ -1636,6 +1699,42 @@ static void launch_step(const navsim* h, const float* action, const float* past,
     }
 #undef NAVSIM_GO
 }
+
+// navsim_step_seq: the same shapes and cast variants, all steps of the tape in one launch
+template <int NB>
+static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st) {
+    const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
+    auto go = [&](auto kernel, int epb, int nw) {
+        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, h->P, R);
+    };
+    const int epb = pick_epb(h->P.N);   // the shapes and cast variants of launch_step
+    const bool boxes = h->P.tile_box != nullptr;
+    const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
+#define NAVSIM_GO(EPB_, NW_)                                                                          \
+    do {                                                                                              \
+        if (boxes) {                                                                                  \
+            if (sens) go(steps_kernel<NB, EPB_, true, NW_, true>, EPB_, NW_);                         \
+            else go(steps_kernel<NB, EPB_, false, NW_, true>, EPB_, NW_);                             \
+        } else if (pair) {                                                                            \
+            if (sens) go(steps_kernel<NB, EPB_, true, NW_, false, true>, EPB_, NW_);                  \
+            else go(steps_kernel<NB, EPB_, false, NW_, false, true>, EPB_, NW_);                      \
+        } else {                                                                                      \
+            if (sens) go(steps_kernel<NB, EPB_, true, NW_, false>, EPB_, NW_);                        \
+            else go(steps_kernel<NB, EPB_, false, NW_, false>, EPB_, NW_);                            \
+        }                                                                                             \
+    } while (0)
+    if (epb == 8) {
+        NAVSIM_GO(8, 4);
+    } else if (epb == 32 || (epb == 64 && NB > 10)) {
+        NAVSIM_GO(32, 8);
+    } else if (epb == 64) {
+        if constexpr (NB == 10) NAVSIM_GO(64, 16);
+    } else {
+        NAVSIM_GO(16, 4);
+    }
+#undef NAVSIM_GO
+}
+
 
 static int invalidate_records(navsim* h, hipStream_t st) {
     hipLaunchKernelGGL(invalidate_records_kernel, dim3((h->P.N + 255) / 256), dim3(256), 0, st, h->P.ep_step, h->P.N);
@@ -1997,6 +2096,24 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
         if (sens) hipLaunchKernelGGL((rollout_kernel<16, true, kRollWaves>), grid, block, 0, st, h->P, R);
         else hipLaunchKernelGGL((rollout_kernel<16, false, kRollWaves>), grid, block, 0, st, h->P, R);
     }
+    HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
+}
+
+int navsim_step_seq(navsim_t* h, const float* actions_dev, int32_t n_steps, void* obs_dev, float* reward_dev, uint8_t* done_dev,
+                    uint8_t* arrive_dev, uint8_t* ended_dev, float* ep_return_dev, int32_t* ep_length_dev, float* ep_path_dev,
+                    void* stream) {
+    if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev || !arrive_dev || n_steps < 0)
+        return fail(NAVSIM_E_ARG, "navsim_step_seq: bad argument");
+    if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_step_seq: call navsim_set_map first");
+    if ((uintptr_t)actions_dev & 7) return fail(NAVSIM_E_ARG, "navsim_step_seq: actions must be 8-byte aligned");
+    if (n_steps == 0) return NAVSIM_OK;
+    SeqArgs R;
+    R.io = StepIO{reinterpret_cast<const float2*>(actions_dev), nullptr, obs_dev, reward_dev, done_dev, arrive_dev, ended_dev,
+                  ep_return_dev, ep_length_dev, ep_path_dev};
+    R.T = n_steps;
+    if (h->P.B == 10) launch_steps<10>(h, R, (hipStream_t)stream);
+    else launch_steps<36>(h, R, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;
 }

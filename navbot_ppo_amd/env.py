@@ -126,6 +126,19 @@ class NavSim:
                                     _ptr(arrive), _ptr(ended), _ptr(ep_return), _ptr(ep_length), _ptr(ep_path), _stream()),
                   "navsim_step")
 
+    def step_seq(self, actions, obs, reward, done, arrive, ended=None, ep_return=None, ep_length=None, ep_path=None):
+        """All steps of an action tape in ONE launch (navsim_step_seq): actions [T, N, 2] float32; every output is [T, N, ...]
+        and row t is what ``step(actions[t], ...)`` would have written.  For loops whose actions do not depend on the
+        observations they produce (recorded tapes, scripted / random policies): the workgroups keep their envs on chip
+        between the steps, so the launch ramp and the kernel boundaries of T launches are paid once."""
+        T = int(actions.shape[0])
+        assert actions.shape == (T, self.N, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
+        for buf in (obs, reward, done, arrive, ended, ep_return, ep_length, ep_path):
+            assert buf is None or (buf.shape[0] == T and buf.shape[1] == self.N and buf.is_contiguous())
+        with torch.cuda.device(self.device):
+            check(lib().navsim_step_seq(self._h, _ptr(actions), T, _ptr(obs), _ptr(reward), _ptr(done), _ptr(arrive), _ptr(ended),
+                                        _ptr(ep_return), _ptr(ep_length), _ptr(ep_path), _stream()), "navsim_step_seq")
+
     def raycast(self, pose):
         pose = pose.to(device=self.device, dtype=torch.float64).contiguous()
         out = torch.empty((self.N, self.B), dtype=torch.float32, device=self.device)

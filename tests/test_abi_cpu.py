@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     bound = {n for n, _, _ in _native.SYMBOLS}
     assert set(declared) == bound, (set(declared) ^ bound)
-    assert lib.navsim_version() == 3
+    assert lib.navsim_version() == 4
 
 
 def test_default_cfg_matches_reference_constants():

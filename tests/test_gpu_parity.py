@@ -843,3 +843,114 @@ def test_gae_scan(T, N, monkeypatch):
             np.testing.assert_allclose(adv.cpu().numpy(), want.astype(np.float32) - V, rtol=0, atol=3e-4)
             adv2, none = gae_scan(cu(rew), cu(ended), cu(V), 0.99, lam, last_value=None if lv is None else cu(lv), want_returns=False)
             assert none is None and torch.equal(adv2, adv)
+
+
+def _seq_vs_steps(N, seg, per_env, T, B=10, sampler=None, rects=None, **kw):
+    """navsim_step_seq against T navsim_step launches from the same start: every output row and the final state bit for bit."""
+    from navbot_ppo_amd.env import NavSim
+    rng = np.random.default_rng(5)
+    acts = torch.from_numpy(_actions(rng, T, N)).cuda()
+    outs = []
+    for mode in ("steps", "seq"):
+        s = NavSim(N, n_beams=B, seed=3, **kw)
+        if rects:
+            rr, rs = maps.goal_rects(rects)
+            s.set_goal_rects(0, rr)
+            s.set_goal_rects(1, rs)
+        s.set_map(seg, per_env=per_env)
+        if sampler:
+            s.set_spawn_sampler(*sampler)
+        io = s.alloc_io()
+        s.reset(io.obs)
+        dev = s.device
+        buf = dict(obs=torch.zeros((T, N, s.D), dtype=s.obs_dtype, device=dev), reward=torch.zeros((T, N), device=dev),
+                   done=torch.zeros((T, N), dtype=torch.uint8, device=dev), arrive=torch.zeros((T, N), dtype=torch.uint8, device=dev),
+                   ended=torch.zeros((T, N), dtype=torch.uint8, device=dev), ep_return=torch.zeros((T, N), device=dev),
+                   ep_length=torch.zeros((T, N), dtype=torch.int32, device=dev), ep_path=torch.zeros((T, N), device=dev))
+        if mode == "steps":
+            for t in range(T):
+                s.step(acts[t], buf["obs"][t], buf["reward"][t], buf["done"][t], buf["arrive"][t], buf["ended"][t],
+                       buf["ep_return"][t], buf["ep_length"][t], ep_path=buf["ep_path"][t])
+        else:
+            s.step_seq(acts, buf["obs"], buf["reward"], buf["done"], buf["arrive"], buf["ended"], buf["ep_return"],
+                       buf["ep_length"], buf["ep_path"])
+        torch.cuda.synchronize()
+        outs.append(({k: v.cpu() for k, v in buf.items()}, s.get_state()))
+        s.close()
+    (a, sa), (b, sb) = outs
+    for k in a:
+        assert torch.equal(a[k].view(torch.uint8) if a[k].dtype == torch.float16 else a[k], b[k].view(torch.uint8) if b[k].dtype == torch.float16 else b[k]), k
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    return a
+
+
+@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg4", "cfg5", "small", "ragged", "sens", "no_reset"])
+def test_step_seq_equals_step_launches(case):
+    """One launch for a whole action tape (navsim_step_seq: env state on chip between the steps) == one navsim_step launch per
+    step, bit for bit, in every workgroup shape and cast variant: configs[1] (32-env shape, shared 32 segments), configs[2]
+    (64-env shape, per-env 128 segments, two-segments-per-lane passes), configs[3]'s shard (36 beams), configs[4]'s shard (tile
+    boxes, f16 observations, start / goal tables), a 16-env-shape case, ragged N, the sensor options, and no auto-reset."""
+    if case == "cfg2":
+        a = _seq_vs_steps(4096, maps.stage_1(), False, 40, max_episode_steps=25, auto_reset=True, respawn_on_arrive=True)
+    elif case == "cfg3":
+        a = _seq_vs_steps(16384, maps.replicate_per_env(maps.stage_2(), 16384, seed=0), True, 30, rects="stage_2", max_episode_steps=20,
+                          auto_reset=True)
+    elif case == "cfg4":
+        a = _seq_vs_steps(4096, maps.stage_4(), False, 30, B=36, max_episode_steps=20, auto_reset=True)
+    elif case == "cfg5":
+        seg = maps.house(2048)
+        st, g, lo, hi = maps.spawn_tables("small_house")
+        a = _seq_vs_steps(8192, seg, False, 24, sampler=maps.open_tables(seg, st, g) + (lo, hi), max_episode_steps=15, auto_reset=True,
+                          obs_f16=True)
+    elif case == "small":
+        a = _seq_vs_steps(96, maps.replicate_per_env(maps.stage_2(), 96, seed=1), True, 60, max_episode_steps=30, auto_reset=True,
+                          respawn_on_arrive=True)
+    elif case == "ragged":
+        a = _seq_vs_steps(1000, maps.stage_1(), False, 33, max_episode_steps=16, auto_reset=True)
+    elif case == "sens":
+        a = _seq_vs_steps(512, maps.stage_1(), False, 40, max_episode_steps=25, auto_reset=True, lidar_noise_sigma=0.01,
+                          lidar_below_min="gazebo")
+    else:
+        a = _seq_vs_steps(256, maps.stage_1(), False, 50, respawn_on_arrive=True)
+    assert int(a["ended"].sum()) > 0 or case == "no_reset"
+
+
+def test_step_seq_against_the_oracle():
+    """navsim_step_seq checked DIRECTLY against the CPU oracle (not only against the per-step launches): 48 steps of 512 envs on
+    per-env stage_2 maps with auto-reset and arrival re-spawn; flags exact, observations 1e-6, rewards, episode statistics."""
+    N, T = 512, 48
+    seg = maps.replicate_per_env(maps.stage_2(), N, seed=2)
+    gpu, cpu = _mk(N, seg, per_env=True, max_episode_steps=20, auto_reset=True, respawn_on_arrive=True, seed=9)
+    rng = np.random.default_rng(11)
+    acts = _actions(rng, T, N)
+    io = gpu.alloc_io()
+    gpu.reset(io.obs)
+    cpu.reset()
+    dev = gpu.device
+    obs = torch.zeros((T, N, gpu.D), device=dev)
+    rew, epr, epp = (torch.zeros((T, N), device=dev) for _ in range(3))
+    done, arrive, ended = (torch.zeros((T, N), dtype=torch.uint8, device=dev) for _ in range(3))
+    epl = torch.zeros((T, N), dtype=torch.int32, device=dev)
+    gpu.step_seq(torch.from_numpy(acts).to(dev), obs, rew, done, arrive, ended, epr, epl, epp)
+    torch.cuda.synchronize()
+    exact = 0
+    for t in range(T):
+        out = cpu.step(acts[t])
+        np.testing.assert_array_equal(done[t].cpu().numpy(), out["done"])
+        np.testing.assert_array_equal(arrive[t].cpu().numpy(), out["arrive"])
+        np.testing.assert_array_equal(ended[t].cpu().numpy(), out["ended"])
+        og = obs[t].cpu().numpy()
+        np.testing.assert_allclose(og, out["obs"], rtol=0, atol=OBS_ATOL)
+        np.testing.assert_allclose(rew[t].cpu().numpy(), out["reward"], rtol=REW_RTOL, atol=1e-5)
+        e = out["ended"].astype(bool)
+        np.testing.assert_array_equal(epl[t].cpu().numpy()[e], out["ep_length"][e])
+        np.testing.assert_allclose(epr[t].cpu().numpy()[e], out["ep_return"][e], rtol=REW_RTOL, atol=1e-4)
+        np.testing.assert_allclose(epp[t].cpu().numpy()[e], out["ep_path"][e], rtol=1e-6, atol=1e-7)
+        exact += int((og == out["obs"]).all(axis=1).sum())
+    assert exact > 0.99 * T * N
+    sg, sc = gpu.get_state(), cpu.get_state()
+    np.testing.assert_allclose(sg["pose"], sc["pose"], rtol=0, atol=1e-11)
+    np.testing.assert_array_equal(sg["goal"], sc["goal"])
+    np.testing.assert_array_equal(sg["ep_step"], sc["ep_step"])
+    np.testing.assert_array_equal(sg["rng_ctr"], sc["rng_ctr"])

@@ -14,8 +14,7 @@ if len(sys.argv) > 2:
         t = t.replace(old, new)
 src = f"/tmp/navsim_{name}.hip"
 open(src, "w").write(t)
-out = os.path.join(R, "build", f"libnavsim_{name}.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
-                       "-shared", "-fvisibility=hidden", "-I", os.path.join(R, "include"), "-I", os.path.join(R, "navbot_ppo_amd/csrc"), src,
-                       os.path.join(R, "navbot_ppo_amd/csrc/ppo_mlp64.hip"), os.path.join(R, "navbot_ppo_amd/csrc/ppo_resmlp512.hip"), "-o", out])
-print(out)
+os.makedirs(os.path.join(R, "build"), exist_ok=True)
+sys.path.insert(0, R)
+from navbot_ppo_amd.build import build_native   # the product's flags, per source
+print(build_native(navsim_src=src, out=os.path.join(R, "build", f"libnavsim_{name}.so")))

@@ -45,8 +45,6 @@ if "--lb4" in extra_flags:
     rep("__global__ __launch_bounds__(kThreads) void step_kernel", "__global__ __launch_bounds__(kThreads, 4) void step_kernel")
 os.makedirs(os.path.join(R, "build"), exist_ok=True)
 open("/tmp/navsim_timing.hip", "w").write(t)
-out = os.path.join(R, "build", OUT)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-                       "-fvisibility=hidden", "-I", os.path.join(R, "include"), "-I", os.path.join(R, "navbot_ppo_amd/csrc"), "/tmp/navsim_timing.hip",
-                       os.path.join(R, "navbot_ppo_amd/csrc/ppo_mlp64.hip"), os.path.join(R, "navbot_ppo_amd/csrc/ppo_resmlp512.hip"), "-o", out])
-print(out)
+sys.path.insert(0, R)
+from navbot_ppo_amd.build import build_native   # the product's flags, per source
+print(build_native(navsim_src="/tmp/navsim_timing.hip", out=os.path.join(R, "build", OUT)))
