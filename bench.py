@@ -15,9 +15,11 @@ policy, seeded goals).  Default: weak scaling, every GPU owns its own 4096-env s
 are independent envs).  `--scaling strong` keeps 4096 envs IN TOTAL (SURVEY.md 8d(i) read literally): shards of 4096 / N.
 
 Besides the contract fields, rank 0 adds
-  roofline            step kernel on BASELINE configs[2] (16384 envs, per-env stage_2 segment buffers, S=128): algorithmic
-                      bytes (134 + 16*S per env-step) / mean launch duration from HIP events
-  roofline_beyond_l3  the same kernel with S=1024 per env (268 MB working set: past the 256 MiB Infinity Cache)
+  roofline            the ray-cast run of BASELINE configs[2] (16384 envs, per-env stage_2 segment buffers, S=128) as ONE launch per
+                      256-step action tape (navsim_step_seq, steps_kernel): algorithmic bytes (134 + 16*S per env-step, SURVEY.md
+                      8d) x env-steps per launch / mean launch duration from HIP events
+  roofline_single_launch   the same step body launched once per step (navsim_step, step_kernel), 64 launches per graph replay
+  roofline_beyond_l3 (+ _single_launch)   the same kernels with S=1024 per env (268 MB per step: past the 256 MiB Infinity Cache)
   roofline_timed_region   the persistent rollout kernel of the timed workload
   time_to_reward_s    PPO wall-clock until mean episode return >= +100 (ppo.py:833) from a fresh policy
   resmlp512           the same iteration with the reference's active 512-wide residual nets (fused f32-MFMA kernels of
@@ -97,6 +99,51 @@ def step_kernel_roofline(n_envs, map_name, per_env, iters=640, seed=0, sides=Non
                 achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
                 traffic=None, launch_us=round(ms * 1e3, 3), algorithmic_bytes_per_launch=int(alg_bytes),
                 bytes_per_env_step=bytes_per_env_step, env_steps_per_sec=round(n_envs / (ms * 1e-3), 1))
+
+
+def step_seq_roofline(n_envs, map_name, per_env, T, reps=12, seed=0, sides=None, detail=""):
+    """HIP-event timing of navsim_step_seq: T steps of a random action tape (resident in HBM) per launch, the env state on chip
+    between the steps.  Algorithmic bytes per launch = T x n_envs x (134 + 16 S) (SURVEY.md 8(d) per env-step)."""
+    from navbot_ppo_amd import maps
+    from navbot_ppo_amd.env import NavSim
+    seg = maps.stage_2(sides=sides) if sides else maps.by_name(map_name)
+    S = int(seg.shape[0])
+    sim = NavSim(n_envs, max_episode_steps=500, auto_reset=True, seed=seed)
+    rr, rs = maps.goal_rects(map_name)
+    sim.set_goal_rects(0, rr)
+    sim.set_goal_rects(1, rs)
+    sim.set_map(maps.replicate_per_env(seg, n_envs, seed=seed) if per_env else seg)
+    io = sim.alloc_io()
+    sim.reset(io.obs)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    acts = torch.rand((T, n_envs, 2), device="cuda", generator=g)
+    acts[..., 1] = acts[..., 1] * 2 - 1
+    obs = torch.zeros((T, n_envs, sim.D), device="cuda")
+    rew, epr = torch.zeros((T, n_envs), device="cuda"), torch.zeros((T, n_envs), device="cuda")
+    done, arrive, ended = (torch.zeros((T, n_envs), dtype=torch.uint8, device="cuda") for _ in range(3))
+    epl = torch.zeros((T, n_envs), dtype=torch.int32, device="cuda")
+    launch = lambda: sim.step_seq(acts, obs, rew, done, arrive, ended, epr, epl)
+    for _ in range(2):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    bytes_per_env_step = 134 + (16 * S if per_env else 0)  # SURVEY.md 8(d)
+    alg_bytes = T * n_envs * bytes_per_env_step + (0 if per_env else 16 * S)
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    sim.close()
+    return dict(bound="hbm", bound_detail=detail,
+                kernel="steps_kernel<10,%s> (navsim_step_seq: %d steps per launch, same step body as step_kernel)" % ("per_env" if per_env else "shared", T),
+                workload=f"{n_envs} envs x {T} steps, {map_name} ({S} segments, {'per-env' if per_env else 'shared'} map), 10 beams",
+                achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                launch_us=round(ms * 1e3, 2), steps_per_launch=T, us_per_step=round(ms * 1e3 / T, 3),
+                algorithmic_bytes_per_launch=int(alg_bytes), bytes_per_env_step=bytes_per_env_step,
+                env_steps_per_sec=round(T * n_envs / (ms * 1e-3), 1))
 
 
 def cpu_baseline(n_envs, procs, budget_s):
@@ -328,14 +375,24 @@ def main():
         out["roofline_timed_region"] = rollout_kernel_leg(trainer) if trainer.updater.fused_mlp64 else None
         del trainer
         torch.cuda.empty_cache()
-        out["roofline"] = step_kernel_roofline(
+        # the ray-cast run of BASELINE configs[2]: a 256-step action tape per launch (navsim_step_seq), and the same step body
+        # launched once per step (navsim_step) beside it
+        out["roofline"] = step_seq_roofline(
+            16384, "stage_2", per_env=True, T=256,
+            detail="working set 35.7 MB per step sits in the 256 MiB Infinity Cache: L3-fed, VALU-issue bound at this size")
+        out["roofline"]["traffic"] = profiled_traffic("cfg3_seq_bytes_per_launch")
+        out["roofline_single_launch"] = step_kernel_roofline(
             16384, "stage_2", per_env=True, iters=64 * 1500,
-            detail="working set 35.7 MB sits in the 256 MiB Infinity Cache: L3-fed, VALU / phase-latency bound at this size")
-        out["roofline"]["traffic"] = profiled_traffic("cfg3_step_bytes_per_launch")
-        out["roofline_beyond_l3"] = step_kernel_roofline(
+            detail="one step per launch: + launch ramp of 256 x 16 waves, state round trips, graph-node boundary")
+        out["roofline_single_launch"]["traffic"] = profiled_traffic("cfg3_step_bytes_per_launch")
+        out["roofline_beyond_l3"] = step_seq_roofline(
+            16384, "stage_2", per_env=True, T=64, sides=248,
+            detail="working set 268 MB per step > Infinity Cache: the segment stream comes from HBM")
+        out["roofline_beyond_l3"]["traffic"] = profiled_traffic("s1024_seq_bytes_per_launch")
+        out["roofline_beyond_l3_single_launch"] = step_kernel_roofline(
             16384, "stage_2", per_env=True, iters=64 * 400, sides=248,
-            detail="working set 268 MB > Infinity Cache: the segment stream comes from HBM")
-        out["roofline_beyond_l3"]["traffic"] = profiled_traffic("s1024_step_bytes_per_launch")
+            detail="one step per launch; working set 268 MB > Infinity Cache")
+        out["roofline_beyond_l3_single_launch"]["traffic"] = profiled_traffic("s1024_step_bytes_per_launch")
         if ctx.world == 1:
             ttr = time_to_reward(n_local)
             out["time_to_reward_s"] = ttr["seconds"]

@@ -270,6 +270,21 @@ class VecEnv:
         return io.obs, io.reward, io.done, io.arrive
 
 
+    def step_seq(self, actions):
+        """A whole action tape in ONE launch (navsim_step_seq): actions [T, N, 2] float32 on the device.  Returns a namespace of
+        [T, N, ...] tensors (obs after each step, reward, done, arrive, ended, ep_return, ep_length, ep_path); row t is what
+        ``step(actions[t])`` would have produced.  For loops whose actions do not depend on the observations they produce."""
+        actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        T, N, dev = int(actions.shape[0]), self.N, self.device
+        out = types.SimpleNamespace(
+            obs=torch.empty((T, N, self.sim.D), dtype=self.sim.obs_dtype, device=dev), reward=torch.empty((T, N), device=dev),
+            done=torch.empty((T, N), dtype=torch.uint8, device=dev), arrive=torch.empty((T, N), dtype=torch.uint8, device=dev),
+            ended=torch.empty((T, N), dtype=torch.uint8, device=dev), ep_return=torch.zeros((T, N), device=dev),
+            ep_length=torch.zeros((T, N), dtype=torch.int32, device=dev), ep_path=torch.zeros((T, N), device=dev))
+        self.sim.step_seq(actions, out.obs, out.reward, out.done, out.arrive, out.ended, out.ep_return, out.ep_length, out.ep_path)
+        return out
+
+
 class _XY:
     __slots__ = ("x", "y", "z")
 

@@ -954,3 +954,43 @@ def test_step_seq_against_the_oracle():
     np.testing.assert_array_equal(sg["goal"], sc["goal"])
     np.testing.assert_array_equal(sg["ep_step"], sc["ep_step"])
     np.testing.assert_array_equal(sg["rng_ctr"], sc["rng_ctr"])
+
+
+def test_g10_reference_rollout_in_one_launch():
+    """a-8 through navsim_step_seq: the action tape the reference's PPO.rollout produced over its own Env (G10, 600 steps, episode
+    cap 45) replayed in ONE launch; the stored observations (obs BEFORE acting, ppo.py:508: row 0 = the reset observation, row
+    t = the observation after step t - 1), rewards, terminations, episode statistics and returns must match the recording."""
+    from navbot_ppo_amd.env import NavSim, rtg_scan
+    from test_rollout_golden_cpu import check_against_g10
+    d = np.load(os.path.join(G, "g10_rollout.npz"))
+    sim = NavSim(1, max_episode_steps=int(d["cap"]), auto_reset=True, respawn_on_arrive=True, seed=int(d["seed"]))
+    sim.set_map(maps.stage_1())
+    io = sim.alloc_io()
+    acts = torch.from_numpy(np.ascontiguousarray(d["acts_tape"], dtype=np.float32)).cuda().view(-1, 1, 2)
+    T = acts.shape[0]
+    obs = torch.zeros((T + 1, 1, 16), device="cuda")
+    sim.reset(obs[0])
+    rew, epr, epp = (torch.zeros((T, 1), device="cuda") for _ in range(3))
+    done, arrive, ended = (torch.zeros((T, 1), dtype=torch.uint8, device="cuda") for _ in range(3))
+    epl = torch.zeros((T, 1), dtype=torch.int32, device="cuda")
+    sim.step_seq(acts, obs[1:], rew, done, arrive, ended, epr, epl, epp)
+    rtg = rtg_scan(rew, ended, float(d["gamma"])).cpu().numpy()[:, 0]
+    flags = torch.cat([done, arrive], 1).cpu().numpy()
+    check_against_g10(d, obs[:T, 0].cpu().numpy(), rew[:, 0].cpu().numpy(), ended[:, 0].cpu().numpy(), flags, epl[:, 0].cpu().numpy(),
+                      epr[:, 0].cpu().numpy(), epp[:, 0].cpu().numpy(), rtg)
+    assert int(sim.get_state()["rng_ctr"][0]) == int(d["rng_ctr_final"])
+
+
+def test_vecenv_step_seq_surface():
+    """VecEnv.step_seq (the host-side mirror of navsim_step_seq) returns what T VecEnv.step calls return."""
+    from navbot_ppo_amd.env import VecEnv
+    T, N = 12, 64
+    acts = torch.from_numpy(_actions(np.random.default_rng(2), T, N)).cuda()
+    a, b = VecEnv(N, map="stage_1", max_episode_steps=6, seed=4), VecEnv(N, map="stage_1", max_episode_steps=6, seed=4)
+    a.reset(), b.reset()
+    out = a.step_seq(acts)
+    for t in range(T):
+        obs, rew, done, arrive = b.step(acts[t])
+        assert torch.equal(out.obs[t], obs) and torch.equal(out.reward[t], rew) and torch.equal(out.done[t], done)
+        assert torch.equal(out.arrive[t], arrive) and torch.equal(out.ended[t], b.io.ended)
+    assert int(out.ended.sum()) >= N

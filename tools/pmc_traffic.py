@@ -9,14 +9,14 @@ import csv, glob, hashlib, json, os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["TMPDIR"] = "/tmp"
 
-def counter(ctr, flag):
-    d = f"/tmp/pmc_tr_{ctr}_{flag.strip('-').replace('=', '')}"
+def counter(ctr, flag, tool="tools/time_step.py", kernel="step_kernel"):
+    d = f"/tmp/pmc_tr_{ctr}_{kernel}_{flag.strip('-').replace('=', '')}"
     subprocess.run(["rm", "-rf", d])
     subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-                    sys.executable, os.path.join(R, "tools/time_step.py"), flag], cwd="/tmp", stdout=subprocess.DEVNULL,
+                    sys.executable, os.path.join(R, tool), flag], cwd="/tmp", stdout=subprocess.DEVNULL,
                    stderr=subprocess.DEVNULL, check=False)
     f = glob.glob(d + "/**/p_counter_collection.csv", recursive=True)
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "step_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if kernel + "<" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
     vals = vals[len(vals) // 4:]   # steady state
     return sum(vals) / len(vals)
 
@@ -30,6 +30,12 @@ for key, flag, alg in (("cfg3", "--cfg3", 16384 * (134 + 16 * 128)), ("s1024", "
     f, w = counter("FETCH_SIZE", flag), counter("WRITE_SIZE", flag)
     out[key + "_step"] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "algorithmic_bytes_per_launch": alg}
     out[key + "_step_bytes_per_launch"] = int((2 * f + w) * 1024)
+# navsim_step_seq (steps_kernel): one launch = T steps of tools/time_step_seq.py's tape (256 at configs[2], 64 at S=1024)
+for key, flag, T, S in (("cfg3", "--cfg3", int(os.environ.get("TS_T", "256")), 128), ("s1024", "--s=1024", 64, 1024)):
+    f, w = (counter(c, flag, "tools/time_step_seq.py", "steps_kernel") for c in ("FETCH_SIZE", "WRITE_SIZE"))
+    out[key + "_seq"] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "steps_per_launch": T,
+                         "algorithmic_bytes_per_launch": T * 16384 * (134 + 16 * S)}
+    out[key + "_seq_bytes_per_launch"] = int((2 * f + w) * 1024)
 os.makedirs(os.path.join(R, "gpurun_out", RND), exist_ok=True)
 json.dump(out, open(os.path.join(R, "gpurun_out", RND, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
