@@ -19,6 +19,7 @@ Besides the contract fields, rank 0 adds
                       256-step action tape (navsim_step_seq, steps_kernel): algorithmic bytes (134 + 16*S per env-step, SURVEY.md
                       8d) x env-steps per launch / mean launch duration from HIP events
   roofline_single_launch   the same step body launched once per step (navsim_step, step_kernel), 64 launches per graph replay
+  roofline_closed_loop     the same run with the mlp64 policy in the kernel (navsim_rollout_mlp64 at 16384 envs: rollout_big_kernel)
   roofline_beyond_l3 (+ _single_launch)   the same kernels with S=1024 per env (268 MB per step: past the 256 MiB Infinity Cache)
   roofline_timed_region   the persistent rollout kernel of the timed workload
   time_to_reward_s    PPO wall-clock until mean episode return >= +100 (ppo.py:833) from a fresh policy
@@ -155,6 +156,47 @@ def cpu_baseline(n_envs, procs, budget_s):
     if out.returncode != 0:
         return {"error": out.stderr[-400:]}
     return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def closed_loop_roofline(n_envs, map_name, per_env, T, reps=8, seed=0, sides=None, detail=""):
+    """HIP-event timing of navsim_rollout_mlp64 at a configs[2]-sized shard (rollout_big_kernel): the ray-cast run CLOSED-LOOP -- the
+    16-64-64 actor chooses every action from the observation the previous step left on chip (PPO.rollout, ppo.py:505-594), T steps
+    per launch.  Algorithmic bytes per launch = T x n_envs x (134 + 16 S), the env-step figure of SURVEY.md 8(d): the 12 bytes of
+    action + log-prob the policy adds per env-step are not counted."""
+    from navbot_ppo_amd import maps, ppo
+    from navbot_ppo_amd.env import VecEnv
+    seg = maps.stage_2(sides=sides) if sides else maps.by_name(map_name)
+    S = int(seg.shape[0])
+    env = VecEnv(n_envs, map=seg, max_episode_steps=500, seed=seed, per_env_map=per_env)
+    rr, rs = maps.goal_rects(map_name)
+    env.sim.set_goal_rects(0, rr)
+    env.sim.set_goal_rects(1, rs)
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(policy="mlp64x2", rollout_len=T, max_episode_steps=500, seed=seed))
+    assert tr.updater.fused_mlp64
+    env.sim.reset(tr.obs_buf[0])
+    for _ in range(2):
+        tr._persistent_rollout()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        tr._persistent_rollout()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    bytes_per_env_step = 134 + (16 * S if per_env else 0)
+    alg_bytes = T * n_envs * bytes_per_env_step + (0 if per_env else 16 * S)
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    env.close()
+    return dict(bound="hbm", bound_detail=detail,
+                kernel="rollout_big_kernel<64 envs, 16 waves, %s> (navsim_rollout_mlp64: %d steps per launch, policy phase + the step "
+                       "body of step_kernel)" % ("per_env" if per_env else "shared", T),
+                workload=f"{n_envs} envs x {T} steps, {map_name} ({S} segments, {'per-env' if per_env else 'shared'} map), 10 beams, "
+                         "16-64-64 policy in-kernel",
+                achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                launch_us=round(ms * 1e3, 2), steps_per_launch=T, us_per_step=round(ms * 1e3 / T, 3),
+                algorithmic_bytes_per_launch=int(alg_bytes), bytes_per_env_step=bytes_per_env_step,
+                env_steps_per_sec=round(T * n_envs / (ms * 1e-3), 1))
 
 
 def rollout_kernel_leg(trainer, reps=6):
@@ -385,6 +427,10 @@ def main():
             16384, "stage_2", per_env=True, iters=64 * 1500,
             detail="one step per launch: + launch ramp of 256 x 16 waves, state round trips, graph-node boundary")
         out["roofline_single_launch"]["traffic"] = profiled_traffic("cfg3_step_bytes_per_launch")
+        out["roofline_closed_loop"] = closed_loop_roofline(
+            16384, "stage_2", per_env=True, T=256,
+            detail="the same ray-cast run with the 16-64-64 policy choosing every action in-kernel (PPO.rollout closed-loop): + the "
+                   "policy phase, bound by the SIMDs' f32 MFMA pipes (64 envs x 10.2 kFLOP per CU and step = 1.07 us)")
         out["roofline_beyond_l3"] = step_seq_roofline(
             16384, "stage_2", per_env=True, T=64, sides=248,
             detail="working set 268 MB per step > Infinity Cache: the segment stream comes from HBM")

@@ -1380,6 +1380,103 @@ __global__ __launch_bounds__(64 * NW) void steps_kernel(Params, SeqArgs) {
     }
 }
 
+// ---------------------------------------------------------------- the persistent rollout at the big shard shapes
+// navsim_rollout_mlp64 for shards of 16384+ envs: steps_kernel's workgroup (64 envs on 16 waves, one per CU, the cast at its
+// vector-issue bound, the cast variants of launch_step) with a policy phase in front of every step -- the closed-loop form of the
+// tape kernel: the action of step t is PPO.get_action (ppo.py:673-706) of the observation tile step t - 1 left in LDS.
+// The phase is bound by the SIMDs' MFMA pipes (64 envs x 10.2 kFLOP at the f32 MFMA rate of 64 FLOP per cycle and SIMD = 2560
+// cycles), so each of the EPB / 16 policy tiles of 16 envs belongs to ONE wave -- the waves of a workgroup land on the SIMDs round
+// robin, one tile per SIMD -- which runs policy_wave16's sequence: layer 1, the four 16-row tiles of layer 2 in order, the finish
+// on its lanes 0-15 (no partial sums through LDS, no redundant layer 1: two waves per tile measured 2.05 us per step over the tape
+// kernel, this 1.6).  The action noise does not depend on the observation: wave EPB / 16 draws the noise of step t + 1 during the
+// policy phase of step t (two LDS rows that take turns).  Same device functions, same order of the partial sums and same Philox
+// keys as rollout_kernel / navppo_mlp64_act: the rows are bit-identical to the per-step entry points.
+struct BigKArgs {
+    Params P;
+    RolloutArgs R;
+    StepIO io;   // rows of step t at element offset t N: obs_out = obs_buf + N D (row t + 1 of obs_buf), reward / flags / statistics
+};
+typedef const BigKArgs __attribute__((address_space(4))) * BigKArgsPtr;
+
+template <int EPB, bool SENS, int NW, bool BOXES = false, bool PAIR = false>
+__global__ __launch_bounds__(64 * NW) void rollout_big_kernel(Params, RolloutArgs, StepIO) {
+    constexpr int NB = 10, D = NB + 6, DP = D + 1, kThreads = 64 * NW;
+    constexpr int TW = EPB / 16;   // policy tiles = MFMA waves of the policy phase
+    static_assert(D == mlp64::IN, "the 16-64-64 policy reads 16-wide observations");
+    static_assert(EPB % 16 == 0 && EPB <= 64 && TW < NW, "policy phase: EPB / 16 tile waves + the noise wave");
+    __shared__ StepSmem<NB, EPB, NW> sm;
+    __shared__ int next_env;
+    __shared__ __attribute__((aligned(16))) float wts[mlp64::P_ACTOR + 2];   // the actor, staged once for all T steps
+    __shared__ float2 pol_eps[2][EPB];   // action noise of this step and of the next one
+    BigKArgsPtr A = (BigKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(A));
+    const Params __attribute__((address_space(4)))& P = A->P;
+    const RolloutArgs __attribute__((address_space(4)))& R = A->R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int base = blockIdx.x * EPB;
+    const int nloc = min(EPB, P.N - base);
+    const int T = R.T;
+    {
+        const float* const prm = R.params;
+        for (int k = tid; k < mlp64::P_ACTOR; k += kThreads) wts[k] = prm[k];
+    }
+    if (tid < nloc) {   // the envs' state: HBM -> LDS for the whole rollout
+        const int e = tid, i = base + e;
+        sm.st_d[0][e] = P.x[i]; sm.st_d[1][e] = P.y[i]; sm.st_d[2][e] = P.th[i]; sm.st_d[3][e] = P.gx[i]; sm.st_d[4][e] = P.gy[i];
+        sm.st_d[5][e] = P.past_dist[i]; sm.st_d[6][e] = P.ep_ret[i]; sm.st_d[7][e] = P.ep_path[i];
+        sm.st_pact[e] = P.past_action[i];
+        sm.st_step[e] = (uint32_t)P.ep_step[i];
+        sm.st_ctr[e] = P.rng_ctr[i];
+    }
+    {
+        const float* const ob = R.obs_buf;
+        for (int k = tid; k < nloc * D; k += kThreads) sm.obs[(k / D) * DP + (k % D)] = ob[(size_t)base * D + k];
+    }
+    for (int k = tid; k < 2 * NB; k += kThreads) sm.beam[k] = P.beam_cs[k];
+    for (int k = tid; k < (int)(sizeof(Rects) / 8); k += kThreads)
+        reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
+    const uint32_t step0 = R.step_base ? *R.step_base : 0u;
+    const float var = *R.var_ptr;
+    const uint64_t seed = R.seed, gid = P.env_id_base + (uint64_t)(base + lane);
+    if (wave == TW && lane < nloc) {
+        float e0, e1;
+        mlp64::policy_noise(step0, seed, gid, e0, e1);
+        pol_eps[0][lane] = make_float2(e0, e1);
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const size_t N = (size_t)P.N;
+        const size_t tn = (size_t)t * N;
+        asm volatile("" ::: "memory");   // keeps the weight reads of the policy phase inside the loop
+        if (wave < TW) {
+            const int e = 16 * wave + (lane & 15), kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]
+            const bool valid = e < nloc;
+            const float* row = sm.obs + min(e, nloc - 1) * DP + 4 * kk;
+            const float4 xq = valid ? make_float4(row[0], row[1], row[2], row[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float2 eps = pol_eps[t & 1][min(e, nloc - 1)];   // requested ahead of the MFMA chain, used behind it
+            mlp64::f32x4 c1[4];
+            mlp64::policy_hidden1(wts, xq, lane, c1);
+            float pz3[4], pz4[4];
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) mlp64::policy_tile2(wts, c1, lane, t2, pz3[t2], pz4[t2]);
+            if (kk == 0 && valid) {
+                const mlp64::PolicyOut o = mlp64::policy_finish(wts, pz3, pz4, var, eps.x, eps.y);
+                sm.act_l[e] = make_float2(o.a0, o.a1);
+                reinterpret_cast<float2*>(R.act_buf)[tn + base + e] = make_float2(o.a0, o.a1);
+                R.logp_buf[tn + base + e] = o.logp;
+            }
+        } else if (wave == TW && lane < nloc && t + 1 < T) {
+            float e0, e1;
+            mlp64::policy_noise(step0 + (uint32_t)(t + 1), seed, gid, e0, e1);
+            pol_eps[(t + 1) & 1][lane] = make_float2(e0, e1);
+        }
+        __syncthreads();
+        step_body<NB, EPB, SENS, true, NW, BOXES, PAIR, const Params __attribute__((address_space(4)))&,
+                  const StepIO __attribute__((address_space(4)))&>(P, sm, next_env, A->io, t == T - 1, tn);
+        // the observation tile of step t + 1 is in sm.obs; its store only reads it, like the next policy phase
+    }
+}
+
 // Env.getOdometry (environment_new.py:138-181) for n independent (position, orientation quaternion, goal) triples
 __global__ void odometry_kernel(int n, const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ q,
                                 const double* __restrict__ goal, double* __restrict__ out) {
@@ -2081,11 +2178,35 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
     // measured (tools/time_rollout.py, 512 steps) 4096 / 2048 / 1024 / 512 envs take 2.92 / 2.90 / 2.89 / 2.97 ms with 16 envs
     // per workgroup, 3.05-3.06 ms with 8 and 2.96 ms with 4 wherever the grid still fits one round of 256 CUs (a second
     // round doubles the time: 256 registers x 8 waves fill a CU) -- spreading a small shard over more CUs buys nothing.
+    hipStream_t st = (hipStream_t)stream;
+    // Shards of 16384+ envs (NAVSIM_EPB=64 forces it): the tape kernel's 64-env workgroup with the policy phase in front of every
+    // step (rollout_big_kernel), with the cast variants of launch_step (tile boxes, 128-segment passes).  At 16384 envs one latency
+    // chain per 16 envs would be four rounds of workgroups; the 64-env workgroup runs the cast at its vector-issue bound instead.
+    const bool boxes = h->P.tile_box != nullptr;
+    const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
+    if (g_epb == 64 || (g_epb == 0 && h->P.N >= 16384)) {
+        StepIO io;
+        io.action = nullptr; io.past_override = nullptr;
+        io.obs_out = obs_buf_dev + (size_t)h->P.N * 16;
+        io.reward = reward_dev; io.done = done_dev; io.arrive = arrive_dev; io.ended = ended_dev;
+        io.ep_return = ep_return_dev; io.ep_length = ep_length_dev; io.ep_path_out = ep_path_dev;
+        const dim3 grid((h->P.N + 63) / 64), block(64 * 16);
+#define NAVSIM_BIG(BOXES_, PAIR_)                                                                                         \
+    do {                                                                                                                  \
+        if (sens) hipLaunchKernelGGL((rollout_big_kernel<64, true, 16, BOXES_, PAIR_>), grid, block, 0, st, h->P, R, io);   \
+        else hipLaunchKernelGGL((rollout_big_kernel<64, false, 16, BOXES_, PAIR_>), grid, block, 0, st, h->P, R, io);       \
+    } while (0)
+        if (boxes) NAVSIM_BIG(true, false);
+        else if (pair) NAVSIM_BIG(false, true);
+        else NAVSIM_BIG(false, false);
+#undef NAVSIM_BIG
+        HIP_TRY(hipGetLastError());
+        return NAVSIM_OK;
+    }
     const int epb = (g_epb == 4 || g_epb == 8 || g_epb == 16) ? g_epb : 16;
     // 8 waves per workgroup: more ray waves shorten the cast
     constexpr int kRollWaves = 8;
     const dim3 grid((h->P.N + epb - 1) / epb), block(64 * kRollWaves);
-    hipStream_t st = (hipStream_t)stream;
     if (epb == 4) {
         if (sens) hipLaunchKernelGGL((rollout_kernel<4, true, kRollWaves>), grid, block, 0, st, h->P, R);
         else hipLaunchKernelGGL((rollout_kernel<4, false, kRollWaves>), grid, block, 0, st, h->P, R);

@@ -241,16 +241,25 @@ def test_cli_train_resume_eval(tmp_path):
     assert os.path.exists(os.path.join(out, "dbg", "logs", "dbg_eval_episodes.csv"))
 
 
-@pytest.mark.parametrize("N,T,per_env", [(4096, 64, False), (200, 90, False), (96, 40, True)])
-def test_persistent_rollout_equals_per_step_rollout(N, T, per_env):
+@pytest.mark.parametrize("N,T,map_name,per_env,epb", [
+    (4096, 64, "stage_1", False, None), (200, 90, "stage_1", False, None), (96, 40, "stage_2", True, None),
+    # rollout_big_kernel (64-env workgroups, policy phase in front of the tape kernel's step): the shard sizes that select it
+    # with each cast variant (plain / 128-segment passes of per-env maps / tile boxes of a shared 2048-segment map), and forced
+    # onto small ragged shards (200 = 3 workgroups + 8 envs; 40 envs: one partial policy tile)
+    (16384, 40, "stage_1", False, None), (16384, 36, "stage_2", True, None), (16384, 34, "house", False, None),
+    (200, 60, "stage_1", False, "64"), (40, 50, "stage_2", True, "64"), (1000, 36, "house", False, "64")])
+def test_persistent_rollout_equals_per_step_rollout(N, T, map_name, per_env, epb, monkeypatch):
     """navsim_rollout_mlp64 (all T steps in one launch) against T pairs of navppo_mlp64_act / navsim_step: same device
     functions and Philox keys, so every rollout buffer and the simulator state must come out bit-identical -- over two
     consecutive rollouts (the noise counter and the cached next-episode records carry over)."""
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
+    if epb:
+        monkeypatch.setenv("NAVSIM_EPB", epb)   # read by navsim_create: both paths then run their 64-env shapes
     outs = []
     for persistent in (True, False):
-        env = VecEnv(N, map="stage_2" if per_env else "stage_1", max_episode_steps=30, seed=3, per_env_map=per_env)
+        env = VecEnv(N, map=map_name, max_episode_steps=30, seed=3, per_env_map=per_env,
+                     sampler="small_house" if map_name == "house" else None)
         cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=30, n_updates_per_iteration=1, policy="mlp64x2", seed=5,
                             persistent_rollout=persistent, use_graph=False)
         tr = ppo.PPOTrainer(env, cfg)
@@ -438,8 +447,10 @@ def test_episode_sums_match_torch_reductions(shape):
     assert abs(outs[0][5] - want[5]) <= 1e-12 * max(1.0, abs(want[5])) + 1e-9
 
 
-def test_persistent_rollout_at_bench_size_against_the_oracle():
-    """navsim_rollout_mlp64 at the timed configuration (BASELINE configs[1]: T = 512, N = 4096, episode cap 500) checked
+@pytest.mark.parametrize("N,T,cap,lo,n_s", [(4096, 512, 500, 2000, 96), (16384, 160, 150, 9000, 96)])
+def test_persistent_rollout_at_bench_size_against_the_oracle(N, T, cap, lo, n_s):
+    """navsim_rollout_mlp64 at the timed configuration (BASELINE configs[1]: T = 512, N = 4096, episode cap 500) and at the
+    16384-env shard of configs[2] (rollout_big_kernel) checked
     DIRECTLY against the oracle, not against the per-step HIP path: the actions the kernel recorded for a block of 96 envs
     are replayed on an OracleSim keyed by the same global env ids (goal stream = Philox(seed, env id)); flags must be
     bit-exact, observations within 1e-6, rewards within 1e-5; the stored log-probs are those of the stored (clamped)
@@ -447,7 +458,6 @@ def test_persistent_rollout_at_bench_size_against_the_oracle():
     from navbot_ppo_amd import maps
     from navbot_ppo_amd.env import VecEnv
     from oracle import navsim_oracle as O
-    N, T, cap, lo, n_s = 4096, 512, 500, 2000, 96
     env = VecEnv(N, map="stage_1", max_episode_steps=cap, seed=7)
     cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=cap, policy="mlp64x2", seed=3)
     tr = ppo.PPOTrainer(env, cfg)

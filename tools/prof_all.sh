@@ -12,14 +12,19 @@ tools/prof_stats.sh step_cfg3 -- python tools/time_step.py --cfg3 > $O/step_cfg3
 tools/prof_stats.sh step_s1024 -- python tools/time_step.py --s=1024 > $O/step_s1024_rocprof.log 2>&1
 tools/prof_stats.sh step_seq_cfg3 -- python tools/time_step_seq.py --cfg3 > $O/step_seq_cfg3_rocprof.log 2>&1
 tools/prof_stats.sh step_seq_s1024 -- python tools/time_step_seq.py --s=1024 > $O/step_seq_s1024_rocprof.log 2>&1
+TR_SIZES=16384 TR_MAP=stage_2 TR_PER_ENV=1 TR_T=256 tools/prof_stats.sh rollout_big_cfg3 -- python tools/time_rollout.py > $O/rollout_big_cfg3_rocprof.log 2>&1
 tools/prof_stats.sh update -- python tools/time_update.py navbot_ppo_amd/libnavsim.so > $O/update_rocprof.log 2>&1
 tools/prof_stats.sh resmlp512_update -- python tools/time_update_resmlp.py 2097152 5 > $O/resmlp512_update_rocprof.log 2>&1
 tools/pmc.sh step_final "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU" -- python tools/time_step.py --cfg3 > /dev/null 2>&1
 tools/pmc.sh step_final_b "SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVES GRBM_GUI_ACTIVE" -- python tools/time_step.py --cfg3 > /dev/null 2>&1
 tools/pmc.sh step_seq_final "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU" -- python tools/time_step_seq.py --cfg3 > /dev/null 2>&1
+TR_SIZES=16384 TR_MAP=stage_2 TR_PER_ENV=1 TR_T=256 tools/pmc.sh rollout_big "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS" -- python tools/time_rollout.py > /dev/null 2>&1
 tools/pmc.sh update_final "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" -- python tools/time_update.py navbot_ppo_amd/libnavsim.so > /dev/null 2>&1
 tools/pmc.sh resmlp512_update "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" -- python tools/time_update_resmlp.py 2097152 2 > /dev/null 2>&1
 python tools/time_rollout.py > $O/rollout_shard_sizes.txt 2>&1
+(TR_SIZES=16384 TR_MAP=stage_2 TR_PER_ENV=1 TR_T=256 python tools/time_rollout.py; NAVSIM_EPB=16 TR_SIZES=16384 TR_MAP=stage_2 TR_PER_ENV=1 TR_T=256 python tools/time_rollout.py
+ TR_SIZES=16384 TR_PER_ENV=1 TR_T=64 TR_SIDES=248 python tools/time_rollout.py; TR_SIZES=16384 TR_T=256 python tools/time_rollout.py; NAVSIM_EPB=16 TR_SIZES=16384 TR_T=256 python tools/time_rollout.py
+ TR_SIZES=16384 TR_MAP=house TR_T=64 python tools/time_rollout.py; python tools/time_step_seq.py --cfg3) 2>&1 | grep -v amdgpu > $O/rollout_big.txt
 python tools/time_update_scale.py > $O/update_scale.txt 2>&1
 python tools/time_rtg.py > $O/time_rtg.log 2>&1
 python tools/phase_timing.py build/libnavsim_timing.so > $O/step_cfg3_phase_stamps.txt 2>&1

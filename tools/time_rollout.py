@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Dev tool: the persistent rollout kernel (navsim_rollout_mlp64) at the shard sizes of a strong-scaling run: 4096 envs over
-1 / 2 / 4 / 8 GPUs = 4096 / 2048 / 1024 / 512 envs per GPU.  NAVSIM_EPB = 4 | 8 | 16 forces the envs per workgroup.
+1 / 2 / 4 / 8 GPUs = 4096 / 2048 / 1024 / 512 envs per GPU.  NAVSIM_EPB = 4 | 8 | 16 forces the envs per workgroup (64: the
+big-shard kernel, rollout_big_kernel, which shards of 16384+ envs select by themselves).
+TR_SIZES=16384 TR_MAP=stage_2 TR_PER_ENV=1 TR_T=256 [TR_SIDES=248]: the closed-loop form of BASELINE configs[2] (S=1024 with TR_SIDES).
 usage: python tools/time_rollout.py [lib.so] [policy]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
@@ -13,9 +15,18 @@ if _libs:
     _native.LIB_PATH = os.path.abspath(_libs[0])
 _pol = [a for a in sys.argv[1:] if not a.endswith(".so")]
 policy = _pol[0] if _pol else "mlp64x2"
+from navbot_ppo_amd import maps
+MAP, PER_ENV, T = os.environ.get("TR_MAP", "stage_1"), os.environ.get("TR_PER_ENV", "0") == "1", int(os.environ.get("TR_T", "512"))
+SIDES = int(os.environ.get("TR_SIDES", "0"))
 for N in [int(x) for x in os.environ.get("TR_SIZES", "4096,2048,1024,512").split(",")]:
-    env = VecEnv(N, map="stage_1", max_episode_steps=500, seed=0)
-    tr = ppo.PPOTrainer(env, ppo.PPOConfig(policy=policy, rollout_len=512, seed=0))
+    if SIDES:   # stage_2 with SIDES-gon pillars (248: 1024 segments), stage_2's goal rectangles
+        env = VecEnv(N, map=maps.stage_2(sides=SIDES), max_episode_steps=500, seed=0, per_env_map=PER_ENV)
+        rr, rs = maps.goal_rects("stage_2")
+        env.sim.set_goal_rects(0, rr)
+        env.sim.set_goal_rects(1, rs)
+    else:
+        env = VecEnv(N, map=MAP, max_episode_steps=500, seed=0, per_env_map=PER_ENV, sampler="small_house" if MAP == "house" else None)
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(policy=policy, rollout_len=T, seed=0))
     for _ in range(2):
         tr.rollout()
     torch.cuda.synchronize()
@@ -26,6 +37,7 @@ for N in [int(x) for x in os.environ.get("TR_SIZES", "4096,2048,1024,512").split
         tr.rollout()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f"{policy} N={N:5d} EPB={os.environ.get('NAVSIM_EPB', 'auto'):>4s}: rollout {ms:7.3f} ms = {ms / 512 * 1e3:6.2f} us per step, "
-          f"{N * 512 / ms / 1e3:8.1f} M env-steps/s", flush=True)
+    tag = MAP + (" per-env" if PER_ENV else "") + (" sides=%d" % SIDES if SIDES else "")
+    print(f"{policy} {tag} T={T} N={N:5d} EPB={os.environ.get('NAVSIM_EPB', 'auto'):>4s}: rollout {ms:7.3f} ms = {ms / T * 1e3:6.2f} us per step, "
+          f"{N * T / ms / 1e3:8.1f} M env-steps/s", flush=True)
     env.close()
