@@ -431,6 +431,7 @@ def main():
             16384, "stage_2", per_env=True, T=256,
             detail="the same ray-cast run with the 16-64-64 policy choosing every action in-kernel (PPO.rollout closed-loop): + the "
                    "policy phase, bound by the SIMDs' f32 MFMA pipes (64 envs x 10.2 kFLOP per CU and step = 1.07 us)")
+        out["roofline_closed_loop"]["traffic"] = profiled_traffic("cfg3_closed_loop_bytes_per_launch")
         out["roofline_beyond_l3"] = step_seq_roofline(
             16384, "stage_2", per_env=True, T=64, sides=248,
             detail="working set 268 MB per step > Infinity Cache: the segment stream comes from HBM")

@@ -36,6 +36,11 @@ for key, flag, T, S in (("cfg3", "--cfg3", int(os.environ.get("TS_T", "256")), 1
     out[key + "_seq"] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "steps_per_launch": T,
                          "algorithmic_bytes_per_launch": T * 16384 * (134 + 16 * S)}
     out[key + "_seq_bytes_per_launch"] = int((2 * f + w) * 1024)
+# navsim_rollout_mlp64 at configs[2] (rollout_big_kernel): one launch = 256 closed-loop steps of tools/time_rollout.py --cfg3
+f, w = (counter(c, "--cfg3", "tools/time_rollout.py", "rollout_big_kernel") for c in ("FETCH_SIZE", "WRITE_SIZE"))
+out["cfg3_closed_loop"] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "steps_per_launch": 256,
+                           "algorithmic_bytes_per_launch": 256 * 16384 * (134 + 16 * 128)}
+out["cfg3_closed_loop_bytes_per_launch"] = int((2 * f + w) * 1024)
 os.makedirs(os.path.join(R, "gpurun_out", RND), exist_ok=True)
 json.dump(out, open(os.path.join(R, "gpurun_out", RND, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

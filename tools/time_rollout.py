@@ -13,7 +13,9 @@ from navbot_ppo_amd import _native
 _libs = [a for a in sys.argv[1:] if a.endswith(".so")]
 if _libs:
     _native.LIB_PATH = os.path.abspath(_libs[0])
-_pol = [a for a in sys.argv[1:] if not a.endswith(".so")]
+if "--cfg3" in sys.argv:   # the closed-loop form of BASELINE configs[2] (what bench.py's roofline_closed_loop runs)
+    os.environ.update(TR_SIZES="16384", TR_MAP="stage_2", TR_PER_ENV="1", TR_T="256")
+_pol = [a for a in sys.argv[1:] if not a.endswith(".so") and not a.startswith("--")]
 policy = _pol[0] if _pol else "mlp64x2"
 from navbot_ppo_amd import maps
 MAP, PER_ENV, T = os.environ.get("TR_MAP", "stage_1"), os.environ.get("TR_PER_ENV", "0") == "1", int(os.environ.get("TR_T", "512"))
