@@ -1,5 +1,6 @@
 import sys, os, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
 import numpy as np, torch
 from navbot_ppo_amd import maps
 from navbot_ppo_amd.env import NavSim
@@ -26,11 +27,52 @@ def soak(N, seg, per_env, K, B=10, cap=60, seed=0, sampler=None, amax=1.0):
         if fl or d > 1e-6:
             print("MISMATCH step", k, "maxdiff", d, "flags", fl); break
     print(f"N={N} S={seg.shape[-2]} per_env={per_env} B={B} steps={K}: bad={bad} max|dobs|={mx:.2e} exact rows {exact/tot:.5f} episode ends {ends}")
-soak(4096, maps.replicate_per_env(maps.stage_2(), 4096, seed=1), True, 600)
-soak(16384, maps.replicate_per_env(maps.stage_2(), 16384, seed=2), True, 80)
-soak(4096, maps.stage_1(), False, 800)
 st, g, lo, hi = maps.spawn_tables("small_house"); seg = maps.house(2048)
-soak(2048, seg, False, 400, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi))
-soak(8192, seg, False, 60, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi))
-soak(2048, maps.stage_4(), False, 300, B=36)
-soak(2048, maps.replicate_per_env(maps.stage_2(sides=56), 2048, seed=3), True, 300, amax=3.0)
+if "--rollout" not in sys.argv:   # (--rollout: only the closed-loop part below)
+    soak(4096, maps.replicate_per_env(maps.stage_2(), 4096, seed=1), True, 600)
+    soak(16384, maps.replicate_per_env(maps.stage_2(), 16384, seed=2), True, 80)
+    soak(4096, maps.stage_1(), False, 800)
+    soak(2048, seg, False, 400, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi))
+    soak(8192, seg, False, 60, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi))
+    soak(2048, maps.stage_4(), False, 300, B=36)
+    soak(2048, maps.replicate_per_env(maps.stage_2(sides=56), 2048, seed=3), True, 300, amax=3.0)
+
+
+def soak_rollout(N, seg, per_env, T, iters=2, cap=60, seed=0, sampler=None):
+    """The persistent rollout CLOSED-LOOP (navsim_rollout_mlp64: rollout_big_kernel from 16384 envs): the actions the in-kernel policy
+    chose are replayed on the oracle for EVERY env; every observation row, flag and reward of every step is compared."""
+    from navbot_ppo_amd import ppo
+    from navbot_ppo_amd.env import VecEnv
+    env = VecEnv(N, map=seg, max_episode_steps=cap, seed=seed, per_env_map=False, sampler=sampler)
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=T, max_episode_steps=cap, policy="mlp64x2", seed=seed + 1))
+    with torch.no_grad():
+        tr.actor.layer3.bias.add_(2.0)   # drive forward: collisions and arrivals, not only timeouts
+    cpu = O.OracleSim(N, max_episode_steps=cap, auto_reset=True, seed=seed)
+    cpu.set_map(seg, per_env=per_env)
+    if sampler: cpu.set_spawn_sampler(*sampler)
+    bad = 0; exact = 0; tot = 0; ends = 0; mx = 0.0; mr = 0.0
+    for it in range(iters):
+        tr.rollout(); torch.cuda.synchronize()
+        obs, acts = tr.obs_buf.cpu().numpy(), tr.act_buf.cpu().numpy()
+        fl = {k: getattr(tr, k + "_buf").cpu().numpy() for k in ("done", "arrive", "ended", "rew")}
+        o0 = cpu.reset()   # ppo.py:486: every batch starts from a reset
+        bad += int(np.abs(obs[0] - o0).max() > 1e-6)
+        for t in range(T):
+            out = cpu.step(acts[t])
+            d = np.abs(obs[t + 1] - out["obs"]).max(); mx = max(mx, d)
+            mr = max(mr, float(np.abs(fl["rew"][t] - out["reward"]).max()))
+            f = sum(int((fl[k][t] != out[k]).sum()) for k in ("done", "arrive", "ended"))
+            bad += f + int(d > 1e-6)
+            exact += int((obs[t + 1] == out["obs"]).all(1).sum()); tot += N; ends += int(out["ended"].sum())
+            if f or d > 1e-6:
+                print("MISMATCH iteration", it, "step", t, "maxdiff", d, "flags", f); break
+    print(f"closed-loop rollout N={N} S={seg.shape[-2]} per_env={per_env} T={T} x {iters}: bad={bad} max|dobs|={mx:.2e} max|dreward|={mr:.2e} "
+          f"exact rows {exact/tot:.5f} episode ends {ends}")
+    env.close()
+
+
+if True:
+    soak_rollout(16384, maps.replicate_per_env(maps.stage_2(), 16384, seed=2), True, 200)
+    soak_rollout(16384, maps.stage_1(), False, 200)
+    soak_rollout(16384, seg, False, 60, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi))
+    soak_rollout(4096, maps.stage_1(), False, 512, cap=500)

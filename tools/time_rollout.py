@@ -5,7 +5,7 @@ big-shard kernel, rollout_big_kernel, which shards of 16384+ envs select by them
 TR_SIZES=16384 TR_MAP=stage_2 TR_PER_ENV=1 TR_T=256 [TR_SIDES=248]: the closed-loop form of BASELINE configs[2] (S=1024 with TR_SIDES).
 usage: python tools/time_rollout.py [lib.so] [policy]"""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from navbot_ppo_amd import ppo
 from navbot_ppo_amd.env import VecEnv
