@@ -278,9 +278,11 @@ def test_persistent_rollout_equals_per_step_rollout(N, T, map_name, per_env, epb
         env.close()
     (a, sa), (b, sb) = outs
     assert int(a[0][6].sum()) > N // 4          # episodes ended
+    # bit patterns: with lidar_below_min="gazebo" a reading below range_min is -inf and the policy's log-prob NaN on both paths
+    bits = lambda x: x.view(torch.int32) if x.dtype == torch.float32 else x
     for ra, rb in zip(a, b):
         for x, y in zip(ra, rb):
-            assert torch.equal(x, y)
+            assert torch.equal(bits(x), bits(y))
     for k in sa:
         np.testing.assert_array_equal(sa[k], sb[k])
 
