@@ -19,9 +19,10 @@ Besides the contract fields, rank 0 adds
                       256-step action tape (navsim_step_seq, steps_kernel): algorithmic bytes (134 + 16*S per env-step, SURVEY.md
                       8d) x env-steps per launch / mean launch duration from HIP events
   roofline_single_launch   the same step body launched once per step (navsim_step, step_kernel), 64 launches per graph replay
-  roofline_closed_loop     the same run with the mlp64 policy in the kernel (navsim_rollout_mlp64 at 16384 envs: rollout_big_kernel)
+  roofline_closed_loop (+ _beyond_l3)   the same runs with the mlp64 policy in the kernel (navsim_rollout_mlp64 at 16384 envs: rollout_big_kernel)
   roofline_beyond_l3 (+ _single_launch)   the same kernels with S=1024 per env (268 MB per step: past the 256 MiB Infinity Cache)
   roofline_timed_region   the persistent rollout kernel of the timed workload
+  update_roofline     the update kernels of the timed workload (94 % of the timed region): MFMA FLOPs of one epoch / its duration
   time_to_reward_s    PPO wall-clock until mean episode return >= +100 (ppo.py:833) from a fresh policy
   resmlp512           the same iteration with the reference's active 512-wide residual nets (fused f32-MFMA kernels of
                       csrc/ppo_resmlp512.hip) + `update_roofline`: MFMA FLOPs of one epoch / its duration vs the 157.3 TF peak
@@ -294,6 +295,36 @@ def resmlp512_leg(n_envs, rollout, epochs, steps=2):
                 update="fused f32-MFMA kernels" if up.fused_resmlp512 else "PyTorch-ROCm", update_roofline=roof)
 
 
+def mlp64_update_roofline(tr, reps=10):
+    """The update kernels of the TIMED workload alone (94 % of the timed region): HIP events around whole epochs of
+    navppo_mlp64_update_epoch (mlp64_pass_both + reduce_adam) on the trainer's own rollout buffers."""
+    up = tr.updater
+    if not up.fused_mlp64:
+        return None
+    T, N, D = tr.cfg.rollout_len, tr.env.N, tr.env.D
+    obs, acts = tr.obs_buf[:T].reshape(T * N, D), tr.act_buf.reshape(T * N, 2)
+    logp, rtg = tr.logp_buf.reshape(T * N), tr.rtg_buf.reshape(T * N)
+    adv = torch.randn(T * N, device=obs.device)
+    st = torch.zeros(8, device=obs.device)
+    up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    # MACs per sample and net: F1 1024 + F2 4096 + B2 4096 + G2 4096 + G1 1024 on MFMA (14,336), output units / their gradients
+    # on the vector units (actor 384, critic 192): 2 x (2 x 14,336 + 576) = 58,496 FLOP per sample
+    flop = 58496 * T * N
+    return dict(bound="mfma", kernel="navppo_mlp64_update_epoch (mlp64_pass_both + reduce_adam)", achieved=round(flop / ms / 1e9, 2),
+                peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4), epoch_us=round(ms * 1e3, 1),
+                flop_per_epoch=flop, samples=T * N, traffic=None,
+                detail="f32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): 14,336 MFMA cycles + ~575 vector instructions per 32-sample "
+                       "tile and net; f32 MFMA and VALU share the SIMD's FMA lanes, the loop sustains ~2.2 GHz")
+
+
 def env_n1_step_us(budget_s=1.5):
     """The N = 1 drop-in class `Env` (navbot_ppo_amd/env.py) stepped from Python exactly as PPO.rollout steps the reference's
     (ppo.py:541, 591-593): one launch + one stream wait per step, caller-side reset."""
@@ -415,6 +446,7 @@ def main():
     if not args.no_extras and ctx.rank == 0:   # rank 0 only (the other ranks wait at the barrier below)
         # GPU legs first and long enough (several seconds in total) for an outside utilisation sampler to see them
         out["roofline_timed_region"] = rollout_kernel_leg(trainer) if trainer.updater.fused_mlp64 else None
+        out["update_roofline"] = mlp64_update_roofline(trainer)
         del trainer
         torch.cuda.empty_cache()
         # the ray-cast run of BASELINE configs[2]: a 256-step action tape per launch (navsim_step_seq), and the same step body
@@ -436,6 +468,9 @@ def main():
             16384, "stage_2", per_env=True, T=64, sides=248,
             detail="working set 268 MB per step > Infinity Cache: the segment stream comes from HBM")
         out["roofline_beyond_l3"]["traffic"] = profiled_traffic("s1024_seq_bytes_per_launch")
+        out["roofline_closed_loop_beyond_l3"] = closed_loop_roofline(
+            16384, "stage_2", per_env=True, T=64, sides=248,
+            detail="closed-loop (policy in the kernel), working set 268 MB per step > Infinity Cache")
         out["roofline_beyond_l3_single_launch"] = step_kernel_roofline(
             16384, "stage_2", per_env=True, iters=64 * 400, sides=248,
             detail="one step per launch; working set 268 MB > Infinity Cache")
