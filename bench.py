@@ -295,7 +295,7 @@ def resmlp512_leg(n_envs, rollout, epochs, steps=2):
                 update="fused f32-MFMA kernels" if up.fused_resmlp512 else "PyTorch-ROCm", update_roofline=roof)
 
 
-def mlp64_update_roofline(tr, reps=10):
+def mlp64_update_roofline(tr, reps=40):
     """The update kernels of the TIMED workload alone (94 % of the timed region): HIP events around whole epochs of
     navppo_mlp64_update_epoch (mlp64_pass_both + reduce_adam) on the trainer's own rollout buffers."""
     up = tr.updater
@@ -306,7 +306,8 @@ def mlp64_update_roofline(tr, reps=10):
     logp, rtg = tr.logp_buf.reshape(T * N), tr.rtg_buf.reshape(T * N)
     adv = torch.randn(T * N, device=obs.device)
     st = torch.zeros(8, device=obs.device)
-    up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+    for _ in range(10):   # the clock settles on the MFMA loop's level within a few epochs
+        up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
