@@ -285,6 +285,44 @@ class VecEnv:
         return out
 
 
+    def rollout_mlp64(self, actor_params, n_steps, var, seed=0, step_base=0, obs0=None):
+        """PPO.rollout's hot loop (ppo.py:505-594) for the 16-64-64 policy in ONE launch (navsim_rollout_mlp64): per step
+        PPO.get_action (ppo.py:673-706) on the observation the previous step left on chip, then the env step.
+        actor_params: flat float32 device tensor [5378] in nn.Module.named_parameters order (include/navppo.h); var: exploration
+        variance (float or device scalar); action noise = Philox(seed, global env id, step_base + t).  obs0 [N, 16]: the observations
+        to start from (default: a fresh reset).  Returns a namespace: obs [T + 1, N, 16] (row 0 = obs0), act [T, N, 2], logp / reward /
+        done / arrive / ended / ep_return / ep_length / ep_path [T, N] -- bit-identical to T pairs of navppo_mlp64_act / step calls."""
+        import ctypes as C
+        from ._native import check, lib
+        if self.B != 10 or self.sim.obs_dtype != torch.float32:
+            raise NavsimError("rollout_mlp64 needs 10 beams and float32 observations")
+        T, N, dev = int(n_steps), self.N, self.device
+        prm = actor_params.to(device=dev, dtype=torch.float32).contiguous()
+        if prm.numel() != 5378 or prm.data_ptr() % 16:
+            raise NavsimError("actor_params: 5378 float32 values, 16-byte aligned")
+        out = types.SimpleNamespace(
+            obs=torch.empty((T + 1, N, 16), device=dev), act=torch.empty((T, N, 2), device=dev), logp=torch.empty((T, N), device=dev),
+            reward=torch.empty((T, N), device=dev), done=torch.empty((T, N), dtype=torch.uint8, device=dev),
+            arrive=torch.empty((T, N), dtype=torch.uint8, device=dev), ended=torch.empty((T, N), dtype=torch.uint8, device=dev),
+            ep_return=torch.zeros((T, N), device=dev), ep_length=torch.zeros((T, N), dtype=torch.int32, device=dev),
+            ep_path=torch.zeros((T, N), device=dev))
+        if obs0 is None:
+            self.sim.reset(out.obs[0])
+        else:
+            out.obs[0].copy_(obs0)
+        var_t = var if torch.is_tensor(var) else torch.tensor(float(var), device=dev)
+        var_t = var_t.to(device=dev, dtype=torch.float32).reshape(())
+        base_t = torch.tensor(int(step_base), dtype=torch.int32, device=dev)
+        p = lambda x: C.c_void_p(x.data_ptr())
+        with torch.cuda.device(dev):
+            check(lib().navsim_rollout_mlp64(self.sim._h, p(prm), p(out.obs), p(out.act), p(out.logp), p(out.reward), p(out.done),
+                                             p(out.arrive), p(out.ended), p(out.ep_return), p(out.ep_length), p(out.ep_path), p(var_t),
+                                             int(seed) & 0xFFFFFFFFFFFFFFFF, p(base_t), T,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "navsim_rollout_mlp64")
+            torch.cuda.current_stream().synchronize()   # var_t / base_t / prm may be temporaries of this call
+        return out
+
+
 class _XY:
     __slots__ = ("x", "y", "z")
 

@@ -506,3 +506,32 @@ def test_persistent_rollout_at_bench_size_against_the_oracle(N, T, cap, lo, n_s)
     from test_gpu_parity import assert_rtg_close
     assert_rtg_close(tr.rtg_buf[:, sl].cpu().numpy(), O.compute_rtgs_tn(g["rew"], g["ended"], cfg.gamma))
     env.close()
+
+
+@pytest.mark.parametrize("N", [300, 16384])
+def test_vecenv_rollout_mlp64_equals_the_trainers_rollout(N):
+    """VecEnv.rollout_mlp64 (the closed-loop rollout without a trainer: flat actor parameters in, [T, N, .] buffers out) against
+    PPOTrainer.rollout with the same actor, variance and noise key -- both shapes of the kernel -- and its log-probs against PyTorch's
+    evaluation of the same actor on the stored observations / actions (ppo.py:696-704)."""
+    from navbot_ppo_amd.env import VecEnv
+    T = 40
+    env = VecEnv(N, map="stage_1", max_episode_steps=30, seed=11)
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=T, max_episode_steps=30, policy="mlp64x2", seed=4))
+    tr.rollout()
+    torch.cuda.synchronize()
+    ref = {k: getattr(tr, k + "_buf").clone() for k in ("obs", "act", "logp", "rew", "done", "arrive", "ended")}
+    var, seed = tr.var.clone(), tr._act_seed
+    flat = tr.updater.fp.flat[:5378].clone()
+    env.close()
+    env2 = VecEnv(N, map="stage_1", max_episode_steps=30, seed=11)
+    out = env2.rollout_mlp64(flat, T, var, seed=seed, step_base=0)
+    for k, v in (("obs", out.obs), ("act", out.act), ("logp", out.logp), ("rew", out.reward), ("done", out.done),
+                 ("arrive", out.arrive), ("ended", out.ended)):
+        assert torch.equal(ref[k], v), k
+    assert int(out.ended.sum()) >= N
+    with torch.no_grad():
+        lp = ppo.gaussian_log_prob(tr.actor(out.obs[:T].reshape(T * N, 16)), out.act.reshape(T * N, 2), var)
+    np.testing.assert_allclose(out.logp.reshape(-1).cpu().numpy(), lp.cpu().numpy(), rtol=1e-4, atol=3e-5)
+    with pytest.raises(Exception):
+        env2.rollout_mlp64(flat[:100], T, var)
+    env2.close()
