@@ -201,7 +201,7 @@ int navsim_gae_scan(const float* rew_dev, const uint8_t* ended_dev, const float*
  *   var_dev  device scalar: exploration variance (ppo.py:123-124)
  *   act_seed, step_base_dev (device scalar, nullable = 0): action noise = Philox(act_seed, env id, *step_base_dev + t)
  * Needs n_beams == 10 and float32 observations.  Two workgroup shapes, same rows bit for bit: 16 envs on 8 waves (a latency chain per
- * workgroup: shards below 16384 envs, shared maps without tile boxes in the cast) and, from 16384 envs per GPU, 64 envs on 16 waves
+ * workgroup, one round of workgroups up to 4096 envs; no tile boxes in the cast) and, beyond 4096 envs per GPU, 64 envs on 16 waves
  * with the cast variants of navsim_step (tile boxes of shared 65..4096-segment maps, 128-segment passes of per-env maps): the
  * closed-loop form of navsim_step_seq (NAVSIM_EPB = 4 | 8 | 16 | 64 forces a shape).
  */

@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(64 * NW) void steps_kernel(Params, SeqArgs) {
 }
 
 // ---------------------------------------------------------------- the persistent rollout at the big shard shapes
-// navsim_rollout_mlp64 for shards of 16384+ envs: steps_kernel's workgroup (64 envs on 16 waves, one per CU, the cast at its
+// navsim_rollout_mlp64 for shards beyond 4096 envs: steps_kernel's workgroup (64 envs on 16 waves, one per CU, the cast at its
 // vector-issue bound, the cast variants of launch_step) with a policy phase in front of every step -- the closed-loop form of the
 // tape kernel: the action of step t is PPO.get_action (ppo.py:673-706) of the observation tile step t - 1 left in LDS.
 // The phase is bound by the SIMDs' MFMA pipes (64 envs x 10.2 kFLOP at the f32 MFMA rate of 64 FLOP per cycle and SIMD = 2560
@@ -2179,12 +2179,14 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
     // per workgroup, 3.05-3.06 ms with 8 and 2.96 ms with 4 wherever the grid still fits one round of 256 CUs (a second
     // round doubles the time: 256 registers x 8 waves fill a CU) -- spreading a small shard over more CUs buys nothing.
     hipStream_t st = (hipStream_t)stream;
-    // Shards of 16384+ envs (NAVSIM_EPB=64 forces it): the tape kernel's 64-env workgroup with the policy phase in front of every
-    // step (rollout_big_kernel), with the cast variants of launch_step (tile boxes, 128-segment passes).  At 16384 envs one latency
-    // chain per 16 envs would be four rounds of workgroups; the 64-env workgroup runs the cast at its vector-issue bound instead.
+    // Shards beyond 4096 envs (NAVSIM_EPB=64 forces it): the tape kernel's 64-env workgroup with the policy phase in front of every
+    // step (rollout_big_kernel), with the cast variants of launch_step (tile boxes, 128-segment passes).  The 16-env shape is one
+    // latency chain per workgroup and one workgroup per CU: from 4097 envs it needs a second round of workgroups (measured, us per
+    // step, 16-env / 64-env shape: 4608 envs 10.6 / 7.3, 8192 10.5 / 7.4, 12288 15.5 / 7.4, 16384 20.5 / 7.6; 4096: 5.3 / 7.5), while
+    // a 64-env workgroup costs the same 7.3-7.6 us whether 72 or 256 CUs hold one.
     const bool boxes = h->P.tile_box != nullptr;
     const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
-    if (g_epb == 64 || (g_epb == 0 && h->P.N >= 16384)) {
+    if (g_epb == 64 || (g_epb == 0 && h->P.N > 16 * 256)) {
         StepIO io;
         io.action = nullptr; io.past_override = nullptr;
         io.obs_out = obs_buf_dev + (size_t)h->P.N * 16;

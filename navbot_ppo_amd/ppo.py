@@ -528,11 +528,11 @@ class PPOTrainer:
         self.eplen_buf.zero_()
         self.env.sim.reset(self.obs_buf[0])  # ppo.py:486: every batch starts from a reset
         sim = self.env.sim
-        # shared maps of 65..4096 segments carry tile bounding boxes (navsim_set_map); below 16384 envs per GPU only the per-step
+        # shared maps of 65..4096 segments carry tile bounding boxes (navsim_set_map); up to 4096 envs per GPU only the per-step
         # kernel's BOXES instantiation uses them to skip whole tiles, so there the hipGraph of per-step launches is the faster
-        # rollout (from 16384 envs navsim_rollout_mlp64 runs rollout_big_kernel, which has the cast variants of the step kernel)
+        # rollout (beyond 4096 envs navsim_rollout_mlp64 runs rollout_big_kernel, which has the cast variants of the step kernel)
         tile_boxes = ((not getattr(sim, "per_env", False)) and 65 <= getattr(sim, "S", 0) <= 4096
-                      and self.env.N < 16384 and os.environ.get("NAVSIM_EPB") != "64")
+                      and self.env.N <= 4096 and os.environ.get("NAVSIM_EPB") != "64")
         if (cfg.persistent_rollout and self.updater.fused_mlp64 and self.env.B == 10
                 and sim.obs_dtype == torch.float32 and not tile_boxes):
             self._persistent_rollout()

@@ -248,6 +248,7 @@ def test_cli_train_resume_eval(tmp_path):
     # with each cast variant (plain / 128-segment passes of per-env maps / tile boxes of a shared 2048-segment map), and forced
     # onto small ragged shards (200 = 3 workgroups + 8 envs; 40 envs: one partial policy tile)
     (16384, 40, "stage_1", False, None), (16384, 36, "stage_2", True, None), (16384, 34, "house", False, None),
+    (4160, 40, "stage_1", False, None), (6144, 36, "stage_2", True, None),   # the first shard sizes of the 64-env shape
     (200, 60, "stage_1", False, "64"), (40, 50, "stage_2", True, "64"), (1000, 36, "house", False, "64")])
 def test_persistent_rollout_equals_per_step_rollout(N, T, map_name, per_env, epb, sens, monkeypatch):
     """navsim_rollout_mlp64 (all T steps in one launch) against T pairs of navppo_mlp64_act / navsim_step: same device

@@ -24,7 +24,8 @@ tools/pmc.sh resmlp512_update "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_
 python tools/time_rollout.py > $O/rollout_shard_sizes.txt 2>&1
 (TR_SIZES=16384 TR_MAP=stage_2 TR_PER_ENV=1 TR_T=256 python tools/time_rollout.py; NAVSIM_EPB=16 TR_SIZES=16384 TR_MAP=stage_2 TR_PER_ENV=1 TR_T=256 python tools/time_rollout.py
  TR_SIZES=16384 TR_PER_ENV=1 TR_T=64 TR_SIDES=248 python tools/time_rollout.py; TR_SIZES=16384 TR_T=256 python tools/time_rollout.py; NAVSIM_EPB=16 TR_SIZES=16384 TR_T=256 python tools/time_rollout.py
- TR_SIZES=16384 TR_MAP=house TR_T=64 python tools/time_rollout.py; python tools/time_step_seq.py --cfg3) 2>&1 | grep -v amdgpu > $O/rollout_big.txt
+ TR_SIZES=16384 TR_MAP=house TR_T=64 python tools/time_rollout.py; python tools/time_step_seq.py --cfg3
+ TR_SIZES=4096,4608,8192,12288 TR_T=256 python tools/time_rollout.py; NAVSIM_EPB=16 TR_SIZES=4608,8192,12288 TR_T=256 python tools/time_rollout.py; NAVSIM_EPB=64 TR_SIZES=4096 TR_T=256 python tools/time_rollout.py) 2>&1 | grep -v amdgpu > $O/rollout_big.txt
 python tools/time_update_scale.py > $O/update_scale.txt 2>&1
 python tools/time_rtg.py > $O/time_rtg.log 2>&1
 python tools/phase_timing.py build/libnavsim_timing.so > $O/step_cfg3_phase_stamps.txt 2>&1

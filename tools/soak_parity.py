@@ -39,7 +39,7 @@ if "--rollout" not in sys.argv:   # (--rollout: only the closed-loop part below)
 
 
 def soak_rollout(N, seg, per_env, T, iters=2, cap=60, seed=0, sampler=None):
-    """The persistent rollout CLOSED-LOOP (navsim_rollout_mlp64: rollout_big_kernel from 16384 envs): the actions the in-kernel policy
+    """The persistent rollout CLOSED-LOOP (navsim_rollout_mlp64: rollout_big_kernel beyond 4096 envs): the actions the in-kernel policy
     chose are replayed on the oracle for EVERY env; every observation row, flag and reward of every step is compared."""
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: the persistent rollout kernel (navsim_rollout_mlp64) at the shard sizes of a strong-scaling run: 4096 envs over
 1 / 2 / 4 / 8 GPUs = 4096 / 2048 / 1024 / 512 envs per GPU.  NAVSIM_EPB = 4 | 8 | 16 forces the envs per workgroup (64: the
-big-shard kernel, rollout_big_kernel, which shards of 16384+ envs select by themselves).
+big-shard kernel, rollout_big_kernel, which shards beyond 4096 envs select by themselves).
 TR_SIZES=16384 TR_MAP=stage_2 TR_PER_ENV=1 TR_T=256 [TR_SIDES=248]: the closed-loop form of BASELINE configs[2] (S=1024 with TR_SIDES).
 usage: python tools/time_rollout.py [lib.so] [policy]"""
 import os, sys
