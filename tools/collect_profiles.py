@@ -14,6 +14,9 @@ for a, b in (("step_seq_final_pmc.txt", "r03_step_seq_pmc.txt"), ("update_final_
              ("rollout_big_pmc.txt", "r03_rollout_big_pmc.txt"), ("rollout_big.txt", "r03_rollout_big.txt"), ("rollout_shard_sizes.txt", "r03_rollout_shard_sizes.txt"),
              ("update_scale.txt", "r03_update_scale.txt"), ("run_id.txt", "r03_run_id.txt"), ("step_cfg3_phase_stamps.txt", "r03_step_cfg3_phase_stamps.txt"),
              ("time_to_reward_resmlp512.txt", "r03_time_to_reward_resmlp512.txt")):
+    if "Traceback" in open(os.path.join(O, a)).read():   # e.g. the phase stamps need build/libnavsim_timing.so (tools/make_timing_build.py)
+        print("skipped (the tool failed on the box):", a)
+        continue
     cp(a, b)
 open(os.path.join(P, "r03_time_rtg.txt"), "w").write("".join(l for l in open(os.path.join(O, "time_rtg.log")) if "amdgpu" not in l))
 
@@ -50,7 +53,7 @@ New kernel: `rollout_big_kernel` (`navsim_rollout_mlp64` beyond 4096 envs per GP
 | `r03_time_to_reward_cfg3.txt` | `TTR_ENVS=16384 TTR_MAP=stage_2 TTR_PER_ENV=1 TTR_ROLLOUT=256 python tools/time_to_reward.py`: PPO on configs[2]'s shard through the closed-loop kernel: +100 mean episode return after 3 iterations (≈0.1 s each), 735 / 68 % success after 23 |
 | `r03_learning_curve.txt` | `python tools/learning_curve.py 400`: the timed workload for 400 iterations = 839 M env-steps in 21.7 s; mean episode return −381 → 1306, success rate 0.03 → 0.88, collisions 0.96 → 0.11 |
 | `r03_update_fixed_cost.txt` | `tools/time_update_fixed.py`: one mlp64x2 epoch at small batches — 31.8 µs with one workgroup, 56.2 µs at one tile per wave, + 30.3 µs per further tile and wave (both nets) → 22 µs of batch-independent cost in the 984 µs epoch of the timed workload |
-| the other `r03_*` files of the list below | re-recorded in the same call on unchanged kernels (`step_kernel` 4.21e6 VALU instructions per launch, resmlp512 epoch 11.2 ms, rollout at 4096 / 2048 / 1024 / 512 envs ≈2.66 ms) |
+| the other `r03_*` files of the list below | (`r03_step_cfg3_phase_stamps.txt` only when the instrumented library was built: `tools/make_timing_build.py`) re-recorded in the same call on unchanged kernels (`step_kernel` 4.21e6 VALU instructions per launch, resmlp512 epoch 11.2 ms, rollout at 4096 / 2048 / 1024 / 512 envs ≈2.66 ms) |
 
 '''
 p = os.path.join(P, "README.md")
