@@ -472,6 +472,7 @@ def main():
         out["roofline_closed_loop_beyond_l3"] = closed_loop_roofline(
             16384, "stage_2", per_env=True, T=64, sides=248,
             detail="closed-loop (policy in the kernel), working set 268 MB per step > Infinity Cache")
+        out["roofline_closed_loop_beyond_l3"]["traffic"] = profiled_traffic("s1024_closed_loop_bytes_per_launch")
         out["roofline_beyond_l3_single_launch"] = step_kernel_roofline(
             16384, "stage_2", per_env=True, iters=64 * 400, sides=248,
             detail="one step per launch; working set 268 MB > Infinity Cache")

@@ -41,6 +41,10 @@ f, w = (counter(c, "--cfg3", "tools/time_rollout.py", "rollout_big_kernel") for 
 out["cfg3_closed_loop"] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "steps_per_launch": 256,
                            "algorithmic_bytes_per_launch": 256 * 16384 * (134 + 16 * 128)}
 out["cfg3_closed_loop_bytes_per_launch"] = int((2 * f + w) * 1024)
+f, w = (counter(c, "--s1024", "tools/time_rollout.py", "rollout_big_kernel") for c in ("FETCH_SIZE", "WRITE_SIZE"))
+out["s1024_closed_loop"] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "steps_per_launch": 64,
+                            "algorithmic_bytes_per_launch": 64 * 16384 * (134 + 16 * 1024)}
+out["s1024_closed_loop_bytes_per_launch"] = int((2 * f + w) * 1024)
 os.makedirs(os.path.join(R, "gpurun_out", RND), exist_ok=True)
 json.dump(out, open(os.path.join(R, "gpurun_out", RND, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -13,6 +13,7 @@ tools/prof_stats.sh step_s1024 -- python tools/time_step.py --s=1024 > $O/step_s
 tools/prof_stats.sh step_seq_cfg3 -- python tools/time_step_seq.py --cfg3 > $O/step_seq_cfg3_rocprof.log 2>&1
 tools/prof_stats.sh step_seq_s1024 -- python tools/time_step_seq.py --s=1024 > $O/step_seq_s1024_rocprof.log 2>&1
 TR_SIZES=16384 TR_MAP=stage_2 TR_PER_ENV=1 TR_T=256 tools/prof_stats.sh rollout_big_cfg3 -- python tools/time_rollout.py > $O/rollout_big_cfg3_rocprof.log 2>&1
+tools/prof_stats.sh rollout_big_s1024 -- python tools/time_rollout.py --s1024 > $O/rollout_big_s1024_rocprof.log 2>&1
 tools/prof_stats.sh update -- python tools/time_update.py navbot_ppo_amd/libnavsim.so > $O/update_rocprof.log 2>&1
 tools/prof_stats.sh resmlp512_update -- python tools/time_update_resmlp.py 2097152 5 > $O/resmlp512_update_rocprof.log 2>&1
 tools/pmc.sh step_final "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU" -- python tools/time_step.py --cfg3 > /dev/null 2>&1

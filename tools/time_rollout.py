@@ -15,6 +15,8 @@ if _libs:
     _native.LIB_PATH = os.path.abspath(_libs[0])
 if "--cfg3" in sys.argv:   # the closed-loop form of BASELINE configs[2] (what bench.py's roofline_closed_loop runs)
     os.environ.update(TR_SIZES="16384", TR_MAP="stage_2", TR_PER_ENV="1", TR_T="256")
+if "--s1024" in sys.argv:   # the same shard past the Infinity Cache (bench.py's roofline_closed_loop_beyond_l3)
+    os.environ.update(TR_SIZES="16384", TR_PER_ENV="1", TR_T="64", TR_SIDES="248")
 _pol = [a for a in sys.argv[1:] if not a.endswith(".so") and not a.startswith("--")]
 policy = _pol[0] if _pol else "mlp64x2"
 from navbot_ppo_amd import maps
