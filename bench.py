@@ -15,12 +15,19 @@ policy, seeded goals).  Default: weak scaling, every GPU owns its own 4096-env s
 are independent envs).  `--scaling strong` keeps 4096 envs IN TOTAL (SURVEY.md 8d(i) read literally): shards of 4096 / N.
 
 Besides the contract fields, rank 0 adds
-  roofline            the ray-cast run of BASELINE configs[2] (16384 envs, per-env stage_2 segment buffers, S=128) as ONE launch per
-                      256-step action tape (navsim_step_seq, steps_kernel): algorithmic bytes (134 + 16*S per env-step, SURVEY.md
-                      8d) x env-steps per launch / mean launch duration from HIP events
-  roofline_single_launch   the same step body launched once per step (navsim_step, step_kernel), 64 launches per graph replay
-  roofline_closed_loop (+ _beyond_l3)   the same runs with the mlp64 policy in the kernel (navsim_rollout_mlp64 at 16384 envs: rollout_big_kernel)
-  roofline_beyond_l3 (+ _single_launch)   the same kernels with S=1024 per env (268 MB per step: past the 256 MiB Infinity Cache)
+  roofline            the ray-cast run of BASELINE configs[2] (16384 envs, per-env stage_2 segment buffers, S=128) through the entry
+                      point the north star names: navsim_step (step_kernel), ONE launch per env step, 64 launches per graph replay:
+                      algorithmic bytes (134 + 16*S per env-step) x envs / mean launch duration from HIP events.
+                      (Rounds 1-2 reported this kernel here; round 3 had put the open-loop tape under this key.)
+  roofline_closed_loop       the same step body with the mlp64 policy in the kernel (navsim_rollout_mlp64 at 16384 envs:
+                      rollout_big_kernel, 256 steps per launch): what PPO.rollout does, the form a trainer can use
+  roofline_open_loop_tape    the same step body, one launch per 256-step action tape (navsim_step_seq): replay / evaluation form only
+  roofline_at_l3 (+ _closed_loop, _open_loop_tape)   the same three with S=1024 per env: 268 MB per step = the Infinity Cache size
+  roofline_hbm (+ _closed_loop, _open_loop_tape)     the same three with S=2048 per env: 537 MB per step = 2x the Infinity Cache, the
+                      HBM-bound regime; `frac` of the 8 TB/s spec, `frac_of_achievable_hbm` of the ~6.3 TB/s the guide calls achievable
+  cfg4_shard / cfg5_shard    one GPU's shard of BASELINE configs[3] (4096 envs, stage_4, 36 beams) and configs[4] (8192 envs, 2048-segment
+                      house map, f16 observations, start / goal tables): us per step (launch per step / tape), env-steps/s
+  traffic_source      which rocprofv3 --pmc file the `traffic` fields come from (--with-pmc-file: the same gpurun call as this run)
   roofline_timed_region   the persistent rollout kernel of the timed workload
   update_roofline     the update kernels of the timed workload (94 % of the timed region): MFMA FLOPs of one epoch / its duration
   time_to_reward_s    PPO wall-clock until mean episode return >= +100 (ppo.py:833) from a fresh policy
@@ -69,21 +76,74 @@ def _event_time_ms(fn, iters, warm=20, per_graph=64):
     return e0.elapsed_time(e1) / (reps * per_graph)
 
 
-def step_kernel_roofline(n_envs, map_name, per_env, iters=640, seed=0, sides=None, detail=""):
-    """HIP-event timing of navsim_step alone (random actions resident in HBM)."""
-    from navbot_ppo_amd import maps
-    from navbot_ppo_amd.env import NavSim
-    seg = maps.stage_2(sides=sides) if sides else maps.by_name(map_name)
-    S = int(seg.shape[0])
-    sim = NavSim(n_envs, max_episode_steps=500, auto_reset=True, seed=seed)
-    rr, rs = maps.goal_rects(map_name)
-    sim.set_goal_rects(0, rr)
-    sim.set_goal_rects(1, rs)
-    sim.set_map(maps.replicate_per_env(seg, n_envs, seed=seed) if per_env else seg)
+HBM_ACHIEVABLE_GBS = 6300.0  # same guide, HBM section: "8 TB/s peak (spec); ~6.3 TB/s achievable"
+
+
+class CastWorkload:
+    """One ray-cast workload (map + shard size + options), built once and shared by the legs that time it (one launch per step,
+    one launch per action tape, closed loop): replicating a per-env map on the host is the slow part at S = 2048."""
+
+    def __init__(self, n_envs, map_name, per_env, sides=None, n_beams=10, obs_f16=False, sampler=None, seed=0, house_segments=None):
+        from navbot_ppo_amd import maps
+        self.n_envs, self.map_name, self.per_env, self.B, self.obs_f16, self.seed = n_envs, map_name, per_env, n_beams, obs_f16, seed
+        if house_segments:
+            seg = maps.house(house_segments)
+        else:
+            seg = maps.stage_2(sides=sides) if sides else maps.by_name(map_name)
+        self.S = int(seg.shape[0])
+        self.rects = maps.goal_rects(map_name)
+        self.sampler = None
+        if sampler:
+            st, g, lo, hi = maps.spawn_tables(sampler)
+            self.sampler = maps.open_tables(seg, st, g) + (lo, hi)
+        if per_env:
+            self.seg = torch.from_numpy(maps.replicate_per_env(seg, n_envs, seed=seed)).cuda()
+        else:
+            self.seg = torch.from_numpy(np.ascontiguousarray(seg)).cuda()
+        # SURVEY.md 8(d): reads 44 B + writes 26 + 4 (B + 6) B per env-step (f16 observations: 26 + 2 (B + 6)); B = 10, f32: 134 B;
+        # + 16 S with a per-env map
+        self.bytes_per_env_step = 70 + (2 if obs_f16 else 4) * (n_beams + 6) + (16 * self.S if per_env else 0)
+        assert n_beams != 10 or obs_f16 or self.bytes_per_env_step == 134 + (16 * self.S if per_env else 0)
+
+    def alg_bytes(self, steps):
+        return steps * self.n_envs * self.bytes_per_env_step + (0 if self.per_env else 16 * self.S)
+
+    def sim(self):
+        from navbot_ppo_amd.env import NavSim
+        sim = NavSim(self.n_envs, n_beams=self.B, max_episode_steps=500, auto_reset=True, seed=self.seed, obs_f16=self.obs_f16)
+        sim.set_goal_rects(0, self.rects[0])
+        sim.set_goal_rects(1, self.rects[1])
+        sim.set_map(self.seg, per_env=self.per_env)
+        if self.sampler:
+            sim.set_spawn_sampler(*self.sampler)
+        return sim
+
+    def describe(self, steps=None):
+        return (f"{self.n_envs} envs" + (f" x {steps} steps" if steps else "") + f", {self.map_name} ({self.S} segments, "
+                f"{'per-env' if self.per_env else 'shared'} map), {self.B} beams" + (", f16 observations" if self.obs_f16 else ""))
+
+    def leg(self, kernel, ms, steps, detail, **extra):
+        alg = self.alg_bytes(steps)
+        ach = alg / (ms * 1e-3) / 1e9
+        d = dict(bound="hbm", bound_detail=detail, kernel=kernel, workload=self.describe(steps if steps > 1 else None),
+                 achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
+                 frac_of_achievable_hbm=round(ach / HBM_ACHIEVABLE_GBS, 5), traffic=None, launch_us=round(ms * 1e3, 3),
+                 algorithmic_bytes_per_launch=int(alg), bytes_per_env_step=self.bytes_per_env_step,
+                 env_steps_per_sec=round(steps * self.n_envs / (ms * 1e-3), 1))
+        if steps > 1:
+            d.update(steps_per_launch=steps, us_per_step=round(ms * 1e3 / steps, 3))
+        d.update(extra)
+        return d
+
+
+def step_kernel_roofline(w, iters=640, detail=""):
+    """HIP-event timing of navsim_step alone -- ONE launch per env step, the entry point a policy outside the kernel drives
+    (Env.step, environment_new.py:272-310) -- with random actions resident in HBM."""
+    sim = w.sim()
     io = sim.alloc_io()
     sim.reset(io.obs)
-    g = torch.Generator(device="cuda").manual_seed(seed)
-    acts = torch.rand((64, n_envs, 2), device="cuda", generator=g)
+    g = torch.Generator(device="cuda").manual_seed(w.seed)
+    acts = torch.rand((64, w.n_envs, 2), device="cuda", generator=g)
     acts[..., 1] = acts[..., 1] * 2 - 1
     k = [0]
 
@@ -92,35 +152,21 @@ def step_kernel_roofline(n_envs, map_name, per_env, iters=640, seed=0, sides=Non
         k[0] += 1
 
     ms = _event_time_ms(launch, iters)
-    bytes_per_env_step = 134 + (16 * S if per_env else 0)
-    alg_bytes = n_envs * bytes_per_env_step + (0 if per_env else 16 * S)
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
     sim.close()
-    return dict(bound="hbm", bound_detail=detail, kernel="step_kernel<10,%s>" % ("per_env" if per_env else "shared"),
-                workload=f"{n_envs} envs, {map_name} ({S} segments, {'per-env' if per_env else 'shared'} map), 10 beams",
-                achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
-                traffic=None, launch_us=round(ms * 1e3, 3), algorithmic_bytes_per_launch=int(alg_bytes),
-                bytes_per_env_step=bytes_per_env_step, env_steps_per_sec=round(n_envs / (ms * 1e-3), 1))
+    return w.leg("step_kernel<%d beams,%s> (navsim_step: one launch per step)" % (w.B, "per_env" if w.per_env else "shared"), ms, 1, detail)
 
 
-def step_seq_roofline(n_envs, map_name, per_env, T, reps=12, seed=0, sides=None, detail=""):
+def step_seq_roofline(w, T, reps=12, detail=""):
     """HIP-event timing of navsim_step_seq: T steps of a random action tape (resident in HBM) per launch, the env state on chip
     between the steps.  Algorithmic bytes per launch = T x n_envs x (134 + 16 S) (SURVEY.md 8(d) per env-step)."""
-    from navbot_ppo_amd import maps
-    from navbot_ppo_amd.env import NavSim
-    seg = maps.stage_2(sides=sides) if sides else maps.by_name(map_name)
-    S = int(seg.shape[0])
-    sim = NavSim(n_envs, max_episode_steps=500, auto_reset=True, seed=seed)
-    rr, rs = maps.goal_rects(map_name)
-    sim.set_goal_rects(0, rr)
-    sim.set_goal_rects(1, rs)
-    sim.set_map(maps.replicate_per_env(seg, n_envs, seed=seed) if per_env else seg)
+    sim = w.sim()
+    n_envs = w.n_envs
     io = sim.alloc_io()
     sim.reset(io.obs)
-    g = torch.Generator(device="cuda").manual_seed(seed)
+    g = torch.Generator(device="cuda").manual_seed(w.seed)
     acts = torch.rand((T, n_envs, 2), device="cuda", generator=g)
     acts[..., 1] = acts[..., 1] * 2 - 1
-    obs = torch.zeros((T, n_envs, sim.D), device="cuda")
+    obs = torch.zeros((T, n_envs, sim.D), dtype=sim.obs_dtype, device="cuda")
     rew, epr = torch.zeros((T, n_envs), device="cuda"), torch.zeros((T, n_envs), device="cuda")
     done, arrive, ended = (torch.zeros((T, n_envs), dtype=torch.uint8, device="cuda") for _ in range(3))
     epl = torch.zeros((T, n_envs), dtype=torch.int32, device="cuda")
@@ -135,17 +181,9 @@ def step_seq_roofline(n_envs, map_name, per_env, T, reps=12, seed=0, sides=None,
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    bytes_per_env_step = 134 + (16 * S if per_env else 0)
-    alg_bytes = T * n_envs * bytes_per_env_step + (0 if per_env else 16 * S)
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
     sim.close()
-    return dict(bound="hbm", bound_detail=detail,
-                kernel="steps_kernel<10,%s> (navsim_step_seq: %d steps per launch, same step body as step_kernel)" % ("per_env" if per_env else "shared", T),
-                workload=f"{n_envs} envs x {T} steps, {map_name} ({S} segments, {'per-env' if per_env else 'shared'} map), 10 beams",
-                achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
-                launch_us=round(ms * 1e3, 2), steps_per_launch=T, us_per_step=round(ms * 1e3 / T, 3),
-                algorithmic_bytes_per_launch=int(alg_bytes), bytes_per_env_step=bytes_per_env_step,
-                env_steps_per_sec=round(T * n_envs / (ms * 1e-3), 1))
+    return w.leg("steps_kernel<%d beams,%s> (navsim_step_seq: %d steps per launch, same step body as step_kernel)"
+                 % (w.B, "per_env" if w.per_env else "shared", T), ms, T, detail)
 
 
 def cpu_baseline(n_envs, procs, budget_s):
@@ -159,20 +197,17 @@ def cpu_baseline(n_envs, procs, budget_s):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-def closed_loop_roofline(n_envs, map_name, per_env, T, reps=8, seed=0, sides=None, detail=""):
+def closed_loop_roofline(w, T, reps=8, detail=""):
     """HIP-event timing of navsim_rollout_mlp64 at a configs[2]-sized shard (rollout_big_kernel): the ray-cast run CLOSED-LOOP -- the
     16-64-64 actor chooses every action from the observation the previous step left on chip (PPO.rollout, ppo.py:505-594), T steps
     per launch.  Algorithmic bytes per launch = T x n_envs x (134 + 16 S), the env-step figure of SURVEY.md 8(d): the 12 bytes of
     action + log-prob the policy adds per env-step are not counted."""
-    from navbot_ppo_amd import maps, ppo
+    from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
-    seg = maps.stage_2(sides=sides) if sides else maps.by_name(map_name)
-    S = int(seg.shape[0])
-    env = VecEnv(n_envs, map=seg, max_episode_steps=500, seed=seed, per_env_map=per_env)
-    rr, rs = maps.goal_rects(map_name)
-    env.sim.set_goal_rects(0, rr)
-    env.sim.set_goal_rects(1, rs)
-    tr = ppo.PPOTrainer(env, ppo.PPOConfig(policy="mlp64x2", rollout_len=T, max_episode_steps=500, seed=seed))
+    env = VecEnv(w.n_envs, map=w.seg, max_episode_steps=500, seed=w.seed)
+    env.sim.set_goal_rects(0, w.rects[0])
+    env.sim.set_goal_rects(1, w.rects[1])
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(policy="mlp64x2", rollout_len=T, max_episode_steps=500, seed=w.seed))
     assert tr.updater.fused_mlp64
     env.sim.reset(tr.obs_buf[0])
     for _ in range(2):
@@ -185,19 +220,11 @@ def closed_loop_roofline(n_envs, map_name, per_env, T, reps=8, seed=0, sides=Non
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    bytes_per_env_step = 134 + (16 * S if per_env else 0)
-    alg_bytes = T * n_envs * bytes_per_env_step + (0 if per_env else 16 * S)
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
     env.close()
-    return dict(bound="hbm", bound_detail=detail,
-                kernel="rollout_big_kernel<64 envs, 16 waves, %s> (navsim_rollout_mlp64: %d steps per launch, policy phase + the step "
-                       "body of step_kernel)" % ("per_env" if per_env else "shared", T),
-                workload=f"{n_envs} envs x {T} steps, {map_name} ({S} segments, {'per-env' if per_env else 'shared'} map), 10 beams, "
-                         "16-64-64 policy in-kernel",
-                achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
-                launch_us=round(ms * 1e3, 2), steps_per_launch=T, us_per_step=round(ms * 1e3 / T, 3),
-                algorithmic_bytes_per_launch=int(alg_bytes), bytes_per_env_step=bytes_per_env_step,
-                env_steps_per_sec=round(T * n_envs / (ms * 1e-3), 1))
+    d = w.leg("rollout_big_kernel<64 envs, 16 waves, %s> (navsim_rollout_mlp64: %d steps per launch, policy phase + the step "
+              "body of step_kernel)" % ("per_env" if w.per_env else "shared", T), ms, T, detail)
+    d["workload"] += ", 16-64-64 policy in-kernel"
+    return d
 
 
 def rollout_kernel_leg(trainer, reps=6):
@@ -352,11 +379,15 @@ def env_n1_step_us(budget_s=1.5):
     return round(dt / (n - n0) * 1e6, 2)
 
 
+PMC_FILE = [None]   # --with-pmc-file: counters recorded in the SAME gpurun call as this bench run (tools/prof_all.sh)
+
+
 def profiled_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh -> profiles/pmc_traffic.json),
-    used only while the file was recorded from THIS kernel source (sha256 of csrc/navsim.hip), else None."""
+    """HBM bytes per launch from rocprofv3 --pmc passes (tools/pmc_traffic.py): the file given with --with-pmc-file (recorded in
+    the same call as this run), else the committed profiles/pmc_traffic.json; either is used only while it was recorded from THIS
+    kernel source (sha256 of csrc/navsim.hip), else None."""
     import hashlib
-    f = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    f = PMC_FILE[0] or os.path.join(REPO, "profiles", "pmc_traffic.json")
     src = os.path.join(REPO, "navbot_ppo_amd", "csrc", "navsim.hip")
     if not (os.path.exists(f) and os.path.exists(src)):
         return None
@@ -364,6 +395,31 @@ def profiled_traffic(key):
     if d.get("navsim_hip_sha256") != hashlib.sha256(open(src, "rb").read()).hexdigest():
         return None
     return d.get(key)
+
+
+def traffic_source():
+    f = PMC_FILE[0] or os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    return dict(file=os.path.relpath(f, REPO), run_id=d.get("run_id"), recorded_utc=d.get("recorded_utc"),
+                same_call_as_this_run=bool(PMC_FILE[0]) and d.get("run_id") == os.environ.get("PROF_RUN_ID"))
+
+
+def pmc_field(key):
+    """VALU-issue figures of a leg from the same pmc file (tools/pmc_traffic.py records SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU /
+    SQ_BUSY_CYCLES passes for the shard legs), or None."""
+    return profiled_traffic(key)
+
+
+def shard_leg(w, T, detail):
+    """One GPU's shard of a BASELINE 8-GPU configuration: us per step one launch per step and one launch per tape, env-steps/s."""
+    a = step_kernel_roofline(w, iters=64 * 200, detail=detail)
+    b = step_seq_roofline(w, T, reps=6, detail=detail)
+    return dict(workload=w.describe(), step_us=a["launch_us"], tape_us_per_step=b["us_per_step"], env_steps_per_sec_step=a["env_steps_per_sec"],
+                env_steps_per_sec_tape=b["env_steps_per_sec"], bytes_per_env_step=w.bytes_per_env_step,
+                hbm_frac_step=a["frac"], hbm_frac_tape=b["frac"], bound_detail=detail,
+                ray_segment_tests_per_sec_tape=round(w.n_envs * w.S * w.B / (b["us_per_step"] * 1e-6), 1))
 
 
 def main():
@@ -380,9 +436,12 @@ def main():
     ap.add_argument("--policy", default="mlp64x2")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline legs")
+    ap.add_argument("--with-pmc-file", default=None,
+                    help="pmc_traffic.json recorded by tools/pmc_traffic.py in the same gpurun call (roofline.traffic comes from it)")
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="N > 1, mlp64x2: the two-stage per-net pipeline instead of one all-reduce of the flat gradient per epoch")
     args = ap.parse_args()
+    PMC_FILE[0] = args.with_pmc_file
 
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
@@ -450,33 +509,57 @@ def main():
         out["update_roofline"] = mlp64_update_roofline(trainer)
         del trainer
         torch.cuda.empty_cache()
-        # the ray-cast run of BASELINE configs[2]: a 256-step action tape per launch (navsim_step_seq), and the same step body
-        # launched once per step (navsim_step) beside it
-        out["roofline"] = step_seq_roofline(
-            16384, "stage_2", per_env=True, T=256,
-            detail="working set 35.7 MB per step sits in the 256 MiB Infinity Cache: L3-fed, VALU-issue bound at this size")
-        out["roofline"]["traffic"] = profiled_traffic("cfg3_seq_bytes_per_launch")
-        out["roofline_single_launch"] = step_kernel_roofline(
-            16384, "stage_2", per_env=True, iters=64 * 1500,
-            detail="one step per launch: + launch ramp of 256 x 16 waves, state round trips, graph-node boundary")
-        out["roofline_single_launch"]["traffic"] = profiled_traffic("cfg3_step_bytes_per_launch")
+        # The ray-cast run of BASELINE configs[2].  `roofline` is the entry point the north star names -- navsim_step, ONE launch per
+        # env step, what a policy outside the kernel drives (Env.step, environment_new.py:272-310; like for like with rounds 1-2) --
+        # and beside it the two persistent forms of the same step body: closed loop (the 16-64-64 policy in the kernel: PPO.rollout,
+        # ppo.py:505-594) and an open-loop action tape (replay / evaluation form: the actions do not depend on the observations).
+        l3 = "working set 35.7 MB per step sits in the 256 MiB Infinity Cache: L3-fed, VALU-issue bound at this size"
+        w = CastWorkload(16384, "stage_2", per_env=True)
+        out["roofline"] = step_kernel_roofline(
+            w, iters=64 * 1500, detail=l3 + "; one step per launch: + launch ramp of 256 x 16 waves, state round trips, graph-node boundary")
+        out["roofline"]["traffic"] = profiled_traffic("cfg3_step_bytes_per_launch")
         out["roofline_closed_loop"] = closed_loop_roofline(
-            16384, "stage_2", per_env=True, T=256,
-            detail="the same ray-cast run with the 16-64-64 policy choosing every action in-kernel (PPO.rollout closed-loop): + the "
-                   "policy phase, bound by the SIMDs' f32 MFMA pipes (64 envs x 10.2 kFLOP per CU and step = 1.07 us)")
+            w, T=256, detail=l3 + "; the 16-64-64 policy chooses every action in-kernel (PPO.rollout closed-loop): + the policy phase, "
+                               "bound by the SIMDs' f32 MFMA pipes (64 envs x 10.2 kFLOP per CU and step = 1.07 us)")
         out["roofline_closed_loop"]["traffic"] = profiled_traffic("cfg3_closed_loop_bytes_per_launch")
-        out["roofline_beyond_l3"] = step_seq_roofline(
-            16384, "stage_2", per_env=True, T=64, sides=248,
-            detail="working set 268 MB per step > Infinity Cache: the segment stream comes from HBM")
-        out["roofline_beyond_l3"]["traffic"] = profiled_traffic("s1024_seq_bytes_per_launch")
-        out["roofline_closed_loop_beyond_l3"] = closed_loop_roofline(
-            16384, "stage_2", per_env=True, T=64, sides=248,
-            detail="closed-loop (policy in the kernel), working set 268 MB per step > Infinity Cache")
-        out["roofline_closed_loop_beyond_l3"]["traffic"] = profiled_traffic("s1024_closed_loop_bytes_per_launch")
-        out["roofline_beyond_l3_single_launch"] = step_kernel_roofline(
-            16384, "stage_2", per_env=True, iters=64 * 400, sides=248,
-            detail="one step per launch; working set 268 MB > Infinity Cache")
-        out["roofline_beyond_l3_single_launch"]["traffic"] = profiled_traffic("s1024_step_bytes_per_launch")
+        out["roofline_open_loop_tape"] = step_seq_roofline(
+            w, T=256, detail=l3 + "; open loop: the 256 actions of a launch are known ahead (replay / evaluation), NOT what PPO.rollout does")
+        out["roofline_open_loop_tape"]["traffic"] = profiled_traffic("cfg3_seq_bytes_per_launch")
+        del w
+        # the same three at S = 1024 per env: 16384 x 1024 x 16 B = exactly 256 MiB = the Infinity Cache size (AT the L3, not beyond it)
+        at = "segment stream 268 MB per step = the 256 MiB Infinity Cache size: no L2 reuse, L3 hits possible"
+        w = CastWorkload(16384, "stage_2", per_env=True, sides=248)
+        out["roofline_at_l3"] = step_kernel_roofline(w, iters=64 * 400, detail=at + "; one step per launch")
+        out["roofline_at_l3"]["traffic"] = profiled_traffic("s1024_step_bytes_per_launch")
+        out["roofline_at_l3_closed_loop"] = closed_loop_roofline(w, T=64, detail=at + "; closed loop (policy in the kernel)")
+        out["roofline_at_l3_closed_loop"]["traffic"] = profiled_traffic("s1024_closed_loop_bytes_per_launch")
+        out["roofline_at_l3_open_loop_tape"] = step_seq_roofline(w, T=64, detail=at + "; open-loop tape")
+        out["roofline_at_l3_open_loop_tape"]["traffic"] = profiled_traffic("s1024_seq_bytes_per_launch")
+        del w
+        torch.cuda.empty_cache()
+        # ... and at S = 2048 per env (the size SURVEY.md section 7 names for the HBM-bound regime): 512 MiB per step = 2x the Infinity
+        # Cache, so every segment byte of a step comes from HBM; frac = of the 8 TB/s spec, frac_of_achievable_hbm = of the ~6.3 TB/s
+        # the guide gives as achievable
+        hb = "segment stream 537 MB per step = 2x the 256 MiB Infinity Cache: HBM-bound"
+        w = CastWorkload(16384, "stage_2", per_env=True, sides=504)
+        out["roofline_hbm"] = step_kernel_roofline(w, iters=64 * 200, detail=hb + "; one step per launch")
+        out["roofline_hbm"]["traffic"] = profiled_traffic("s2048_step_bytes_per_launch")
+        out["roofline_hbm_closed_loop"] = closed_loop_roofline(w, T=32, reps=6, detail=hb + "; closed loop (policy in the kernel)")
+        out["roofline_hbm_closed_loop"]["traffic"] = profiled_traffic("s2048_closed_loop_bytes_per_launch")
+        out["roofline_hbm_open_loop_tape"] = step_seq_roofline(w, T=32, reps=6, detail=hb + "; open-loop tape")
+        out["roofline_hbm_open_loop_tape"]["traffic"] = profiled_traffic("s2048_seq_bytes_per_launch")
+        del w
+        torch.cuda.empty_cache()
+        out["traffic_source"] = traffic_source()
+        # one GPU's shard of the two 8-GPU configurations of BASELINE.json (shared maps: VALU-bound, SURVEY 8d caveat -- the byte
+        # fraction is nominal there, the vector-issue fraction from the counters says how busy the SIMDs are)
+        out["cfg4_shard"] = shard_leg(CastWorkload(4096, "stage_4", per_env=False, n_beams=36), 128,
+                                      "BASELINE configs[3] per GPU: 32768 / 8 envs, stage_4 (64 segments, shared), 36 beams")
+        out["cfg4_shard"]["valu"] = pmc_field("cfg4_valu")
+        out["cfg5_shard"] = shard_leg(CastWorkload(8192, "house", per_env=False, obs_f16=True, sampler="small_house", house_segments=2048), 64,
+                                      "BASELINE configs[4] per GPU: 65536 / 8 envs, 2048-segment house map (shared, tile boxes), f16 "
+                                      "observations, start / goal tables")
+        out["cfg5_shard"]["valu"] = pmc_field("cfg5_valu")
         if ctx.world == 1:
             ttr = time_to_reward(n_local)
             out["time_to_reward_s"] = ttr["seconds"]

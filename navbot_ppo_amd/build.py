@@ -38,10 +38,31 @@ def needs_build():
 # against 82-101 VGPRs (two workgroups per CU) with the pass off.  The single-step kernels have no such loop and do not change.
 EXTRA_FLAGS = {"navsim.hip": ["-mllvm", "-disable-machine-licm"]}
 
+_flag_ok = {}
+
+
+def flags_accepted(flags):
+    """-mllvm options are internal to LLVM and unversioned: probe them once on an empty translation unit, so that a hipcc that
+    no longer knows one builds without it (slower persistent kernels, same results) instead of failing the build."""
+    key = tuple(flags)
+    if key not in _flag_ok:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            open(src, "w").write("#include <hip/hip_runtime.h>\n__global__ void probe() {}\n")
+            r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-c", src, "-o", os.path.join(d, "probe.o")] + list(flags),
+                               capture_output=True, text=True)
+        _flag_ok[key] = r.returncode == 0
+        if not _flag_ok[key]:
+            print(f"navbot_ppo_amd.build: hipcc rejects {' '.join(flags)} -- building without it", flush=True)
+    return _flag_ok[key]
+
 
 def build_native(force=False, verbose=False, navsim_src=None, out=None, extra=()):
     """navsim_src / out / extra: dev tools build variants of csrc/navsim.hip (patched copies, instrumented builds) as another
     library with exactly the product's flags."""
+    if navsim_src is not None and out is None:
+        raise ValueError("build_native: a variant source (navsim_src) needs its own output library (out)")
     if navsim_src is None and not force and not needs_build():
         return LIB
     tag = "" if navsim_src is None else "_" + os.path.splitext(os.path.basename(out))[0]
@@ -54,6 +75,8 @@ def build_native(force=False, verbose=False, navsim_src=None, out=None, extra=()
     for k, src in enumerate(srcs):   # the sources compile side by side
         obj = os.path.join(objdir, os.path.basename(SRCS[k]) + ".o")
         per_src = [] if os.environ.get("NAVSIM_NO_EXTRA_FLAGS") == "1" else EXTRA_FLAGS.get(os.path.basename(SRCS[k]), [])   # (A/B builds)
+        if per_src and not flags_accepted(per_src):
+            per_src = []
         cmd = ([hipcc()] + compile_flags + per_src + (list(extra) if k == 0 else []) +
                ["-I", INC, "-I", os.path.join(HERE, "csrc"), "-c", src, "-o", obj])
         if verbose:

@@ -1205,22 +1205,21 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     }
 }
 
-// The kernarg segment of step_kernel as the compiler lays it out (members at their natural alignment, in order).
+// The kernarg segment of step_kernel: the kernel takes this struct as its ONLY by-value parameter, so the segment IS the struct
+// (members at their natural alignment, in order) and the reads through the segment pointer below cannot drift from the signature.
 struct StepKArgs {
     Params P;
     StepIO io;
 };
 typedef const StepKArgs __attribute__((address_space(4))) * StepKArgsPtr;
+static_assert(std::is_trivially_copyable<StepKArgs>::value && offsetof(StepKArgs, P) == 0 && sizeof(StepIO) == 10 * sizeof(void*),
+              "kernarg mirror of step_kernel");
 
 template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, bool PAIR = false>
-__global__ __launch_bounds__(64 * NW) void step_kernel(Params, const float2* __restrict__, const float2* __restrict__, void* __restrict__,
-                                                        float* __restrict__, uint8_t* __restrict__, uint8_t* __restrict__,
-                                                        uint8_t* __restrict__, float* __restrict__, int32_t* __restrict__,
-                                                        float* __restrict__) {
+__global__ __launch_bounds__(64 * NW) void step_kernel(StepKArgs) {
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
-    // the parameters are read through the kernarg segment pointer (see step_body); the named parameters above only give the
-    // launch its signature
+    // the parameter is read through the kernarg segment pointer (see step_body): scalar loads at each use
     StepKArgsPtr A = (StepKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(A));
     step_body<NB, EPB, SENS, false, NW, BOXES, PAIR, const Params __attribute__((address_space(4)))&,
@@ -1341,8 +1340,10 @@ struct SeqKArgs {
 };
 typedef const SeqKArgs __attribute__((address_space(4))) * SeqKArgsPtr;
 
+static_assert(std::is_trivially_copyable<SeqKArgs>::value && offsetof(SeqKArgs, P) == 0, "kernarg mirror of steps_kernel");
+
 template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, bool PAIR = false>
-__global__ __launch_bounds__(64 * NW) void steps_kernel(Params, SeqArgs) {
+__global__ __launch_bounds__(64 * NW) void steps_kernel(SeqKArgs) {   // the segment IS the struct (see step_kernel)
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
     // parameters through the kernarg segment pointer, as in step_kernel (scalar loads at each use, no spilled SGPRs)
@@ -1398,8 +1399,10 @@ struct BigKArgs {
 };
 typedef const BigKArgs __attribute__((address_space(4))) * BigKArgsPtr;
 
+static_assert(std::is_trivially_copyable<BigKArgs>::value && offsetof(BigKArgs, P) == 0, "kernarg mirror of rollout_big_kernel");
+
 template <int EPB, bool SENS, int NW, bool BOXES = false, bool PAIR = false>
-__global__ __launch_bounds__(64 * NW) void rollout_big_kernel(Params, RolloutArgs, StepIO) {
+__global__ __launch_bounds__(64 * NW) void rollout_big_kernel(BigKArgs) {   // the segment IS the struct (see step_kernel)
     constexpr int NB = 10, D = NB + 6, DP = D + 1, kThreads = 64 * NW;
     constexpr int TW = EPB / 16;   // policy tiles = MFMA waves of the policy phase
     static_assert(D == mlp64::IN, "the 16-64-64 policy reads 16-wide observations");
@@ -1764,9 +1767,10 @@ template <int NB>
 static void launch_step(const navsim* h, const float* action, const float* past, void* obs, float* reward, uint8_t* done,
                         uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len, float* ep_path, hipStream_t st) {
     const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
+    const StepKArgs ka = {h->P, StepIO{(const float2*)action, (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len,
+                                       ep_path}};
     auto go = [&](auto kernel, int epb, int nw) {
-        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, h->P, (const float2*)action,
-                           (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len, ep_path);
+        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
     };
     const int epb = pick_epb(h->P.N);
     const bool boxes = h->P.tile_box != nullptr;   // shared map with tile bounding boxes (navsim_set_map)
@@ -1801,8 +1805,9 @@ static void launch_step(const navsim* h, const float* action, const float* past,
 template <int NB>
 static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st) {
     const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
+    const SeqKArgs ka = {h->P, R};
     auto go = [&](auto kernel, int epb, int nw) {
-        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, h->P, R);
+        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
     };
     const int epb = pick_epb(h->P.N);   // the shapes and cast variants of launch_step
     const bool boxes = h->P.tile_box != nullptr;
@@ -2193,10 +2198,11 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
         io.reward = reward_dev; io.done = done_dev; io.arrive = arrive_dev; io.ended = ended_dev;
         io.ep_return = ep_return_dev; io.ep_length = ep_length_dev; io.ep_path_out = ep_path_dev;
         const dim3 grid((h->P.N + 63) / 64), block(64 * 16);
+        const BigKArgs ka = {h->P, R, io};
 #define NAVSIM_BIG(BOXES_, PAIR_)                                                                                         \
     do {                                                                                                                  \
-        if (sens) hipLaunchKernelGGL((rollout_big_kernel<64, true, 16, BOXES_, PAIR_>), grid, block, 0, st, h->P, R, io);   \
-        else hipLaunchKernelGGL((rollout_big_kernel<64, false, 16, BOXES_, PAIR_>), grid, block, 0, st, h->P, R, io);       \
+        if (sens) hipLaunchKernelGGL((rollout_big_kernel<64, true, 16, BOXES_, PAIR_>), grid, block, 0, st, ka);   \
+        else hipLaunchKernelGGL((rollout_big_kernel<64, false, 16, BOXES_, PAIR_>), grid, block, 0, st, ka);       \
     } while (0)
         if (boxes) NAVSIM_BIG(true, false);
         else if (pair) NAVSIM_BIG(false, true);

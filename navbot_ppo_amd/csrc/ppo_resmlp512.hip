@@ -868,12 +868,12 @@ thread_local std::string g_err;
 
 struct Plan {
     int groups, wgs, e_blocks;
-    float *p1, *h1, *p2, *dy2, *qb, *dy1, *wpart, *epart;
+    float *p1, *h1, *p2, *dy2, *qb, *wpart, *epart;
 };
 
 size_t ws_floats(int64_t n) {
     const size_t N = (size_t)n;
-    return 2 * N * (NSL * 16 + 16 + NSL * 32 + 32 + NSL * 16 + 16) + (size_t)kWRows * PSTRIDE + (size_t)2 * kEMaxBlocks * EP + 64;
+    return 2 * N * (NSL * 16 + 16 + NSL * 32 + 32 + NSL * 16) + (size_t)kWRows * PSTRIDE + (size_t)2 * kEMaxBlocks * EP + 64;
 }
 
 Plan make_plan(void* ws, int64_t n, int n_nets) {
@@ -894,7 +894,6 @@ Plan make_plan(void* ws, int64_t n, int n_nets) {
     p.p2 = f; f += 2 * NSL * N * 32;
     p.dy2 = f; f += 2 * N * 32;
     p.qb = f; f += 2 * NSL * N * 16;
-    p.dy1 = f; f += 2 * N * 16;
     p.wpart = f; f += (size_t)kWRows * PSTRIDE;
     p.epart = f;
     return p;

@@ -561,9 +561,14 @@ class PPOTrainer:
         if cfg.gae_lambda is None:
             rtg_scan(self.rew_buf, self.ended_buf, cfg.gamma, out=self.rtg_buf)  # ppo.py:619 -> 643-671
         else:   # extension: the critic's values of the stored observations -> lambda-returns (critic targets) and advantages
+            # lambda < 1: the envs still running at the batch end are bootstrapped with V(obs_buf[T]), the observation behind the last
+            # row (an env that ended on the last row has ended[T-1] set, which cuts the bootstrap).  lambda = 1 keeps the reference's
+            # convention -- the batch end is terminal, ppo.py:601,658-666 -- and stays bit-identical to compute_rtgs.
             T, N, D = cfg.rollout_len, self.env.N, self.env.D
-            V = self.updater.value(self.obs_buf[:T].reshape(T * N, D)).reshape(T, N)
-            adv, ret = gae_scan(self.rew_buf, self.ended_buf, V, cfg.gamma, cfg.gae_lambda)
+            boot = cfg.gae_lambda < 1.0
+            Vall = self.updater.value(self.obs_buf[:T + 1 if boot else T].reshape(-1, D)).reshape(-1, N)
+            V = Vall[:T].contiguous()
+            adv, ret = gae_scan(self.rew_buf, self.ended_buf, V, cfg.gamma, cfg.gae_lambda, last_value=Vall[T] if boot else None)
             self.rtg_buf.copy_(ret)
             self._gae = (adv.reshape(T * N), V.reshape(T * N))
         self.env_steps += cfg.rollout_len * self.env.N

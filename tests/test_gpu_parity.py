@@ -916,17 +916,22 @@ def test_step_seq_equals_step_launches(case):
     assert int(a["ended"].sum()) > 0 or case == "no_reset"
 
 
-def test_step_seq_against_the_oracle():
-    """navsim_step_seq checked DIRECTLY against the CPU oracle (not only against the per-step launches): 48 steps of 512 envs on
-    per-env stage_2 maps with auto-reset and arrival re-spawn; flags exact, observations 1e-6, rewards, episode statistics."""
-    N, T = 512, 48
-    seg = maps.replicate_per_env(maps.stage_2(), N, seed=2)
-    gpu, cpu = _mk(N, seg, per_env=True, max_episode_steps=20, auto_reset=True, respawn_on_arrive=True, seed=9)
-    rng = np.random.default_rng(11)
-    acts = _actions(rng, T, N)
+def _seq_vs_oracle(N, seg, per_env, T, blocks, rects=None, sampler=None, acts_seed=11, **kw):
+    """navsim_step_seq on all N envs (the shard size picks the workgroup shape and the cast variant), then the envs of `blocks`
+    (a list of (first env, count)) replayed on the CPU oracle keyed by the same global env ids: flags exact, observations 1e-6,
+    rewards, episode statistics, final state."""
+    from navbot_ppo_amd.env import NavSim
+    gpu = NavSim(N, **kw)
+    if rects:
+        rr, rs = maps.goal_rects(rects)
+        gpu.set_goal_rects(0, rr)
+        gpu.set_goal_rects(1, rs)
+    gpu.set_map(seg, per_env=per_env)
+    if sampler:
+        gpu.set_spawn_sampler(*sampler)
+    acts = _actions(np.random.default_rng(acts_seed), T, N)
     io = gpu.alloc_io()
-    gpu.reset(io.obs)
-    cpu.reset()
+    obs0 = gpu.reset(io.obs).cpu().numpy()
     dev = gpu.device
     obs = torch.zeros((T, N, gpu.D), device=dev)
     rew, epr, epp = (torch.zeros((T, N), device=dev) for _ in range(3))
@@ -934,26 +939,67 @@ def test_step_seq_against_the_oracle():
     epl = torch.zeros((T, N), dtype=torch.int32, device=dev)
     gpu.step_seq(torch.from_numpy(acts).to(dev), obs, rew, done, arrive, ended, epr, epl, epp)
     torch.cuda.synchronize()
-    exact = 0
-    for t in range(T):
-        out = cpu.step(acts[t])
-        np.testing.assert_array_equal(done[t].cpu().numpy(), out["done"])
-        np.testing.assert_array_equal(arrive[t].cpu().numpy(), out["arrive"])
-        np.testing.assert_array_equal(ended[t].cpu().numpy(), out["ended"])
-        og = obs[t].cpu().numpy()
-        np.testing.assert_allclose(og, out["obs"], rtol=0, atol=OBS_ATOL)
-        np.testing.assert_allclose(rew[t].cpu().numpy(), out["reward"], rtol=REW_RTOL, atol=1e-5)
-        e = out["ended"].astype(bool)
-        np.testing.assert_array_equal(epl[t].cpu().numpy()[e], out["ep_length"][e])
-        np.testing.assert_allclose(epr[t].cpu().numpy()[e], out["ep_return"][e], rtol=REW_RTOL, atol=1e-4)
-        np.testing.assert_allclose(epp[t].cpu().numpy()[e], out["ep_path"][e], rtol=1e-6, atol=1e-7)
-        exact += int((og == out["obs"]).all(axis=1).sum())
-    assert exact > 0.99 * T * N
-    sg, sc = gpu.get_state(), cpu.get_state()
-    np.testing.assert_allclose(sg["pose"], sc["pose"], rtol=0, atol=1e-11)
-    np.testing.assert_array_equal(sg["goal"], sc["goal"])
-    np.testing.assert_array_equal(sg["ep_step"], sc["ep_step"])
-    np.testing.assert_array_equal(sg["rng_ctr"], sc["rng_ctr"])
+    sg = gpu.get_state()
+    g = {k: v.cpu().numpy() for k, v in dict(obs=obs, rew=rew, done=done, arrive=arrive, ended=ended, epr=epr, epl=epl, epp=epp).items()}
+    exact = total = n_end = 0
+    for lo, n in blocks:
+        sl = slice(lo, lo + n)
+        cpu = O.OracleSim(n, **{k: v for k, v in kw.items() if k not in ("obs_f16", "env_id_base")},
+                          env_id_base=kw.get("env_id_base", 0) + lo)
+        if rects:
+            cpu.set_goal_rects(0, rr)
+            cpu.set_goal_rects(1, rs)
+        cpu.set_map(np.ascontiguousarray(seg[sl]) if per_env else seg, per_env=per_env)
+        if sampler:
+            cpu.set_spawn_sampler(*sampler)
+        np.testing.assert_allclose(obs0[sl], cpu.reset(), rtol=0, atol=OBS_ATOL)
+        for t in range(T):
+            out = cpu.step(acts[t, sl])
+            for k in ("done", "arrive", "ended"):
+                np.testing.assert_array_equal(g[k][t, sl], out[k], err_msg=f"{k}, step {t}, envs {lo}..")
+            og = g["obs"][t, sl]
+            np.testing.assert_allclose(og, out["obs"], rtol=0, atol=OBS_ATOL, err_msg=f"obs, step {t}, envs {lo}..")
+            np.testing.assert_allclose(g["rew"][t, sl], out["reward"], rtol=REW_RTOL, atol=1e-5)
+            e = out["ended"].astype(bool)
+            np.testing.assert_array_equal(g["epl"][t, sl][e], out["ep_length"][e])
+            np.testing.assert_allclose(g["epr"][t, sl][e], out["ep_return"][e], rtol=REW_RTOL, atol=1e-4)
+            np.testing.assert_allclose(g["epp"][t, sl][e], out["ep_path"][e], rtol=1e-6, atol=1e-7)
+            exact += int((og == out["obs"]).all(axis=1).sum())
+            total += n
+            n_end += int(e.sum())
+        sc = cpu.get_state()
+        np.testing.assert_allclose(sg["pose"][sl], sc["pose"], rtol=0, atol=1e-11)
+        np.testing.assert_array_equal(sg["goal"][sl], sc["goal"])
+        np.testing.assert_array_equal(sg["ep_step"][sl], sc["ep_step"])
+        np.testing.assert_array_equal(sg["rng_ctr"][sl], sc["rng_ctr"])
+    gpu.close()
+    assert exact > 0.99 * total and n_end > 0
+    return n_end
+
+
+@pytest.mark.parametrize("case", ["small", "cfg3", "cfg5_house", "cfg4_36beams"])
+def test_step_seq_against_the_oracle(case):
+    """navsim_step_seq checked DIRECTLY against the CPU oracle (not only against the per-step launches), in the instantiations the
+    BASELINE shards run: `small` 512 envs on per-env stage_2 maps with auto-reset and arrival re-spawn (16-env shape); `cfg3`
+    configs[2]'s own workload -- 16384 envs, per-env stage_2 maps with their goal rectangles: the 64-env workgroup and the
+    128-segments-per-pass cast -- with three blocks of envs (first, middle, last workgroups) replayed on the oracle; `cfg5_house` an
+    8192-env shard on the shared 2048-segment house map with the start / goal tables (tile boxes); `cfg4_36beams` a 4096-env shard
+    of configs[3] (stage_4, 36 beams)."""
+    if case == "small":
+        seg = maps.replicate_per_env(maps.stage_2(), 512, seed=2)
+        _seq_vs_oracle(512, seg, True, 48, [(0, 512)], max_episode_steps=20, auto_reset=True, respawn_on_arrive=True, seed=9)
+    elif case == "cfg3":
+        seg = maps.replicate_per_env(maps.stage_2(), 16384, seed=0)
+        _seq_vs_oracle(16384, seg, True, 40, [(0, 96), (8000, 160), (16384 - 80, 80)], rects="stage_2", max_episode_steps=25,
+                       auto_reset=True, seed=5)
+    elif case == "cfg5_house":
+        seg = maps.house(2048)
+        st, g, lo, hi = maps.spawn_tables("small_house")
+        _seq_vs_oracle(8192, seg, False, 30, [(0, 64), (4090, 100), (8192 - 40, 40)], sampler=maps.open_tables(seg, st, g) + (lo, hi),
+                       max_episode_steps=18, auto_reset=True, seed=6)
+    else:
+        _seq_vs_oracle(4096, maps.stage_4(), False, 40, [(0, 64), (2040, 80), (4096 - 32, 32)], rects="stage_4", n_beams=36,
+                       max_episode_steps=25, auto_reset=True, seed=7)
 
 
 def test_g10_reference_rollout_in_one_launch():
@@ -994,3 +1040,44 @@ def test_vecenv_step_seq_surface():
         assert torch.equal(out.obs[t], obs) and torch.equal(out.reward[t], rew) and torch.equal(out.done[t], done)
         assert torch.equal(out.arrive[t], arrive) and torch.equal(out.ended[t], b.io.ended)
     assert int(out.ended.sum()) >= N
+
+
+def test_integration_md_binding_runs_as_documented(monkeypatch):
+    """INTEGRATION.md section 3 shows the binding a reference maintainer would add next to environment_new.py (main.py:433 imports
+    `Env` from it; PPO.rollout drives reset() / step(action, past_action), ppo.py:486,541,593).  The python block is extracted from
+    the document and executed AS WRITTEN against the built libnavsim.so -- raw ctypes, no argtypes, the ABI's argument order -- and
+    60 steps (with the caller-side episode handling of ppo.py:552-593) must equal navbot_ppo_amd.env.Env bit for bit."""
+    import sys
+    import types
+    from navbot_ppo_amd import _native
+    from navbot_ppo_amd.env import Env
+    md = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    start = md.index("# project_ppo/src/navsim_env.py")
+    code = md[start:md.index("```", start)]
+    assert "navsim_step(" in code and "navsim_reset(" in code and "class Env" in code
+    stage1 = types.ModuleType("navsim_stage1")
+    stage1.STAGE1_SEGMENTS = maps.stage_1().tolist()
+    monkeypatch.setitem(sys.modules, "navsim_stage1", stage1)
+    monkeypatch.setenv("NAVSIM_LIB", _native.LIB_PATH)
+    ns = {"__name__": "navsim_env"}
+    exec(compile(code, "INTEGRATION.md#navsim_env", "exec"), ns)
+    doc, ours = ns["Env"](True), Env(True)
+    rng = np.random.default_rng(3)
+    o1, o2 = doc.reset(), ours.reset()
+    assert o1.shape == (16,) and o1.dtype == np.float64
+    np.testing.assert_array_equal(o1, o2)
+    past = np.zeros(2)
+    n_end = 0
+    for k in range(60):
+        a = np.array([0.7 + 0.3 * rng.uniform(), 0.2 * rng.uniform(-1, 1)])
+        r1, r2 = doc.step(a, past), ours.step(a, past)
+        np.testing.assert_array_equal(r1[0], r2[0])
+        assert r1[1:] == r2[1:] and isinstance(r1[1], float) and isinstance(r1[2], bool) and isinstance(r1[3], bool)
+        past = a
+        if r1[2] or r1[3] or (k % 25 == 24):   # ppo.py:552-553,591-593
+            np.testing.assert_array_equal(doc.reset(), ours.reset())
+            past = np.zeros(2)
+            n_end += 1
+    assert n_end >= 2
+    ours.close()
+    ns["_lib"].navsim_destroy(doc.h)

@@ -454,18 +454,22 @@ def test_episode_sums_match_torch_reductions(shape):
     assert abs(outs[0][5] - want[5]) <= 1e-12 * max(1.0, abs(want[5])) + 1e-9
 
 
-@pytest.mark.parametrize("N,T,cap,lo,n_s", [(4096, 512, 500, 2000, 96), (16384, 160, 150, 9000, 96)])
-def test_persistent_rollout_at_bench_size_against_the_oracle(N, T, cap, lo, n_s):
-    """navsim_rollout_mlp64 at the timed configuration (BASELINE configs[1]: T = 512, N = 4096, episode cap 500) and at the
-    16384-env shard of configs[2] (rollout_big_kernel) checked
-    DIRECTLY against the oracle, not against the per-step HIP path: the actions the kernel recorded for a block of 96 envs
+@pytest.mark.parametrize("N,T,cap,lo,n_s,world", [(4096, 512, 500, 2000, 96, "stage_1"), (16384, 160, 150, 9000, 96, "stage_1"),
+                                                    (16384, 160, 150, 16384 - 96, 96, "cfg3")])
+def test_persistent_rollout_at_bench_size_against_the_oracle(N, T, cap, lo, n_s, world):
+    """navsim_rollout_mlp64 checked DIRECTLY against the oracle, not against the per-step HIP path, at the timed configuration
+    (BASELINE configs[1]: T = 512, N = 4096, episode cap 500, shared stage_1 map: rollout_kernel), at a 16384-env shard on the
+    shared stage_1 map (rollout_big_kernel, 32-segment passes) and on configs[2]'s OWN workload (`cfg3`: 16384 envs, per-env
+    stage_2 maps with their goal rectangles: rollout_big_kernel with the 128-segments-per-pass cast, the instantiation the
+    `roofline_closed_loop` leg of bench.py times): the actions the kernel recorded for a block of 96 envs
     are replayed on an OracleSim keyed by the same global env ids (goal stream = Philox(seed, env id)); flags must be
     bit-exact, observations within 1e-6, rewards within 1e-5; the stored log-probs are those of the stored (clamped)
     actions under PyTorch's evaluation of the same actor (ppo.py:696-704)."""
     from navbot_ppo_amd import maps
     from navbot_ppo_amd.env import VecEnv
     from oracle import navsim_oracle as O
-    env = VecEnv(N, map="stage_1", max_episode_steps=cap, seed=7)
+    name = "stage_2" if world == "cfg3" else "stage_1"
+    env = VecEnv(N, map=name, max_episode_steps=cap, seed=7, per_env_map=(world == "cfg3"), map_seed=0)
     cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=cap, policy="mlp64x2", seed=3)
     tr = ppo.PPOTrainer(env, cfg)
     with torch.no_grad():   # drive: a forward bias so that collisions / arrivals happen inside 512 steps, not only timeouts
@@ -476,8 +480,12 @@ def test_persistent_rollout_at_bench_size_against_the_oracle(N, T, cap, lo, n_s)
     sl = slice(lo, lo + n_s)
     acts = tr.act_buf[:, sl].cpu().numpy()
     cpu = O.OracleSim(n_s, max_episode_steps=cap, auto_reset=True, seed=7, env_id_base=lo)
-    cpu.set_map(maps.stage_1())
-    rr, rs = maps.goal_rects("stage_1")
+    if world == "cfg3":
+        assert env.sim.per_env and env.sim.S == 128
+        cpu.set_map(env.sim._seg[sl].cpu().numpy(), per_env=True)
+    else:
+        cpu.set_map(maps.stage_1())
+    rr, rs = maps.goal_rects(name)
     cpu.set_goal_rects(0, rr)
     cpu.set_goal_rects(1, rs)
     obs = tr.obs_buf[:, sl].cpu().numpy()

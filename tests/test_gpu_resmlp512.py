@@ -108,20 +108,28 @@ def test_g7_reference_update_through_the_fused_kernels():
     np.testing.assert_allclose(up._fused_value(t("obs")).cpu().numpy(), d["V0"], rtol=1e-5, atol=2e-6)
     stats = up.update(t("obs"), t("acts"), t("logp"), t("rtgs"), torch.tensor(0.8, device=dev))
     h = up.loss_history.cpu().numpy()
-    np.testing.assert_allclose(h[:, 0], d["actor_losses"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(h[:, 1], d["critic_losses"], rtol=2e-4)
+    # Bounds = 10x what was measured (tools/g7_error.py, profiles/r04_g7_error.txt; deterministic kernels): per-epoch losses agree
+    # with the reference's to 2.4e-7 relative; the weights after 4 Adam epochs to 3.8e-7 absolute = 3.1e-4 of the largest step a
+    # weight took = 8.3e-6 of the tensor's scale (PyTorch's own GPU update of the same batch sits at 2.4e-7 / 2.0e-4 / 5.2e-6 from
+    # the reference's CPU run: summation order, amplified by Adam's g / sqrt(v) on near-zero gradients).
+    np.testing.assert_allclose(h[:, 0], d["actor_losses"], rtol=3e-6, atol=0)
+    np.testing.assert_allclose(h[:, 1], d["critic_losses"], rtol=3e-6, atol=0)
     assert stats["approx_kl"] == pytest.approx(float(d["approx_kl"]), rel=2e-2, abs=1e-5)
     assert stats["clip_frac"] == pytest.approx(float(d["clip_frac"]), abs=5e-3)
     sa, sc = a.state_dict(), c.state_dict()   # the nets' parameters are views of the flat buffer the kernels update
     n = 0
+    worst = 0.0
     for k in d.files:
         if k.startswith("fa/") or k.startswith("fc/"):
             got = (sa if k.startswith("fa/") else sc)[k[3:]].cpu().numpy()
             init = d[("ia/" if k.startswith("fa/") else "ic/") + k[3:]]
             step = np.abs(d[k] - init).max()
-            np.testing.assert_allclose(got, d[k], rtol=0, atol=max(2e-5, 0.05 * step), err_msg=k)
+            np.testing.assert_allclose(got, d[k], rtol=0, atol=4e-6, err_msg=k)
+            assert np.abs(got - d[k]).max() <= 4e-3 * step, k      # 0.4 % of the largest step (measured 0.031 %)
+            worst = max(worst, float(np.abs(got - d[k]).max() / step))
             assert step > 0
             n += 1
+    print(f"G7 through the fused resmlp512 update: worst weight error = {worst:.2e} of the largest step")
     assert n == 22
 
 
@@ -279,6 +287,17 @@ def test_trainer_with_gae_lambda():
         lg = tr.iteration()
         assert np.isfinite(lg["actor_loss"]) and np.isfinite(lg["critic_loss"])
         flats.append(tr.updater.fp.flat.clone())
+        if lam == 0.95:   # the batch end is bootstrapped with V(obs_buf[T]) for the envs still running there (lambda < 1 only)
+            tr2 = ppo.PPOTrainer(VecEnv(256, map="stage_1", max_episode_steps=40, seed=1), cfg)
+            tr2.rollout()
+            T = cfg.rollout_len
+            run = tr2.ended_buf[T - 1] == 0
+            assert int(run.sum()) > 100
+            v_last = tr2.updater.value(tr2.obs_buf[T])
+            want = tr2.rew_buf[T - 1] + cfg.gamma * v_last
+            np.testing.assert_allclose(tr2.rtg_buf[T - 1][run].cpu().numpy(), want[run].cpu().numpy(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_array_equal(tr2.rtg_buf[T - 1][~run].cpu().numpy(), tr2.rew_buf[T - 1][~run].cpu().numpy())
+            tr2.env.close()
         env.close()
     assert torch.equal(flats[0], flats[1])
     assert not torch.equal(flats[0], flats[2])
