@@ -379,6 +379,69 @@ def env_n1_step_us(budget_s=1.5):
     return round(dt / (n - n0) * 1e6, 2)
 
 
+def dist_diagnostics(ctx, trainer, roll_ms, upd_ms, epochs=20):
+    """N > 1: what a scaling run needs to be read in one shot -- every rank takes part, rank 0 reports.
+      rollout_ms / update_ms    min and max over the ranks of the timed region's split (a straggler shows as max >> min)
+      allreduce_us              the flat-gradient all-reduce alone (the ONE collective per epoch), HIP events around 200 of them
+                                back to back on the rank's stream, max over ranks: wire + RCCL launch -- the term DESIGN section 7
+                                could only assume (~25 us)
+      epoch_us_with_allreduce / epoch_us_local   one multi-GPU epoch (fused passes -> all-reduce -> scale + Adam) against the same
+                                epoch without the collective, 20 epochs each on the rank's own batch: their difference is what
+                                the collective costs IN the epoch (launch + wire + the cross-stream hand-over), max over ranks"""
+    import torch.distributed as dist
+    dev = ctx.device
+    t = torch.tensor([roll_ms, upd_ms], dtype=torch.float64, device=dev)
+    lo, hi = t.clone(), t.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    up = trainer.updater
+    g = up.fp.grad.clone()
+
+    def timed(fn, reps):
+        torch.cuda.synchronize()
+        ctx.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    for _ in range(10):
+        ctx.all_reduce_sum(g)
+    ar_us = timed(lambda: ctx.all_reduce_sum(g), 200)
+    ep_with = ep_local = None
+    if up.fused:
+        T, N, D = trainer.cfg.rollout_len, trainer.env.N, trainer.env.D
+        obs, acts = trainer.obs_buf[:T].reshape(T * N, D), trainer.act_buf.reshape(T * N, 2)
+        logp, rtg = trainer.logp_buf.reshape(T * N), trainer.rtg_buf.reshape(T * N)
+        adv = torch.randn(T * N, device=dev)
+        flat, m_, v_, t_ = up.fp.flat.clone(), up._adam_m.clone(), up._adam_v.clone(), up._adam_t
+        st = torch.zeros(8, device=dev)
+
+        def epoch(collective):
+            up._fused_loss_grad(obs, acts, logp, rtg, adv, 0.8, stats=st)
+            if collective:
+                ctx.all_reduce_sum(up.fp.grad)
+            up._fused_adam(1.0 / ctx.world)
+
+        for c in (True, False):
+            epoch(c)
+        ep_with = timed(lambda: epoch(True), epochs)
+        ep_local = timed(lambda: epoch(False), epochs)
+        up.fp.flat.copy_(flat), up._adam_m.copy_(m_), up._adam_v.copy_(v_)   # the diagnostic epochs leave no trace
+        up._adam_t = t_
+    d = torch.tensor([ar_us, ep_with or 0.0, ep_local or 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(d, op=dist.ReduceOp.MAX)
+    ar_us, ep_with_m, ep_local_m = (float(x) for x in d.tolist())
+    return dict(ranks=ctx.world, backend=ctx.backend, rollout_ms_min=round(float(lo[0]), 3), rollout_ms_max=round(float(hi[0]), 3),
+                update_ms_min=round(float(lo[1]), 3), update_ms_max=round(float(hi[1]), 3), allreduce_us=round(ar_us, 2),
+                allreduce_bytes=int(g.numel() * 4), epoch_us_with_allreduce=round(ep_with_m, 2) if up.fused else None,
+                epoch_us_local=round(ep_local_m, 2) if up.fused else None,
+                allreduce_cost_in_epoch_us=round(ep_with_m - ep_local_m, 2) if up.fused else None)
+
+
 PMC_FILE = [None]   # --with-pmc-file: counters recorded in the SAME gpurun call as this bench run (tools/prof_all.sh)
 
 
@@ -410,6 +473,13 @@ def pmc_field(key):
     """VALU-issue figures of a leg from the same pmc file (tools/pmc_traffic.py records SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU /
     SQ_BUSY_CYCLES passes for the shard legs), or None."""
     return profiled_traffic(key)
+
+
+def shard_valu(leg, key):
+    """vector-issue fraction of the shard's step launch from the counters of the pmc file (SQ_ACTIVE_INST_VALU), or None"""
+    v = pmc_field(key)
+    leg["valu"] = v
+    leg["valu_issue_frac_step"] = round(v["valu_busy_us_per_simd_at_2p4GHz"] / leg["step_us"], 4) if v else None
 
 
 def shard_leg(w, T, detail):
@@ -451,6 +521,15 @@ def main():
     ctx = ppo.DistCtx()
     if ctx.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}: launch with torch.distributed.run")
+    if ctx.world > 1 and not os.environ.get("NAVBOT_DIST_BACKEND"):
+        # a scaling run must be a run over RCCL with one rank per GPU -- anything else is a different experiment.
+        # (NAVBOT_DIST_BACKEND=gloo is the explicit override of the 1-GPU tests, where two ranks share a device.)
+        n_rccl = torch.distributed.get_world_size() if ctx.backend == "nccl" else 0
+        if n_rccl != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: RCCL connected {n_rccl} ranks (backend {ctx.backend!r}); refusing to report a "
+                             "scaling number that did not run over RCCL")
+        if torch.cuda.device_count() < ctx.world:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} devices visible: one rank per GPU")
     if args.scaling == "strong":
         if args.envs_total % ctx.world:
             raise SystemExit(f"--envs-total {args.envs_total} is not divisible by {ctx.world} GPUs")
@@ -481,6 +560,7 @@ def main():
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctx.device)
     ctx.all_reduce_max(dt)
     dt = float(dt.item())
+    diag = dist_diagnostics(ctx, trainer, roll_t / args.steps * 1e3, upd_t / args.steps * 1e3) if ctx.enabled else None
 
     out = None
     if ctx.rank == 0:
@@ -500,7 +580,7 @@ def main():
             "dist_backend": ctx.backend, "rccl_version": ctx.rccl_version,
             "rccl_ranks": (torch.distributed.get_world_size() if ctx.backend == "nccl" else 0),
             "rollout_only_env_steps_per_sec": round(K * args.rollout * n_total / roll_t, 1),
-            "rollout_ms": round(roll_t / K * 1e3, 3), "update_ms": round(upd_t / K * 1e3, 3),
+            "rollout_ms": round(roll_t / K * 1e3, 3), "update_ms": round(upd_t / K * 1e3, 3), "dist": diag,
             "last_iter": {k: lg[k] for k in ("avg_ep_rews", "success_rate", "episodes", "actor_loss", "critic_loss", "approx_kl")},
         }
     if not args.no_extras and ctx.rank == 0:   # rank 0 only (the other ranks wait at the barrier below)
@@ -555,11 +635,11 @@ def main():
         # fraction is nominal there, the vector-issue fraction from the counters says how busy the SIMDs are)
         out["cfg4_shard"] = shard_leg(CastWorkload(4096, "stage_4", per_env=False, n_beams=36), 128,
                                       "BASELINE configs[3] per GPU: 32768 / 8 envs, stage_4 (64 segments, shared), 36 beams")
-        out["cfg4_shard"]["valu"] = pmc_field("cfg4_valu")
+        shard_valu(out["cfg4_shard"], "cfg4_valu")
         out["cfg5_shard"] = shard_leg(CastWorkload(8192, "house", per_env=False, obs_f16=True, sampler="small_house", house_segments=2048), 64,
                                       "BASELINE configs[4] per GPU: 65536 / 8 envs, 2048-segment house map (shared, tile boxes), f16 "
                                       "observations, start / goal tables")
-        out["cfg5_shard"]["valu"] = pmc_field("cfg5_valu")
+        shard_valu(out["cfg5_shard"], "cfg5_valu")
         if ctx.world == 1:
             ttr = time_to_reward(n_local)
             out["time_to_reward_s"] = ttr["seconds"]

@@ -967,20 +967,23 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         };
         // stage A: cull + compaction of one tile (64 lanes = 64 segments, or 64 / epp segments of epp envs)
         auto keep_of = [&](const float4 g, const float2 o, const float2 h) __attribute__((always_inline)) -> bool {
-            // endpoints in the robot frame (X ahead, Y left); float32 throughout: this decides only what is tested exactly
+            // float32 throughout: this decides only what is tested exactly.  Endpoints relative to the sensor, WORLD frame -- the
+            // distance test does not care about the frame, and the behind test needs only the forward coordinate X = (p - o) . h.
             const float ax = g.x - o.x, ay = g.y - o.y, bx = g.z - o.x, by = g.w - o.y;
-            const float xa = fmaf(ax, h.x, ay * h.y), ya = fmaf(ay, h.x, -(ax * h.y));
-            const float xb = fmaf(bx, h.x, by * h.y), yb = fmaf(by, h.x, -(bx * h.y));
-            // behind: both endpoints inside the convex cone X < -1e-3 |Y|; the beams span +-(pi/2 + 1.2e-6)
-            const bool behind = (fmaf(1e-3f, fabsf(ya), xa) < 0.f) && (fmaf(1e-3f, fabsf(yb), xb) < 0.f);
+            const float xa = fmaf(ax, h.x, ay * h.y), xb = fmaf(bx, h.x, by * h.y);
+            // behind: both endpoints (hence the whole segment) in the half plane X < -1 mm.  The beams span +-(pi/2 + 1.2e-6): the
+            // outermost one reaches X = -1 mm at a range of 1e-3 / sin(1.2e-6) = 830 m, far beyond the 3.5 m where a return ends
+            // (round 3 tested the cone X < -1e-3 |Y| instead, which needs the lateral coordinates as well; the half plane culls
+            // a superset of it inside the sensor range and is as safe: 1e-3 m / 3.5 m = 2.9e-4 rad against 1.2e-6)
+            const bool behind = (xa < -1e-3f) && (xb < -1e-3f);
             // far: distance from the sensor to the segment above 3.5 m (threshold 12.3 = (3.5 * 1.002)^2).  The closest point
             // is a + t e with t = clamp(-a.e / e.e, 0, 1); the error of the hardware reciprocal moves it by < 1e-7 |e|, far
             // inside the 7 mm margin for any segment shorter than 10 km; a zero-length segment gives t = 0 (0 x inf = NaN
             // takes v_med3's minimum).  So the test stays conservative.
-            const float ex = xb - xa, ey = yb - ya;
-            const float e2 = fmaf(ex, ex, ey * ey), ae = fmaf(xa, ex, ya * ey);
+            const float ex = bx - ax, ey = by - ay;
+            const float e2 = fmaf(ex, ex, ey * ey), ae = fmaf(ax, ex, ay * ey);
             const float t = __builtin_amdgcn_fmed3f(-ae * __builtin_amdgcn_rcpf(e2), 0.f, 1.f);
-            const float cx = fmaf(t, ex, xa), cy = fmaf(t, ey, ya);
+            const float cx = fmaf(t, ex, ax), cy = fmaf(t, ey, ay);
             const float d2 = fmaf(cx, cx, cy * cy);
             // d2 < 1e-6: the segment passes within 1 mm of the sensor, where the angles are noise: keep
             return (d2 < 1e-6f) || !(behind || (d2 > 12.3f));

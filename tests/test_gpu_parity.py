@@ -456,7 +456,32 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert js["n_gpus"] == 2 and js["config"]["n_envs_total"] == 1024 and js["scaling"] == "weak"
     assert js["value"] > 0 and js["metric"] == "env_steps_per_sec"
     assert js["roofline"]["bound"] == "hbm" and js["roofline"]["frac"] > 0   # measured on rank 0 at every N
+    assert "step_kernel" in js["roofline"]["kernel"]                          # the like-for-like key: navsim_step, one launch per step
     assert "cpu_baseline" not in js                                            # N == 1 only
+    # what a first real multi-GPU run is read from: per-rank extremes of the split, the collective alone, and
+    # the collective's cost inside an epoch
+    d = js["dist"]
+    assert d["ranks"] == 2 and d["backend"] == "gloo" and d["allreduce_bytes"] == 4 * 10691
+    assert 0 < d["rollout_ms_min"] <= d["rollout_ms_max"] and 0 < d["update_ms_min"] <= d["update_ms_max"]
+    assert d["allreduce_us"] > 0 and d["epoch_us_with_allreduce"] > 0 and d["epoch_us_local"] > 0
+    assert d["allreduce_cost_in_epoch_us"] == pytest.approx(d["epoch_us_with_allreduce"] - d["epoch_us_local"], abs=0.02)
+
+
+def test_bench_refuses_a_multi_rank_run_that_is_not_over_rccl():
+    """bench.py --gpus 2 on a box with ONE GPU and no backend override: two ranks cannot both own a device over RCCL, and the run
+    must fail loudly instead of printing a scaling number (round-3 review, item 6)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    env = {k: v for k, v in os.environ.items() if k != "NAVBOT_DIST_BACKEND"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--envs-per-gpu", "256", "--rollout", "16", "--epochs", "1", "--no-extras"]
+    out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_degenerate_small_segments_take_the_ieee_divide_path():

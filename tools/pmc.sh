@@ -1,12 +1,12 @@
 #!/bin/bash
 # usage (on the GPU box): tools/pmc.sh <name> "<counters>" -- <command...>
-# one rocprofv3 --pmc pass (kernel-trace only), aggregated per kernel into gpurun_out/${ROUND:-r03}/<name>_pmc.txt
+# one rocprofv3 --pmc pass (kernel-trace only), aggregated per kernel into gpurun_out/${ROUND:-r04}/<name>_pmc.txt
 name="$1"; ctrs="$2"; shift; shift; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/pmc_$name
 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- "$@" > /tmp/pmc_$name.log 2>&1
-mkdir -p gpurun_out/${ROUND:-r03}
-python3 - "$name" "${ROUND:-r03}" <<'PY'
+mkdir -p gpurun_out/${ROUND:-r04}
+python3 - "$name" "${ROUND:-r04}" <<'PY'
 import csv, sys, collections, glob
 name, rnd = sys.argv[1], sys.argv[2]
 f = glob.glob(f"/tmp/pmc_{name}/**/p_counter_collection.csv", recursive=True)

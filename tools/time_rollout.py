@@ -17,6 +17,8 @@ if "--cfg3" in sys.argv:   # the closed-loop form of BASELINE configs[2] (what b
     os.environ.update(TR_SIZES="16384", TR_MAP="stage_2", TR_PER_ENV="1", TR_T="256")
 if "--s1024" in sys.argv:   # the same shard past the Infinity Cache (bench.py's roofline_closed_loop_beyond_l3)
     os.environ.update(TR_SIZES="16384", TR_PER_ENV="1", TR_T="64", TR_SIDES="248")
+if "--s2048" in sys.argv:   # 2x the Infinity Cache (bench.py's roofline_hbm_closed_loop)
+    os.environ.update(TR_SIZES="16384", TR_PER_ENV="1", TR_T="32", TR_SIDES="504")
 _pol = [a for a in sys.argv[1:] if not a.endswith(".so") and not a.startswith("--")]
 policy = _pol[0] if _pol else "mlp64x2"
 from navbot_ppo_amd import maps
@@ -24,7 +26,7 @@ MAP, PER_ENV, T = os.environ.get("TR_MAP", "stage_1"), os.environ.get("TR_PER_EN
 SIDES = int(os.environ.get("TR_SIDES", "0"))
 for N in [int(x) for x in os.environ.get("TR_SIZES", "4096,2048,1024,512").split(",")]:
     if SIDES:   # stage_2 with SIDES-gon pillars (248: 1024 segments), stage_2's goal rectangles
-        env = VecEnv(N, map=maps.stage_2(sides=SIDES), max_episode_steps=500, seed=0, per_env_map=PER_ENV)
+        env = VecEnv(N, map=maps.stage_2(sides=SIDES), max_episode_steps=500, seed=0, per_env_map=PER_ENV)   # (segments: 32 + 4 SIDES)
         rr, rs = maps.goal_rects("stage_2")
         env.sim.set_goal_rects(0, rr)
         env.sim.set_goal_rects(1, rs)
@@ -36,7 +38,7 @@ for N in [int(x) for x in os.environ.get("TR_SIZES", "4096,2048,1024,512").split
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    reps = 5
+    reps = int(os.environ.get("TR_REPS", "16"))   # (the rocprofv3 average of a run includes its 2 warm-up launches: keep them a small share)
     for _ in range(reps):
         tr.rollout()
     e1.record(); torch.cuda.synchronize()
