@@ -338,7 +338,8 @@ struct StepSmem {
     float4 q4[NW][128];
     unsigned qe[NW][128];
     float4 r4[NW][128];          // ... and of those whose angular extent holds at least one beam
-    unsigned re[NW][128];
+    unsigned re[NW][128];        //     env | first beam of that extent << 8 | number of beams << 16
+    unsigned pe[NW][(NB > 16) ? 128 : 1];   // 36 beams: stage-B work entries: r4 slot | first beam << 8 | beams to test << 16
     float4 tbox[64];             // Params::tile_box, staged once per launch (BOXES)
     Rects rects;                 // Params::rects, staged by the ray waves before barrier A (the spec lanes' goal rejection test)
     float2 act_l[EPB];           // persistent rollout: the action the policy phase chose for this step
@@ -890,15 +891,21 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         unsigned* const qe = sm.qe[wave];
         float4* const r4 = sm.r4[wave];
         unsigned* const re = sm.re[wave];
-        int qhead = 0, qtail = 0, rhead = 0, rtail = 0;   // wave-uniform
-        // stage B: exact tests of up to 64 queued segments against every beam of their env
-        auto flushB = [&](int n) __attribute__((always_inline)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const bool on = lane < n;
-            const int slot = (rhead + lane) & 127;
-            const float4 g = on ? r4[slot] : make_float4(0.f, 0.f, 1.f, 0.f);
-            const unsigned el = on ? re[slot] : 0u;
+        unsigned* const pe = sm.pe[wave];
+        int qhead = 0, qtail = 0, rhead = 0, rtail = 0, phead = 0, ptail = 0;   // wave-uniform
+        // Stage B, the exact tests.  With 10 beams every queued segment is tested against ALL beams (lane = segment: 206 vector
+        // instructions per 64 segments).  With 36 beams that is 770 instructions in one wave, although stage A2 has just bounded
+        // the beams the segment's arc can hold -- so there (kPairB) a queued segment is expanded into entries of kBeamsPerEntry
+        // consecutive beams of that extent and a pass tests 64 ENTRIES (lane = entry): the same arithmetic on the same (a, b, o, d),
+        // on the beams that can be hit only, so the scan keeps its bits (the extent is as conservative as the A2 cull itself).
+        // Measured (tools/time_step.py, same box): BASELINE configs[3]'s shard (4096 envs, stage_4, 36 beams) 15.8 -> 12.5 us per
+        // launch, tape form 12.7 -> 9.8 us per step.  At 10 beams the expansion costs more than it saves -- a wave of a configs[2]
+        // workgroup queues only ~40 segments per step, one partial pass either way: 12.96 -> 13.19 us -- so it stays off there.
+        constexpr bool kPairB = NB > 16;
+        constexpr int kBeamsPerEntry = (NB > 16) ? 4 : 2;
+        auto exact_tests = [&](const bool on, const float4 g, const unsigned el, const int b_first, const int n_b, auto n_max)
+                               __attribute__((always_inline)) {
+            constexpr int kMaxB = decltype(n_max)::value;
             const float2 o = sm.org[el];
             const float rx = g.x - o.x, ry = g.y - o.y;
             const float ex = g.z - g.x, ey = g.w - g.y;
@@ -909,24 +916,74 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
             if (__builtin_expect(__any(tiny), 0)) {
                 // the empty volatile asm keeps this a real (wave-uniform) branch the compiler cannot speculate
                 asm volatile("; degenerate-segment pass" ::: "memory");
-                for (int b = 0; b < NB; ++b) {
+                for (int u = 0; u < kMaxB; ++u) {
+                    const int b = min(b_first + u, NB - 1);
                     const float2 d = sm.dir[b * EPB + el];
                     const unsigned bits = __float_as_uint(ray_seg(rx, ry, ex, ey, k, d.x, d.y)) & 0x7fffffffu;
-                    if (on && bits < kInfBits) atomicMin(&sm.rng[b * EPB + el], bits);
+                    if (on && u < n_b && bits < kInfBits) atomicMin(&sm.rng[b * EPB + el], bits);
                 }
             } else {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
+                for (int u = 0; u < kMaxB; ++u) {
+                    const int b = (kMaxB == NB) ? u : min(b_first + u, NB - 1);
                     const float2 d = sm.dir[b * EPB + el];
                     const unsigned bits = ray_seg_bits(rx, ry, ex, ey, k, d.x, d.y);
                     // hits only: same-address LDS atomics of a wave serialise, and most lanes miss
-                    if (on && bits < kInfBits) atomicMin(&sm.rng[b * EPB + el], bits);
+                    if (on && u < n_b && bits < kInfBits) atomicMin(&sm.rng[b * EPB + el], bits);
                 }
             }
+        };
+        // up to 64 queued segments against every beam of their env (lane = segment): the tail of a small map, whose whole cast
+        // is one pass -- there the two extra queue hops of expand / testB would only add latency
+        auto flushB = [&](int n) __attribute__((always_inline)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool on = lane < n;
+            const int slot = (rhead + lane) & 127;
+            const float4 g = on ? r4[slot] : make_float4(0.f, 0.f, 1.f, 0.f);
+            const unsigned el = on ? (re[slot] & 255u) : 0u;
+            exact_tests(on, g, el, 0, NB, std::integral_constant<int, NB>{});
             rhead += n;
         };
+        // up to 64 entries (lane = entry): kBeamsPerEntry consecutive beams of one queued segment
+        auto testB = [&](int n) __attribute__((always_inline)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool on = lane < n;
+            const unsigned e = on ? pe[(phead + lane) & 127] : 0u;
+            const int slot = (int)(e & 127u);
+            const float4 g = on ? r4[slot] : make_float4(0.f, 0.f, 1.f, 0.f);
+            const unsigned el = on ? (re[slot] & 255u) : 0u;
+            exact_tests(on, g, el, (int)((e >> 8) & 255u), (int)(e >> 16), std::integral_constant<int, kBeamsPerEntry>{});
+            phead += n;
+        };
+        // the oldest n queued segments -> entries.  Lane = segment writes its j-th entry in round j (ballot compaction per round:
+        // no prefix sum; a pillar facet is done after round 0, a wall across the whole fan after NB / kBeamsPerEntry rounds).
+        auto expand = [&](int n) __attribute__((always_inline)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int slot = (rhead + lane) & 127;
+            const unsigned w = (lane < n) ? re[slot] : 0u;
+            const int b0 = (int)((w >> 8) & 255u), c = (int)(w >> 16);
+            const int ne = (c + kBeamsPerEntry - 1) / kBeamsPerEntry;   // 0 on the lanes beyond n
+            rhead += n;
+            for (int j = 0;; ++j) {   // wave-uniform
+                const bool mine = ne > j;
+                const unsigned long long bal = __ballot(mine);
+                if (!bal) break;
+                const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (mine)
+                    pe[(ptail + off) & 127] = (unsigned)slot | ((unsigned)(b0 + kBeamsPerEntry * j) << 8) |
+                                              ((unsigned)min(kBeamsPerEntry, c - kBeamsPerEntry * j) << 16);
+                ptail += __popcll(bal);
+                if (ptail - phead >= 64) testB(64);
+            }
+            // ... and the rest: an entry names its segment by the r4 slot, and the next A2 pass may rewrite the slots of the
+            // segments just expanded (the ring only protects the ones still queued), so no entry outlives its expansion
+            if (ptail > phead) testB(ptail - phead);
+        };
         // stage A2, dense over up to 64 survivors of the range / behind cull: does the arc the segment subtends, as seen
-        // from the sensor, hold a beam at all?  (Beams are 20 degrees apart, a pillar facet at 2 m subtends 2.)
+        // from the sensor, hold a beam at all -- and which?  (Beams are 20 degrees apart, a pillar facet at 2 m subtends 2.)
         constexpr float kInvDelta = (float)((NB - 1) / (2.0 * kAngleMax)), kBeamMargin = 0.02f;
         auto flushA2 = [&](int n) __attribute__((always_inline)) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -951,7 +1008,13 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
             const float ce = ceilf(lo - kBeamMargin), fl = floorf(hi + kBeamMargin);
             const bool inside = (fl >= ce) && (fl >= 0.f) && (ce <= (float)(NB - 1));
             const bool outside = (lo + kBeamMargin >= 0.f) || (hi - kBeamMargin <= (float)(NB - 1));
-            const bool keep = on && (bad_a || bad_b || through || (wrap ? outside : inside));
+            // an arc whose beam extent cannot be trusted (an endpoint next to the sensor or straight behind it, a line through the
+            // sensor, an arc through straight-behind) keeps the segment for every beam
+            const bool all = bad_a || bad_b || through || wrap;
+            const bool keep = on && (all ? (bad_a || bad_b || through || outside) : inside);
+            // beams ce .. fl of the fan (v_med3 clamps; a NaN coordinate has set `bad`)
+            const float b_lo = __builtin_amdgcn_fmed3f(ce, 0.f, (float)(NB - 1)), b_hi = __builtin_amdgcn_fmed3f(fl, 0.f, (float)(NB - 1));
+            const unsigned ext = all ? ((unsigned)NB << 16) : (((unsigned)(int)b_lo << 8) | ((unsigned)((int)(b_hi - b_lo) + 1) << 16));
             qhead += n;
             const unsigned long long bal = __ballot(keep);
             if (bal) {
@@ -959,10 +1022,13 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
                 if (keep) {
                     const int s2 = (rtail + off) & 127;
                     r4[s2] = g;
-                    re[s2] = el;
+                    re[s2] = el | ext;
                 }
                 rtail += __popcll(bal);
-                if (rtail - rhead >= 64) flushB(64);
+                if (rtail - rhead >= 64) {
+                    if constexpr (kPairB) expand(64);
+                    else flushB(64);
+                }
             }
         };
         // stage A: cull + compaction of one tile (64 lanes = 64 segments, or 64 / epp segments of epp envs)
@@ -1077,9 +1143,10 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
             p2 = advance(p1);
             request(p2, g2, v2, g2b, v2b);
         }
-        // The tail.  Stage A2 only filters, so when everything that is left fits one stage-B pass it is skipped: the stage-A
-        // survivors join the stage-B queue directly (one pass of 206 VALU instead of 75 + 206; a small map never needs A2).
-        if (qtail - qhead + rtail - rhead <= 64) {
+        // The tail.  10 beams: stage A2 only filters, so when everything that is left fits one stage-B pass it is skipped: the
+        // stage-A survivors join the stage-B queue directly (one pass of 206 VALU instead of 75 + 206; a small map never needs A2).
+        // 36 beams: a pass over all beams is the expensive thing, A2 and the expansion always run.
+        if (!kPairB && qtail - qhead + rtail - rhead <= 64) {
             const int n = qtail - qhead;
             if (lane < n) {
                 const int s1 = (qhead + lane) & 127, s2 = (rtail + lane) & 127;
@@ -1090,7 +1157,10 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
             qhead += n;
         }
         if (qtail > qhead) flushA2(qtail - qhead);
-        if (rtail > rhead) flushB(rtail - rhead);
+        if (rtail > rhead) {
+            if constexpr (kPairB) expand(rtail - rhead);
+            else flushB(rtail - rhead);
+        }
     }
     __syncthreads();  // barrier B: nearest hits complete
 
