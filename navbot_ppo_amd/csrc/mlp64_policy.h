@@ -134,20 +134,25 @@ __device__ __forceinline__ void policy_noise(const uint32_t step, const uint64_t
     e1 = rad * sinf(6.283185307179586f * u2);
 }
 
-// pz3 / pz4: the four tile partials in tile order
-__device__ __forceinline__ PolicyOut policy_finish(const float* __restrict__ params, const float (&pz3)[4], const float (&pz4)[4],
-                                                   const float var, const float e0, const float e1) {
+// pz3 / pz4: the four tile partials in tile order.  sd = sqrtf(var), log_var = logf(var): functions of the launch's variance alone,
+// which a caller that takes many steps with one variance evaluates once (policy_finish below evaluates them per call: same bits).
+__device__ __forceinline__ PolicyOut policy_finish_pre(const float* __restrict__ params, const float (&pz3)[4], const float (&pz4)[4],
+                                                       const float var, const float sd, const float log_var, const float e0,
+                                                       const float e1) {
     const float z3 = (((pz3[0] + pz3[1]) + pz3[2]) + pz3[3]) + params[OFF_B3];
     const float z4 = (((pz4[0] + pz4[1]) + pz4[2]) + pz4[3]) + params[OFF_B4];
     PolicyOut o;
     o.mu0 = 1.0f / (1.0f + expf(-z3));
     o.mu1 = tanhf(z4);
-    const float sd = sqrtf(var);
     o.a0 = fminf(fmaxf(fmaf(sd, e0, o.mu0), 0.f), 1.f);    // ppo.py:698-703
     o.a1 = fminf(fmaxf(fmaf(sd, e1, o.mu1), -1.f), 1.f);
     const float d0 = o.a0 - o.mu0, d1 = o.a1 - o.mu1;
-    o.logp = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);  // ppo.py:704
+    o.logp = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - log_var;  // ppo.py:704
     return o;
+}
+__device__ __forceinline__ PolicyOut policy_finish(const float* __restrict__ params, const float (&pz3)[4], const float (&pz4)[4],
+                                                   const float var, const float e0, const float e1) {
+    return policy_finish_pre(params, pz3, pz4, var, sqrtf(var), logf(var), e0, e1);
 }
 
 // One wave = 16 envs, no LDS and no barrier.  All 64 lanes must call (MFMA); `noise_row`, `gid` are per env (used on lanes

@@ -464,10 +464,16 @@ struct StepIO {
     int32_t* ep_length;
     float* ep_path_out;
 };
+// Hook: called by EVERY wave right behind barrier B2 (the observation rows are complete but for a reset, which the rules lanes of
+// wave 0 work out next): the persistent rollout kernels run the policy of the NEXT step there, on waves that would otherwise
+// wait for the rules, reading the rows through next_obs4 below.  NoHook: nothing (step_kernel, steps_kernel).
+struct NoHook {
+    __device__ __forceinline__ void operator()(int, int) const {}
+};
 template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4, bool BOXES = false, bool PAIR = false, class PRef = const Params&,
-          class IORef = const StepIO&>
+          class IORef = const StepIO&, class Hook = NoHook>
 __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int& next_env, IORef io, const bool last_step = true,
-                                          const size_t row0 = 0) {
+                                          const size_t row0 = 0, Hook hook = Hook()) {
     static_assert(EPB <= 64 && EPB >= 4 && NB % 2 == 0, "EPB / NB");
     static_assert(!(PAIR && BOXES), "tile boxes describe 64-segment tiles");
     constexpr int kThreads = 64 * NW;
@@ -902,6 +908,9 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         // launch, tape form 12.7 -> 9.8 us per step.  At 10 beams the expansion costs more than it saves -- a wave of a configs[2]
         // workgroup queues only ~40 segments per step, one partial pass either way: 12.96 -> 13.19 us -- so it stays off there.
         constexpr bool kPairB = NB > 16;
+        // (Rejected, profiles/r04_stage_b_pool_ablation.txt: pooling what the 16 waves' stage-B queues hold at the end of a step --
+        // a wave queues ~40 segments per step, so its one pass runs with 60 % of its lanes -- removes 6.5 of 16 passes per
+        // workgroup and step and is 14-17 % SLOWER: the passes land on the tail of the slowest wave, behind dependent LDS atomics.)
         constexpr int kBeamsPerEntry = (NB > 16) ? 4 : 2;
         auto exact_tests = [&](const bool on, const float4 g, const unsigned el, const int b_first, const int n_b, auto n_max)
                                __attribute__((always_inline)) {
@@ -1181,6 +1190,7 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         }
     }
     __syncthreads();  // barrier B2: lidar entries and their minima complete
+    hook(wave, lane);
 
     // ---------------- part 3 (wave 0, lane = env): rules of getState / step / setReward + episode logic
     if (own) {
@@ -1278,6 +1288,52 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     }
 }
 
+// Entries 4 kk .. 4 kk + 3 of the observation env `e` (local) will hold when this step is over, readable from barrier B2 on --
+// i.e. BEFORE the rules lane of part 3 has run: the row in sm.obs as it stands, unless the step ends the episode and auto_reset
+// replaces it by the reset observation (ppo.py:582-593).  Whether it does follows from three values that are final at barrier B2
+// -- the minimum of the scan (collision, environment_new.py:200), the goal distance (arrival, :204), the step count (time-out,
+// ppo.py:552) -- and the reset observation is the record the spec lanes staged in part 2.  The same expressions as part 3 on the
+// same operands, so the policy that reads its input through here sees exactly the row part 3 leaves in sm.obs.
+template <int NB, int EPB, int NW, bool SENS, class PRef>
+__device__ __forceinline__ float4 next_obs4(PRef P, const StepSmem<NB, EPB, NW>& sm, const int e, const int kk, const float sigma,
+                                            const int below_min) {
+    constexpr int DP = NB + 7;
+    static_assert(NB % 2 == 0 && (NB + 6) % 4 == 0, "rows of 4-entry groups");
+    const float* row = sm.obs + e * DP + 4 * kk;
+    float4 x = make_float4(row[0], row[1], row[2], row[3]);
+    const float mn = (SENS && sm.neg[e]) ? -INFINITY : __uint_as_float(sm.mn_bits[e]);
+    const bool d = (0.2 > (double)mn) && ((double)mn > 0);                                        // environment_new.py:200
+    const bool a = sm.sv_d[6][e] <= P.thr;                                                       // :204
+    const uint32_t step = (sm.sv_step[e] & kStepMask) + 1;
+    const bool timeout = (P.max_ep_steps > 0) && ((int)step >= P.max_ep_steps);                  // ppo.py:552
+    if ((d || a || timeout) && P.auto_reset) {
+        const int c = (a && P.respawn) ? 1 : 0;
+        const float4 tl = sm.sp_tail[c][e];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = 4 * kk + j;
+            float val;
+            if (idx < NB) {
+                val = sm.sp_scan[c][e][idx];
+                if (SENS) {   // write_lidar's entry: the start pose's nearest hit through this step's range noise
+                    float r = sensor_value(val, sigma, (sigma > 0.f) ? sm.noise[idx * EPB + e] : 0.f, below_min);
+                    if (r == INFINITY) r = 3.5f;
+                    val = r / 3.5f;
+                }
+            } else if (idx < NB + 2) {
+                val = 0.f;                                                                       // environment_new.py:372-373
+            } else {
+                const int q = idx - NB - 2;
+                val = q == 0 ? tl.x : q == 1 ? tl.y : q == 2 ? tl.z : tl.w;
+            }
+            v[j] = val;
+        }
+        x = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return x;
+}
+
 // The kernarg segment of step_kernel: the kernel takes this struct as its ONLY by-value parameter, so the segment IS the struct
 // (members at their natural alignment, in order) and the reads through the segment pointer below cannot drift from the signature.
 struct StepKArgs {
@@ -1331,7 +1387,8 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
     __shared__ __attribute__((aligned(16))) float wts[mlp64::P_ACTOR + 2];   // the actor, staged once for all T steps
     __shared__ float2 pol_z[4][16];   // policy phase: per-tile partial sums of the two output units
     __shared__ float2 pol_eps[16];    // ... and the step's action noise
-    static_assert(NW >= 5 && EPB <= 16, "policy phase: waves 0-3 MFMA, wave 4 noise; one 16-env policy tile per workgroup");
+    __shared__ unsigned pol_cnt;      // arrivals of the in-step policy's five waves (the last one finishes)
+    static_assert(NW >= 6 && EPB <= 16, "policy phase: four tile waves + the noise wave beside wave 0's rules; one 16-env policy tile per workgroup");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int base = blockIdx.x * EPB;
     const int nloc = min(EPB, P.N - base);
@@ -1351,44 +1408,87 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
         reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
     const uint32_t step0 = R.step_base ? *R.step_base : 0u;
     const float var = *R.var_ptr;
+    if (tid == 0) pol_cnt = 0u;
+    __syncthreads();
+    // The policy (mlp64_policy.h) as the kernel runs it: four "tile waves" each compute layer 1 and one 16-row tile of layer 2 with
+    // its share of the two output units (tile_part), one wave draws the step's action noise meanwhile, and -- behind a barrier --
+    // wave 0 finishes (sigmoid / tanh, clamp, log-prob) and publishes the action (finish).
+    const float sigma = SENS ? P.sigma : 0.f;
+    const int below_min = SENS ? P.below_min_mode : 0;
+    auto tile_part = [&](const int t2, auto in_step) __attribute__((always_inline)) {
+        const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]
+        const bool valid = e < nloc;
+        float4 xq;
+        if constexpr (decltype(in_step)::value) {   // inside a step, behind barrier B2: the rows the step will leave
+            xq = next_obs4<NB, EPB, NW, SENS, const Params&>(P, sm, min(e, nloc - 1), kk, sigma, below_min);
+        } else {
+            const float* row = sm.obs + min(e, nloc - 1) * DP + 4 * kk;
+            xq = make_float4(row[0], row[1], row[2], row[3]);
+        }
+        if (!valid) xq = make_float4(0.f, 0.f, 0.f, 0.f);
+        mlp64::f32x4 c1[4];
+        mlp64::policy_hidden1(wts, xq, lane, c1);
+        float pz3, pz4;
+        mlp64::policy_tile2(wts, c1, lane, t2, pz3, pz4);
+        if (kk == 0) pol_z[t2][e] = make_float2(pz3, pz4);
+    };
+    auto draw_noise = [&](const uint32_t step) __attribute__((always_inline)) {
+        float e0, e1;
+        mlp64::policy_noise(step, R.seed, P.env_id_base + (uint64_t)(base + lane), e0, e1);
+        pol_eps[lane] = make_float2(e0, e1);
+    };
+    const float sd = sqrtf(var), log_var = logf(var);   // policy_finish's sqrtf(var) / logf(var), once per launch: same bits
+    auto finish = [&](const size_t tn) __attribute__((always_inline)) {   // any wave, lane = env: row tn / N of act_buf / logp_buf
+        const int e = lane;
+        const float pz3[4] = {pol_z[0][e].x, pol_z[1][e].x, pol_z[2][e].x, pol_z[3][e].x};
+        const float pz4[4] = {pol_z[0][e].y, pol_z[1][e].y, pol_z[2][e].y, pol_z[3][e].y};
+        const float2 eps = pol_eps[e];
+        const mlp64::PolicyOut o = mlp64::policy_finish_pre(wts, pz3, pz4, var, sd, log_var, eps.x, eps.y);
+        sm.act_l[e] = make_float2(o.a0, o.a1);
+        reinterpret_cast<float2*>(R.act_buf)[tn + base + e] = make_float2(o.a0, o.a1);
+        R.logp_buf[tn + base + e] = o.logp;
+    };
+    // the action of step 0, from the reset observations
+    if (wave < 4) tile_part(wave, std::false_type{});
+    else if (wave == 4 && lane < nloc) draw_noise(step0);
+    __syncthreads();
+    if (wave == 0 && lane < nloc) finish(0);
     __syncthreads();
     for (int t = 0; t < R.T; ++t) {
         const size_t tn = (size_t)t * N;
         asm volatile("" ::: "memory");   // keeps the weight reads of the policy phase inside the loop (registers are scarce)
-        // ---------------- policy phase (mlp64_policy.h): waves 0-3 each compute layer 1 and one 16-row tile of layer 2 with
-        // its share of the two output units; wave 4 draws the step's action noise meanwhile; wave 0 then finishes.
-        if (wave < 4) {
-            const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]
-            const bool valid = e < nloc;
-            const float* row = sm.obs + min(e, nloc - 1) * DP + 4 * kk;
-            const float4 xq = valid ? make_float4(row[0], row[1], row[2], row[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            mlp64::f32x4 c1[4];
-            mlp64::policy_hidden1(wts, xq, lane, c1);
-            float pz3, pz4;
-            mlp64::policy_tile2(wts, c1, lane, wave, pz3, pz4);
-            if (kk == 0) pol_z[wave][e] = make_float2(pz3, pz4);
-        } else if (wave == 4 && lane < nloc) {
-            float e0, e1;
-            mlp64::policy_noise(step0 + (uint32_t)t, R.seed, P.env_id_base + (uint64_t)(base + lane), e0, e1);
-            pol_eps[lane] = make_float2(e0, e1);
-        }
-        __syncthreads();
-        if (wave == 0 && lane < nloc) {
-            const int e = lane;
-            const float pz3[4] = {pol_z[0][e].x, pol_z[1][e].x, pol_z[2][e].x, pol_z[3][e].x};
-            const float pz4[4] = {pol_z[0][e].y, pol_z[1][e].y, pol_z[2][e].y, pol_z[3][e].y};
-            const float2 eps = pol_eps[e];
-            const mlp64::PolicyOut o = mlp64::policy_finish(wts, pz3, pz4, var, eps.x, eps.y);
-            sm.act_l[e] = make_float2(o.a0, o.a1);
-            reinterpret_cast<float2*>(R.act_buf)[tn + base + e] = make_float2(o.a0, o.a1);
-            R.logp_buf[tn + base + e] = o.logp;
-        }
-        __syncthreads();
         const StepIO io = {nullptr, nullptr, R.obs_buf + (tn + N) * D, R.reward + tn, R.done + tn, R.arrive + tn, R.ended + tn,
                            R.ep_return ? R.ep_return + tn : nullptr, R.ep_length ? R.ep_length + tn : nullptr,
                            R.ep_path ? R.ep_path + tn : nullptr};
-        step_body<NB, EPB, SENS, true, NW>(P, sm, next_env, io, t == R.T - 1);
-        // the observation tile of step t + 1 is in sm.obs; its store only reads it, like the next policy phase
+        // The policy of step t + 1 runs INSIDE step t, behind barrier B2.  Wave 0 works through the rules there (a float64 latency
+        // chain, 0.85 us) and every other wave would only wait for it at barrier C; instead waves 1-4 run the tile parts, wave 5
+        // draws the noise, and whichever of the five arrives last (an LDS counter: a wave's LDS operations are performed in order,
+        // so the one that reads 4 sees what the other four wrote) finishes and publishes the action -- all before barrier C,
+        // so the next step starts right behind this one.  What the rules still have to decide about the observation tile --
+        // whether an env's row is replaced by its reset observation -- the tile waves work out themselves from the values that
+        // are final at B2 (next_obs4), so they read exactly the rows the step leaves: same device functions on the same inputs,
+        // the buffers keep their bits.  Round 3 ran the phase between the steps with the whole workgroup waiting (5.2 us per
+        // step); stamps of this form in profiles/r04_rollout16_phase_stamps.txt.
+        const bool more = t + 1 < R.T;
+        auto hook = [&](const int wv, const int ln) __attribute__((always_inline)) {
+            // (measured: the parts on waves 1, 2, 3, 5 -- keeping them off wave 0's SIMD if waves land round robin -- 5.34 instead
+            // of 5.01 us per step)
+            if (more && wv >= 1 && wv <= 5) {
+                if (wv <= 4) tile_part(wv - 1, std::true_type{});
+                else if (ln < nloc) draw_noise(step0 + (uint32_t)(t + 1));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                unsigned old = 0u;
+                if (ln == 0) old = atomicAdd(&pol_cnt, 1u);
+                if (__builtin_amdgcn_readfirstlane(old) == 4u) {   // the last of the five
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (ln == 0) pol_cnt = 0u;
+                    if (ln < nloc) finish(tn + N);
+                }
+            }
+        };
+        step_body<NB, EPB, SENS, true, NW, false, false, const Params&, const StepIO&, decltype(hook)>(P, sm, next_env, io,
+                                                                                                     t == R.T - 1, 0, hook);
+        // the observation tile of step t + 1 is in sm.obs (its store only reads it), its action in sm.act_l
     }
 }
 
@@ -1514,42 +1614,71 @@ __global__ __launch_bounds__(64 * NW) void rollout_big_kernel(BigKArgs) {   // t
     const uint32_t step0 = R.step_base ? *R.step_base : 0u;
     const float var = *R.var_ptr;
     const uint64_t seed = R.seed, gid = P.env_id_base + (uint64_t)(base + lane);
-    if (wave == TW && lane < nloc) {
+    // policy tile k (envs 16 k .. 16 k + 15) belongs to wave TW + k -- the waves of a workgroup land on the SIMDs round robin, one
+    // tile per SIMD -- and the noise of a row to wave 2 TW; wave 0 stays free for the rules (see the hook below)
+    constexpr int kTileWave0 = TW, kNoiseWave = 2 * TW;
+    static_assert(kNoiseWave < NW, "tile waves and the noise wave beside wave 0");
+    // get_action (ppo.py:673-706) of policy tile `k` on the observation tile in LDS -> action / log-prob of row tn / N
+    const float sigma = SENS ? P.sigma : 0.f;
+    const int below_min = SENS ? P.below_min_mode : 0;
+    const float sd = sqrtf(var), log_var = logf(var);   // policy_finish's sqrtf(var) / logf(var), once per launch: same bits
+    auto tile_policy = [&](const int k, const size_t tn, const int eps_row, auto in_step) __attribute__((always_inline)) {
+        const int e = 16 * k + (lane & 15), kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]
+        const bool valid = e < nloc;
+        float4 xq;
+        if constexpr (decltype(in_step)::value) {   // inside a step, behind barrier B2: the rows the step will leave
+            xq = next_obs4<NB, EPB, NW, SENS, const Params __attribute__((address_space(4)))&>(P, sm, min(e, nloc - 1), kk, sigma, below_min);
+        } else {
+            const float* row = sm.obs + min(e, nloc - 1) * DP + 4 * kk;
+            xq = make_float4(row[0], row[1], row[2], row[3]);
+        }
+        if (!valid) xq = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float2 eps = pol_eps[eps_row][min(e, nloc - 1)];   // requested ahead of the MFMA chain, used behind it
+        mlp64::f32x4 c1[4];
+        mlp64::policy_hidden1(wts, xq, lane, c1);
+        float pz3[4], pz4[4];
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) mlp64::policy_tile2(wts, c1, lane, t2, pz3[t2], pz4[t2]);
+        if (kk == 0 && valid) {
+            const mlp64::PolicyOut o = mlp64::policy_finish_pre(wts, pz3, pz4, var, sd, log_var, eps.x, eps.y);
+            sm.act_l[e] = make_float2(o.a0, o.a1);
+            reinterpret_cast<float2*>(R.act_buf)[tn + base + e] = make_float2(o.a0, o.a1);
+            R.logp_buf[tn + base + e] = o.logp;
+        }
+    };
+    auto draw_noise = [&](const int t) __attribute__((always_inline)) {   // the noise of rollout row t: rows take turns in two LDS rows
         float e0, e1;
-        mlp64::policy_noise(step0, seed, gid, e0, e1);
-        pol_eps[0][lane] = make_float2(e0, e1);
+        mlp64::policy_noise(step0 + (uint32_t)t, seed, gid, e0, e1);
+        pol_eps[t & 1][lane] = make_float2(e0, e1);
+    };
+    if (wave == kNoiseWave && lane < nloc) {
+        draw_noise(0);
+        if (T > 1) draw_noise(1);
     }
+    __syncthreads();
+    // the action of step 0, from the reset observations
+    if (wave >= kTileWave0 && wave < kTileWave0 + TW) tile_policy(wave - kTileWave0, 0, 0, std::false_type{});
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const size_t N = (size_t)P.N;
         const size_t tn = (size_t)t * N;
         asm volatile("" ::: "memory");   // keeps the weight reads of the policy phase inside the loop
-        if (wave < TW) {
-            const int e = 16 * wave + (lane & 15), kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]
-            const bool valid = e < nloc;
-            const float* row = sm.obs + min(e, nloc - 1) * DP + 4 * kk;
-            const float4 xq = valid ? make_float4(row[0], row[1], row[2], row[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float2 eps = pol_eps[t & 1][min(e, nloc - 1)];   // requested ahead of the MFMA chain, used behind it
-            mlp64::f32x4 c1[4];
-            mlp64::policy_hidden1(wts, xq, lane, c1);
-            float pz3[4], pz4[4];
-#pragma unroll
-            for (int t2 = 0; t2 < 4; ++t2) mlp64::policy_tile2(wts, c1, lane, t2, pz3[t2], pz4[t2]);
-            if (kk == 0 && valid) {
-                const mlp64::PolicyOut o = mlp64::policy_finish(wts, pz3, pz4, var, eps.x, eps.y);
-                sm.act_l[e] = make_float2(o.a0, o.a1);
-                reinterpret_cast<float2*>(R.act_buf)[tn + base + e] = make_float2(o.a0, o.a1);
-                R.logp_buf[tn + base + e] = o.logp;
+        // The policy of step t + 1 runs INSIDE step t, behind barrier B2, while wave 0 works through the rules (a float64 latency
+        // chain) and the other waves would only wait for it at barrier C.  Whether the rules replace an env's observation row by its
+        // reset observation (ppo.py:582-593) the tile waves work out themselves from the values that are final at B2 (next_obs4):
+        // they read exactly the rows the step leaves -- same device functions on the same inputs, the buffers keep their bits --
+        // and the action is in LDS before barrier C, so the next step starts without a policy phase in front of it.  Round 3 ran
+        // the phase between the steps, the whole workgroup waiting for it: + 1.6 us per step over the tape kernel.
+        const bool more = t + 1 < T;
+        auto hook = [&](const int wv, const int ln) __attribute__((always_inline)) {
+            if (more) {
+                if (wv >= kTileWave0 && wv < kTileWave0 + TW) tile_policy(wv - kTileWave0, tn + N, (t + 1) & 1, std::true_type{});
+                else if (wv == kNoiseWave && ln < nloc && t + 2 < T) draw_noise(t + 2);   // row (t + 2) & 1: not the one being read
             }
-        } else if (wave == TW && lane < nloc && t + 1 < T) {
-            float e0, e1;
-            mlp64::policy_noise(step0 + (uint32_t)(t + 1), seed, gid, e0, e1);
-            pol_eps[(t + 1) & 1][lane] = make_float2(e0, e1);
-        }
-        __syncthreads();
+        };
         step_body<NB, EPB, SENS, true, NW, BOXES, PAIR, const Params __attribute__((address_space(4)))&,
-                  const StepIO __attribute__((address_space(4)))&>(P, sm, next_env, A->io, t == T - 1, tn);
-        // the observation tile of step t + 1 is in sm.obs; its store only reads it, like the next policy phase
+                  const StepIO __attribute__((address_space(4)))&, decltype(hook)>(P, sm, next_env, A->io, t == T - 1, tn, hook);
+        // the observation tile of step t + 1 is in sm.obs (its store only reads it) and its action in sm.act_l
     }
 }
 

@@ -31,15 +31,18 @@ rep("int navsim_version(void) { return NAVSIM_ABI_VERSION; }",
     "int navsim_version(void) { return NAVSIM_ABI_VERSION; }\n"
     "int navsim_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 1024); }\n"
     "int navsim_blk_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(long long) * 8192 * 3); }")
-# policy-phase stamps of the persistent rollout kernel (last step wins): loop top, MFMA part done, after barrier 1, finish done
+# stamps of the persistent rollout kernel (last step wins): slot 6 of g_dbg = the wave is through the in-step policy hook;
+# g_pol: 0 = step body left (observation tile stored), 1 = finish done (wave 0), 2 = past the step's last barrier
 rep("__device__ long long g_dbg[128 * 8];", "__device__ long long g_dbg[128 * 8];\n__device__ long long g_pol[8 * 8 * 4];\n"
     "#define PSTAMP(slot) do { if (blockIdx.x % 97 == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) g_pol[((blockIdx.x / 97) % 8) * 32 + (threadIdx.x >> 6) * 4 + (slot)] = wall_clock64(); } while (0)")
-rep("        if (wave < 4) {\n            const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]",
-    "        PSTAMP(0);\n        if (wave < 4) {\n            const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]")
-rep("            pol_eps[lane] = make_float2(e0, e1);\n        }\n        __syncthreads();",
-    "            pol_eps[lane] = make_float2(e0, e1);\n        }\n        PSTAMP(1);\n        __syncthreads();\n        PSTAMP(2);")
-rep("            R.logp_buf[tn + base + e] = o.logp;\n        }\n        __syncthreads();",
-    "            R.logp_buf[tn + base + e] = o.logp;\n        }\n        PSTAMP(3);\n        __syncthreads();")
+rep("    hook(wave, lane);\n", "    hook(wave, lane);\n    STAMP(6);\n")
+# (timing build only: the last step runs the in-step policy too, so that its stamps show the phase; its row lands on row T - 1)
+rep("        const bool more = t + 1 < R.T;\n        auto hook = [&](const int wv, const int ln) __attribute__((always_inline)) {\n            // (measured",
+    "        const bool more_real = t + 1 < R.T; const bool more = true;\n        auto hook = [&](const int wv, const int ln) __attribute__((always_inline)) {\n            // (measured")
+rep("                else if (ln < nloc) draw_noise(step0 + (uint32_t)(t + 1));\n", "                else if (ln < nloc) draw_noise(step0 + (uint32_t)(t + 1));\n                PSTAMP(1);\n")
+rep("                    if (ln < nloc) finish(tn + N);\n", "                    if (ln < nloc) finish(more_real ? tn + N : tn);\n                    PSTAMP(2);\n")
+rep("        // the observation tile of step t + 1 is in sm.obs (its store only reads it), its action in sm.act_l\n    }\n}\n\n// ---------------------------------------------------------------- n steps of an action tape",
+    "        PSTAMP(0);\n    }\n}\n\n// ---------------------------------------------------------------- n steps of an action tape")
 rep("int navsim_blk_read(long long* out)", "int navsim_pol_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pol), sizeof(long long) * 256); }\nint navsim_blk_read(long long* out)")
 if "--lb4" in extra_flags:
     rep("__global__ __launch_bounds__(kThreads) void step_kernel", "__global__ __launch_bounds__(kThreads, 4) void step_kernel")

@@ -23,20 +23,16 @@ if "--rollout" in sys.argv:   # the persistent rollout kernel: stamps of its LAS
     L = _native.lib(); L.navsim_dbg_read.argtypes = [C.c_void_p]; L.navsim_dbg_read(buf.ctypes.data_as(C.c_void_p))
     b = buf.reshape(8, 16, 8)
     print(f"persistent rollout: {us:.2f} us per step ({T} steps)")
-    for blk in range(3):
-        t0 = b[blk, :4, 0].min()
-        print(f"block sample {blk}: last step")
-        for w in range(4):
-            print("  wave", w, " ".join(f"{names[s]}={(b[blk, w, s] - t0) * 10:6d}ns" for s in range(8)))
-        print(f"  step body {(b[blk, :4, 7].max() - t0) * 10} ns -> policy phase + barrier ~ {us * 1e3 - (b[blk, :4, 7].max() - t0) * 10:.0f} ns")
+    names = ["start", "pre-A", "post-A", "pre-B", "post-B", "pre-C", "hook-done", "end"]
     pol = np.zeros(256, dtype=np.int64)
     L.navsim_pol_read.argtypes = [C.c_void_p]; L.navsim_pol_read(pol.ctypes.data_as(C.c_void_p))
     pol = pol.reshape(8, 8, 4)
-    for blk in range(2):
-        p0 = pol[blk, :8, 0].min()
-        print(f"block sample {blk}: policy phase of the last step (ns after its first wave entered): top | MFMA+noise done | past barrier 1 | finish done")
+    for blk in range(3):   # stamps of the step before the last one that ran the hook (T - 2) are overwritten by T - 1: the last step has no hook
+        t0 = b[blk, :8, 0].min()
+        print(f"block sample {blk}: last step (ns after its first wave entered the step body)")
         for w in range(8):
-            print("  wave", w, " ".join(f"{(pol[blk, w, s] - p0) * 10:6d}" for s in range(4)), " step-body start", (b[blk, w, 0] - p0) * 10)
+            print("  wave", w, " ".join(f"{names[s]}={(b[blk, w, s] - t0) * 10:6d}" for s in range(8)),
+                  "| tile part / noise done", (pol[blk, w, 1] - t0) * 10, "finish done (last arriver)", (pol[blk, w, 2] - t0) * 10, "left body", (pol[blk, w, 0] - t0) * 10)
     sys.exit(0)
 N = 4096 if CFG2 else 16384
 EPBv = int(os.environ.get('NAVSIM_EPB', '64' if N >= 16384 else '32' if N >= 4096 else '16'))   # pick_epb's rule
