@@ -143,6 +143,15 @@ int navsim_reset(navsim_t* h, const uint8_t* mask_dev, void* obs_dev, void* stre
  *   ep_path_dev      [N] f32    out  nullable: written only where ended: the episode's path length as PPO.rollout
  *                                    accumulates it (ppo.py:533-537: distances between the positions read BEFORE each
  *                                    step, so the last step's displacement is not part of it)
+ *
+ * Precision of the pose (what "identical" means for the float64 state): the motion model of turtlebot3_fake.cpp:154-163
+ * integrates six 30 Hz sub-steps with one library sincos each.  The kernel evaluates the library sincos of the FINAL heading
+ * (which also gives the sensor origin and the beam directions, i.e. everything the scan's bits depend on) and obtains the six
+ * sub-step headings from it by angle addition, sums the sub-step displacements last-first and takes the step's path length
+ * from the summed displacement.  x, y and the path length therefore agree with the serial integration to ~1e-16 per step
+ * (relative 1e-15), not bit for bit; the heading itself (six additions of delta_theta) is bit-identical.  The tests hold the pose
+ * to 1e-11 over hundreds of steps; observations and flags are compared separately (flags exactly, observations 1e-6, > 99 %
+ * of the rows bit-identical -- a 1e-16 difference moves a float32 rounding or a decimal round() tie with probability ~1e-9).
  */
 int navsim_step(navsim_t* h, const float* action_dev, const float* past_action_dev, void* obs_dev,
                 float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,

@@ -77,7 +77,7 @@ struct Params {
     // The first 128 bytes hold what the first memory requests of a step launch need (the pose waves' state loads, the ray waves'
     // first segment tiles): they arrive with the first round of scalar kernarg loads.  In declaration order the compiler reached
     // the state pointers in its fourth dependent round, ~1 us into the launch.
-    int N, S, per_env;
+    int N, S, per_env;        // per_env: bit 0 = one map per env, bits 1 / 2 = stream it with non-temporal loads (navsim_set_map)
     int seg_pack_log2;        // cast: log2(lanes per env in one 64-lane pass) = 6, or log2(pow2ceil(S)) when S <= 32
     const float4* seg;        // [S] or [N][S]
     double *th, *x, *y, *gx, *gy, *past_dist, *ep_ret, *ep_path;
@@ -521,6 +521,16 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     // (locals: read through the kernarg segment, P's fields are scalar loads at every use -- these sit in the cast loop)
     const int S = P.S;
     const bool per_env = P.per_env != 0;
+    // Non-temporal hint on the per-env segment stream (128-segment passes), by measurement (profiles/r04_nontemporal_loads_ablation.txt,
+    // 16384 envs, us per step, default / non-temporal loads):
+    //   one launch per step   S=128 13.11 / 12.64   S=256 18.58 / 17.62   S=512-1024 equal   S=1280 66.2 / 60.8   S=1536 82.4 / 71.8
+    //   persistent (tape)     S=128  9.74 / 10.93   S=256 14.69 / 16.91   S=1024 41.6 / 48.2  S=1280 equal         S=1536 73.8 / 71.5
+    // A launch reads every segment once and the next launch finds nothing of a >= 35 MB stream in the 8 x 4 MB of L2 (LRU), so
+    // allocating the lines there is pure overhead: step_kernel always streams.  A persistent workgroup re-reads ITS envs' segments every
+    // step from its own XCD's L2 / the Infinity Cache (traffic 0.77 x algorithmic at configs[2]) and keeps the default policy until
+    // one step's stream exceeds 1.25 x the Infinity Cache (bit 1 of per_env, navsim_set_map), where nothing can be re-used either.
+    // (Below 32 MiB the stream fits the L2s and is left there: bit 2.)
+    const bool seg_nt = (P.per_env & (PERSIST ? 2 : 4)) != 0;
     const float4* const segs = P.seg;
     const int ntiles = (S + 63) >> 6;
     // PAIR (maps of more than 64 segments, one env per pass): a pass takes 128 segments, two per lane (j and j + 64) -- the
@@ -547,8 +557,17 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         va = item && (j < S);
         vb = item && (j + 64 < S);
         const float4* src = segs + (per_env ? (size_t)(base + min(p.it, nloc - 1)) * (size_t)S : (size_t)0);
-        ga = src[min(j, S - 1)];
-        gb = src[min(j + 64, S - 1)];
+        if (seg_nt) {   // wave-uniform; two requests on either path (the vmcnt bookkeeping above stays static)
+            typedef float v4f_nt __attribute__((ext_vector_type(4)));
+            const v4f_nt* srcv = reinterpret_cast<const v4f_nt*>(src);
+            const v4f_nt a4 = __builtin_nontemporal_load(srcv + min(j, S - 1));
+            const v4f_nt b4 = __builtin_nontemporal_load(srcv + min(j + 64, S - 1));
+            ga = make_float4(a4.x, a4.y, a4.z, a4.w);
+            gb = make_float4(b4.x, b4.y, b4.z, b4.w);
+        } else {
+            ga = src[min(j, S - 1)];
+            gb = src[min(j + 64, S - 1)];
+        }
     };
     Pos p0 = {n_items, 0}, p1 = {n_items, 0}, p2 = {n_items, 0};
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0, g0b = g0, g1b = g0, g2b = g0;
@@ -950,7 +969,7 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
             const bool on = lane < n;
             const int slot = (rhead + lane) & 127;
             const float4 g = on ? r4[slot] : make_float4(0.f, 0.f, 1.f, 0.f);
-            const unsigned el = on ? (re[slot] & 255u) : 0u;
+            const unsigned el = on ? (kPairB ? (re[slot] & 255u) : re[slot]) : 0u;
             exact_tests(on, g, el, 0, NB, std::integral_constant<int, NB>{});
             rhead += n;
         };
@@ -1021,9 +1040,11 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
             // sensor, an arc through straight-behind) keeps the segment for every beam
             const bool all = bad_a || bad_b || through || wrap;
             const bool keep = on && (all ? (bad_a || bad_b || through || outside) : inside);
-            // beams ce .. fl of the fan (v_med3 clamps; a NaN coordinate has set `bad`)
-            const float b_lo = __builtin_amdgcn_fmed3f(ce, 0.f, (float)(NB - 1)), b_hi = __builtin_amdgcn_fmed3f(fl, 0.f, (float)(NB - 1));
-            const unsigned ext = all ? ((unsigned)NB << 16) : (((unsigned)(int)b_lo << 8) | ((unsigned)((int)(b_hi - b_lo) + 1) << 16));
+            unsigned ext = 0u;
+            if constexpr (kPairB) {   // beams ce .. fl of the fan (v_med3 clamps; a NaN coordinate has set `bad`)
+                const float b_lo = __builtin_amdgcn_fmed3f(ce, 0.f, (float)(NB - 1)), b_hi = __builtin_amdgcn_fmed3f(fl, 0.f, (float)(NB - 1));
+                ext = all ? ((unsigned)NB << 16) : (((unsigned)(int)b_lo << 8) | ((unsigned)((int)(b_hi - b_lo) + 1) << 16));
+            }
             qhead += n;
             const unsigned long long bal = __ballot(keep);
             if (bal) {
@@ -1041,24 +1062,24 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
             }
         };
         // stage A: cull + compaction of one tile (64 lanes = 64 segments, or 64 / epp segments of epp envs)
+        // (Round 4 tried a leaner form -- the distance test in the world frame, "behind" as the half plane X < -1 mm: 12 fewer
+        // vector instructions per 128-segment pass, SQ_INSTS_VALU -2.4 % -- and measured it SLOWER on the same box, configs[2]
+        // 13.18 vs 13.08 us, the house map 34.6 vs 33.3 us: the cast is not bound by the instruction count alone.)
         auto keep_of = [&](const float4 g, const float2 o, const float2 h) __attribute__((always_inline)) -> bool {
-            // float32 throughout: this decides only what is tested exactly.  Endpoints relative to the sensor, WORLD frame -- the
-            // distance test does not care about the frame, and the behind test needs only the forward coordinate X = (p - o) . h.
+            // endpoints in the robot frame (X ahead, Y left); float32 throughout: this decides only what is tested exactly
             const float ax = g.x - o.x, ay = g.y - o.y, bx = g.z - o.x, by = g.w - o.y;
-            const float xa = fmaf(ax, h.x, ay * h.y), xb = fmaf(bx, h.x, by * h.y);
-            // behind: both endpoints (hence the whole segment) in the half plane X < -1 mm.  The beams span +-(pi/2 + 1.2e-6): the
-            // outermost one reaches X = -1 mm at a range of 1e-3 / sin(1.2e-6) = 830 m, far beyond the 3.5 m where a return ends
-            // (round 3 tested the cone X < -1e-3 |Y| instead, which needs the lateral coordinates as well; the half plane culls
-            // a superset of it inside the sensor range and is as safe: 1e-3 m / 3.5 m = 2.9e-4 rad against 1.2e-6)
-            const bool behind = (xa < -1e-3f) && (xb < -1e-3f);
+            const float xa = fmaf(ax, h.x, ay * h.y), ya = fmaf(ay, h.x, -(ax * h.y));
+            const float xb = fmaf(bx, h.x, by * h.y), yb = fmaf(by, h.x, -(bx * h.y));
+            // behind: both endpoints inside the convex cone X < -1e-3 |Y|; the beams span +-(pi/2 + 1.2e-6)
+            const bool behind = (fmaf(1e-3f, fabsf(ya), xa) < 0.f) && (fmaf(1e-3f, fabsf(yb), xb) < 0.f);
             // far: distance from the sensor to the segment above 3.5 m (threshold 12.3 = (3.5 * 1.002)^2).  The closest point
             // is a + t e with t = clamp(-a.e / e.e, 0, 1); the error of the hardware reciprocal moves it by < 1e-7 |e|, far
             // inside the 7 mm margin for any segment shorter than 10 km; a zero-length segment gives t = 0 (0 x inf = NaN
             // takes v_med3's minimum).  So the test stays conservative.
-            const float ex = bx - ax, ey = by - ay;
-            const float e2 = fmaf(ex, ex, ey * ey), ae = fmaf(ax, ex, ay * ey);
+            const float ex = xb - xa, ey = yb - ya;
+            const float e2 = fmaf(ex, ex, ey * ey), ae = fmaf(xa, ex, ya * ey);
             const float t = __builtin_amdgcn_fmed3f(-ae * __builtin_amdgcn_rcpf(e2), 0.f, 1.f);
-            const float cx = fmaf(t, ex, ax), cy = fmaf(t, ey, ay);
+            const float cx = fmaf(t, ex, xa), cy = fmaf(t, ey, ya);
             const float d2 = fmaf(cx, cx, cy * cy);
             // d2 < 1e-6: the segment passes within 1 mm of the sensor, where the angles are noise: keep
             return (d2 < 1e-6f) || !(behind || (d2 > 12.3f));
@@ -2235,6 +2256,11 @@ int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_
     P.seg = reinterpret_cast<const float4*>(seg_dev);
     P.S = n_segments;
     P.per_env = per_env ? 1 : 0;
+    // bit 1: the per-env segment stream of one step (N x S x 16 B) exceeds 1.25 x the 256 MiB Infinity Cache -> the persistent
+    // kernels load it non-temporally too (step_body: seg_nt)
+    if (per_env && (size_t)P.N * (size_t)n_segments * sizeof(float4) >= (size_t)320 << 20) P.per_env |= 2;
+    // bit 2: it does not fit the 8 x 4 MiB of L2 -> the one-launch-per-step kernel loads it non-temporally
+    if (per_env && (size_t)P.N * (size_t)n_segments * sizeof(float4) >= (size_t)32 << 20) P.per_env |= 4;
     P.seg_pack_log2 = 6;
     P.tile_box = nullptr;
     if (h->seg_sorted_dev || h->tile_box_dev) {

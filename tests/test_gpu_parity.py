@@ -1002,14 +1002,16 @@ def _seq_vs_oracle(N, seg, per_env, T, blocks, rects=None, sampler=None, acts_se
     return n_end
 
 
-@pytest.mark.parametrize("case", ["small", "cfg3", "cfg5_house", "cfg4_36beams"])
+@pytest.mark.parametrize("case", ["small", "cfg3", "cfg5_house", "cfg4_36beams", "hbm_stream"])
 def test_step_seq_against_the_oracle(case):
     """navsim_step_seq checked DIRECTLY against the CPU oracle (not only against the per-step launches), in the instantiations the
     BASELINE shards run: `small` 512 envs on per-env stage_2 maps with auto-reset and arrival re-spawn (16-env shape); `cfg3`
     configs[2]'s own workload -- 16384 envs, per-env stage_2 maps with their goal rectangles: the 64-env workgroup and the
     128-segments-per-pass cast -- with three blocks of envs (first, middle, last workgroups) replayed on the oracle; `cfg5_house` an
     8192-env shard on the shared 2048-segment house map with the start / goal tables (tile boxes); `cfg4_36beams` a 4096-env shard
-    of configs[3] (stage_4, 36 beams)."""
+    of configs[3] (stage_4, 36 beams: stage B on (segment, beam-group) entries); `hbm_stream` per-env maps large enough that one
+    step's segment stream exceeds 1.25 x the Infinity Cache (navsim_set_map switches the persistent kernels' segment loads to
+    non-temporal; the one-launch-per-step kernel always streams per-env maps that way)."""
     if case == "small":
         seg = maps.replicate_per_env(maps.stage_2(), 512, seed=2)
         _seq_vs_oracle(512, seg, True, 48, [(0, 512)], max_episode_steps=20, auto_reset=True, respawn_on_arrive=True, seed=9)
@@ -1022,9 +1024,13 @@ def test_step_seq_against_the_oracle(case):
         st, g, lo, hi = maps.spawn_tables("small_house")
         _seq_vs_oracle(8192, seg, False, 30, [(0, 64), (4090, 100), (8192 - 40, 40)], sampler=maps.open_tables(seg, st, g) + (lo, hi),
                        max_episode_steps=18, auto_reset=True, seed=6)
-    else:
+    elif case == "cfg4_36beams":
         _seq_vs_oracle(4096, maps.stage_4(), False, 40, [(0, 64), (2040, 80), (4096 - 32, 32)], rects="stage_4", n_beams=36,
                        max_episode_steps=25, auto_reset=True, seed=7)
+    else:   # 16384 envs x 1536 segments x 16 B = 402 MB per step > 1.25 x the Infinity Cache: non-temporal stream, persistent form too
+        seg = maps.replicate_per_env(maps.stage_2(sides=376), 16384, seed=3)
+        assert seg.shape[1] == 1536
+        _seq_vs_oracle(16384, seg, True, 8, [(0, 48), (16384 - 48, 48)], rects="stage_2", max_episode_steps=5, auto_reset=True, seed=8)
 
 
 def test_g10_reference_rollout_in_one_launch():

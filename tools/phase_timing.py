@@ -13,7 +13,11 @@ if "--rollout" in sys.argv:   # the persistent rollout kernel: stamps of its LAS
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
     T = 256
-    env = VecEnv(4096, map="stage_1", max_episode_steps=500, seed=0)
+    BIG = "--big" in sys.argv   # configs[2] closed loop: 16384 envs, per-env stage_2 maps -> rollout_big_kernel (16 waves, 64 envs)
+    if BIG:
+        env = VecEnv(16384, map="stage_2", max_episode_steps=500, seed=0, per_env_map=True)
+    else:
+        env = VecEnv(4096, map="stage_1", max_episode_steps=500, seed=0)
     tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=T, policy="mlp64x2", n_updates_per_iteration=1))
     tr.rollout(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -28,11 +32,12 @@ if "--rollout" in sys.argv:   # the persistent rollout kernel: stamps of its LAS
     L.navsim_pol_read.argtypes = [C.c_void_p]; L.navsim_pol_read(pol.ctypes.data_as(C.c_void_p))
     pol = pol.reshape(8, 8, 4)
     for blk in range(3):   # stamps of the step before the last one that ran the hook (T - 2) are overwritten by T - 1: the last step has no hook
-        t0 = b[blk, :8, 0].min()
+        NWV = 16 if BIG else 8
+        t0 = b[blk, :NWV, 0].min()
         print(f"block sample {blk}: last step (ns after its first wave entered the step body)")
-        for w in range(8):
+        for w in range(NWV):
             print("  wave", w, " ".join(f"{names[s]}={(b[blk, w, s] - t0) * 10:6d}" for s in range(8)),
-                  "| tile part / noise done", (pol[blk, w, 1] - t0) * 10, "finish done (last arriver)", (pol[blk, w, 2] - t0) * 10, "left body", (pol[blk, w, 0] - t0) * 10)
+                  *(() if BIG or w >= 8 else ("| tile part / noise done", (pol[blk, w, 1] - t0) * 10, "finish done (last arriver)", (pol[blk, w, 2] - t0) * 10, "left body", (pol[blk, w, 0] - t0) * 10)))
     sys.exit(0)
 N = 4096 if CFG2 else 16384
 EPBv = int(os.environ.get('NAVSIM_EPB', '64' if N >= 16384 else '32' if N >= 4096 else '16'))   # pick_epb's rule
