@@ -9,8 +9,9 @@ from navbot_ppo_amd import ppo
 from navbot_ppo_amd.env import VecEnv
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 policy = sys.argv[2] if len(sys.argv) > 2 else "mlp64x2"
-env = VecEnv(4096, map="stage_1", max_episode_steps=500, seed=0)
-tr = ppo.PPOTrainer(env, ppo.PPOConfig(policy=policy, seed=0))
+SEED = int(os.environ.get("LC_SEED", "0"))
+env = VecEnv(4096, map="stage_1", max_episode_steps=500, seed=SEED)
+tr = ppo.PPOTrainer(env, ppo.PPOConfig(policy=policy, seed=SEED))
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for it in range(1, iters + 1):
     lg = tr.iteration()
