@@ -374,6 +374,18 @@ class Env:
         self._obs_t, self._rew_t = self._pin[16:32].view(1, 16), self._pin[32:33]
         self._done_t, self._arrive_t, self._ended_t = self._pin_u8[0:1], self._pin_u8[1:2], self._pin_u8[2:3]
         self._state = None   # host copy of pose / goal / past_distance, fetched when an attribute is read
+        # One env step from Python is launch-latency bound (kernel 6 us, the rest is the way there and back): the argument list of
+        # navsim_step / navsim_reset is built ONCE -- ctypes pointers of the pinned block, the stream the env was created on -- so
+        # that a step is one foreign call and one stream wait (building twelve c_void_p objects, looking up the current stream and
+        # entering a device context per step were 5 of the 25 us).
+        dev = self._sim.device
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._stream_obj = torch.cuda.current_stream(dev)
+        st = C.c_void_p(self._stream_obj.cuda_stream)
+        self._lib = lib()
+        self._step_args = (self._sim._h, _ptr(self._act_t), _ptr(self._past_t), _ptr(self._obs_t), _ptr(self._rew_t), _ptr(self._done_t),
+                           _ptr(self._arrive_t), _ptr(self._ended_t), None, None, None, st)
+        self._reset_args = (self._sim._h, None, _ptr(self._obs_t), st)
 
     # -- attributes the reference's callers read (ppo.py:535, main.py:202; environment_new.py:29-41): fetched lazily, one
     #    navsim_get_state per step at most, and none at all for callers that never look
@@ -403,10 +415,17 @@ class Env:
         return float(self._st()["past_dist"][0])
 
     def _wait(self):
-        torch.cuda.current_stream(self._sim.device).synchronize()   # the step's only synchronisation
+        self._stream_obj.synchronize()   # the step's only synchronisation
+
+    def _call(self, fn, args, what):
+        if torch.cuda.current_device() == self._dev_index:
+            check(fn(*args), what)
+        else:
+            with torch.cuda.device(self._dev_index):
+                check(fn(*args), what)
 
     def reset(self):
-        self._sim.reset(self._obs_t)
+        self._call(self._lib.navsim_reset, self._reset_args, "navsim_reset")
         self._wait()
         self._state = None
         return self._pin_np[16:32].astype(np.float64)
@@ -418,8 +437,7 @@ class Env:
             raise IndexError("action and past_action need two components")  # as action[1] would in the reference
         self._pin_np[0:2] = a[:2]
         self._pin_np[2:4] = p[:2]
-        self._sim.step(self._act_t, self._obs_t, self._rew_t, self._done_t, self._arrive_t, self._ended_t, None, None,
-                       past_action=self._past_t)
+        self._call(self._lib.navsim_step, self._step_args, "navsim_step")
         self._wait()
         self._state = None
         return (self._pin_np[16:32].astype(np.float64), float(self._pin_np[32]), bool(self._pin_u8_np[0]),

@@ -37,3 +37,18 @@ for _ in range(n):
     st.synchronize()
 lw = (time.perf_counter() - t0) / n * 1e6
 print(f"Env.step {full:.1f} us = launch through ctypes {launch:.1f} (async, back to back) | launch + stream wait {lw:.1f} | kernel alone {kern:.1f} (graph replay, device) | numpy in / out {full - lw:.1f}")
+# the same with a query spin instead of the blocking wait
+t0 = time.perf_counter()
+for _ in range(n):
+    sim.step(env._act_t, env._obs_t, env._rew_t, env._done_t, env._arrive_t, env._ended_t, None, None, past_action=env._past_t)
+    while not st.query():
+        pass
+print(f"launch + stream.query() spin {(time.perf_counter() - t0) / n * 1e6:.1f} us")
+ev = torch.cuda.Event()
+t0 = time.perf_counter()
+for _ in range(n):
+    sim.step(env._act_t, env._obs_t, env._rew_t, env._done_t, env._arrive_t, env._ended_t, None, None, past_action=env._past_t)
+    ev.record(st)
+    while not ev.query():
+        pass
+print(f"launch + event.query() spin {(time.perf_counter() - t0) / n * 1e6:.1f} us")
