@@ -973,6 +973,9 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
             exact_tests(on, g, el, 0, NB, std::integral_constant<int, NB>{});
             rhead += n;
         };
+        // (Measured without gain, round 4: splitting a wave's LAST pass -- ~40 segments at configs[2], 15-30 on a small shared map --
+        // over two or four lanes per segment, each testing half / a quarter of the beams: 117 / 75 instead of 206 instructions on the
+        // tail that barrier B waits for, and configs[2] 12.6-12.7 vs 12.6-12.7 us, the 16-env rollout 5.11-5.18 vs 5.06-5.10.)
         // up to 64 entries (lane = entry): kBeamsPerEntry consecutive beams of one queued segment
         auto testB = [&](int n) __attribute__((always_inline)) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1100,12 +1103,15 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         auto cull = [&](const Pos p, const float4 g, const bool v) __attribute__((always_inline)) {
             const int el = min(p.it * epp + sub, nloc - 1);
             const float2 o = sm.org[el], h = sm.hd[el];
-            push(g, (unsigned)el, v && keep_of(g, o, h));
+            push(g, (unsigned)el, keep_of(g, o, h) & v);   // evaluated unconditionally, see cull2
         };
         auto cull2 = [&](const Pos p, const float4 ga, const bool va, const float4 gb, const bool vb) __attribute__((always_inline)) {
             const int el = min(p.it, nloc - 1);
             const float2 o = sm.org[el], h = sm.hd[el];
-            const bool ka = va && keep_of(ga, o, h), kb = vb && keep_of(gb, o, h);
+            // both tests unconditionally (an invalid lane holds a clamped, valid segment): `va && keep_of(...)` made each an exec-masked
+            // branch of its own, one dependent chain after the other; as two independent chains the compiler interleaves them
+            // (configs[2] 12.87 -> 12.62 us per launch, tape 9.30 -> 9.18, same box)
+            const bool ka = keep_of(ga, o, h) & va, kb = keep_of(gb, o, h) & vb;
             push(ga, (unsigned)el, ka);   // at most 63 + 64 queued before either flush: the ring holds 128
             push(gb, (unsigned)el, kb);
         };
