@@ -470,7 +470,7 @@ struct StepIO {
 struct NoHook {
     __device__ __forceinline__ void operator()(int, int) const {}
 };
-template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4, bool BOXES = false, bool PAIR = false, class PRef = const Params&,
+template <int NB, int EPB, bool SENS, bool PERSIST, int NW = 4, bool BOXES = false, int PAIR = 0, class PRef = const Params&,
           class IORef = const StepIO&, class Hook = NoHook>
 __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int& next_env, IORef io, const bool last_step = true,
                                           const size_t row0 = 0, Hook hook = Hook()) {
@@ -529,8 +529,7 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     // allocating the lines there is pure overhead: step_kernel always streams.  A persistent workgroup re-reads ITS envs' segments every
     // step from its own XCD's L2 / the Infinity Cache (traffic 0.77 x algorithmic at configs[2]) and keeps the default policy until
     // one step's stream exceeds 1.25 x the Infinity Cache (bit 1 of per_env, navsim_set_map), where nothing can be re-used either.
-    // (Below 32 MiB the stream fits the L2s and is left there: bit 2.)
-    const bool seg_nt = (P.per_env & (PERSIST ? 2 : 4)) != 0;
+    // (Below 32 MiB the stream fits the L2s and is left there: bit 2.)  The host picks the PAIR == 2 instantiation accordingly.
     const float4* const segs = P.seg;
     const int ntiles = (S + 63) >> 6;
     // PAIR (maps of more than 64 segments, one env per pass): a pass takes 128 segments, two per lane (j and j + 64) -- the
@@ -557,7 +556,8 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
         va = item && (j < S);
         vb = item && (j + 64 < S);
         const float4* src = segs + (per_env ? (size_t)(base + min(p.it, nloc - 1)) * (size_t)S : (size_t)0);
-        if (seg_nt) {   // wave-uniform; two requests on either path (the vmcnt bookkeeping above stays static)
+        if constexpr (PAIR == 2) {   // the stream carries the non-temporal hint (a compile-time variant: as a run-time branch the
+                                     // compiler waited for vmcnt(0) in front of every request, i.e. no tile stayed in flight)
             typedef float v4f_nt __attribute__((ext_vector_type(4)));
             const v4f_nt* srcv = reinterpret_cast<const v4f_nt*>(src);
             const v4f_nt a4 = __builtin_nontemporal_load(srcv + min(j, S - 1));
@@ -1371,7 +1371,7 @@ typedef const StepKArgs __attribute__((address_space(4))) * StepKArgsPtr;
 static_assert(std::is_trivially_copyable<StepKArgs>::value && offsetof(StepKArgs, P) == 0 && sizeof(StepIO) == 10 * sizeof(void*),
               "kernarg mirror of step_kernel");
 
-template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, bool PAIR = false>
+template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, int PAIR = 0>
 __global__ __launch_bounds__(64 * NW) void step_kernel(StepKArgs) {
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
@@ -1542,7 +1542,7 @@ typedef const SeqKArgs __attribute__((address_space(4))) * SeqKArgsPtr;
 
 static_assert(std::is_trivially_copyable<SeqKArgs>::value && offsetof(SeqKArgs, P) == 0, "kernarg mirror of steps_kernel");
 
-template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, bool PAIR = false>
+template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, int PAIR = 0>
 __global__ __launch_bounds__(64 * NW) void steps_kernel(SeqKArgs) {   // the segment IS the struct (see step_kernel)
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
@@ -1601,7 +1601,7 @@ typedef const BigKArgs __attribute__((address_space(4))) * BigKArgsPtr;
 
 static_assert(std::is_trivially_copyable<BigKArgs>::value && offsetof(BigKArgs, P) == 0, "kernarg mirror of rollout_big_kernel");
 
-template <int EPB, bool SENS, int NW, bool BOXES = false, bool PAIR = false>
+template <int EPB, bool SENS, int NW, bool BOXES = false, int PAIR = 0>
 __global__ __launch_bounds__(64 * NW) void rollout_big_kernel(BigKArgs) {   // the segment IS the struct (see step_kernel)
     constexpr int NB = 10, D = NB + 6, DP = D + 1, kThreads = 64 * NW;
     constexpr int TW = EPB / 16;   // policy tiles = MFMA waves of the policy phase
@@ -2011,13 +2011,20 @@ static void launch_step(const navsim* h, const float* action, const float* past,
             if (sens) go(step_kernel<NB, EPB_, true, NW_, true>, EPB_, NW_);                         \
             else go(step_kernel<NB, EPB_, false, NW_, true>, EPB_, NW_);                             \
         } else if (pair) {                                                                           \
-            if (sens) go(step_kernel<NB, EPB_, true, NW_, false, true>, EPB_, NW_);                  \
-            else go(step_kernel<NB, EPB_, false, NW_, false, true>, EPB_, NW_);                      \
+            constexpr int kNT = (NB == 10 && EPB_ >= 32) ? 2 : 1;   /* the streaming variant exists for the big shapes */ \
+            if (nt && kNT == 2) {                                                                    \
+                if (sens) go(step_kernel<NB, EPB_, true, NW_, false, kNT>, EPB_, NW_);               \
+                else go(step_kernel<NB, EPB_, false, NW_, false, kNT>, EPB_, NW_);                   \
+            } else {                                                                                 \
+                if (sens) go(step_kernel<NB, EPB_, true, NW_, false, 1>, EPB_, NW_);                 \
+                else go(step_kernel<NB, EPB_, false, NW_, false, 1>, EPB_, NW_);                     \
+            }                                                                                        \
         } else {                                                                                     \
             if (sens) go(step_kernel<NB, EPB_, true, NW_, false>, EPB_, NW_);                        \
             else go(step_kernel<NB, EPB_, false, NW_, false>, EPB_, NW_);                            \
         }                                                                                            \
     } while (0)
+    const bool nt = (h->P.per_env & 4) != 0;   // navsim_set_map: the per-env stream does not fit the L2s
     if (epb == 8) {
         NAVSIM_GO(8, 4);
     } else if (epb == 32 || (epb == 64 && NB > 10)) {   // 8-wave workgroups of 32 envs: float64 geometry / rules lanes twice as dense
@@ -2041,14 +2048,21 @@ static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st) {
     const int epb = pick_epb(h->P.N);   // the shapes and cast variants of launch_step
     const bool boxes = h->P.tile_box != nullptr;
     const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
+    const bool nt = (h->P.per_env & 2) != 0;   // navsim_set_map: one step's per-env stream exceeds 1.25 x the Infinity Cache
 #define NAVSIM_GO(EPB_, NW_)                                                                          \
     do {                                                                                              \
         if (boxes) {                                                                                  \
             if (sens) go(steps_kernel<NB, EPB_, true, NW_, true>, EPB_, NW_);                         \
             else go(steps_kernel<NB, EPB_, false, NW_, true>, EPB_, NW_);                             \
         } else if (pair) {                                                                            \
-            if (sens) go(steps_kernel<NB, EPB_, true, NW_, false, true>, EPB_, NW_);                  \
-            else go(steps_kernel<NB, EPB_, false, NW_, false, true>, EPB_, NW_);                      \
+            constexpr int kNT = (NB == 10 && EPB_ >= 32) ? 2 : 1;                                     \
+            if (nt && kNT == 2) {                                                                     \
+                if (sens) go(steps_kernel<NB, EPB_, true, NW_, false, kNT>, EPB_, NW_);               \
+                else go(steps_kernel<NB, EPB_, false, NW_, false, kNT>, EPB_, NW_);                   \
+            } else {                                                                                  \
+                if (sens) go(steps_kernel<NB, EPB_, true, NW_, false, 1>, EPB_, NW_);                 \
+                else go(steps_kernel<NB, EPB_, false, NW_, false, 1>, EPB_, NW_);                     \
+            }                                                                                         \
         } else {                                                                                      \
             if (sens) go(steps_kernel<NB, EPB_, true, NW_, false>, EPB_, NW_);                        \
             else go(steps_kernel<NB, EPB_, false, NW_, false>, EPB_, NW_);                            \
@@ -2263,7 +2277,7 @@ int navsim_set_map(navsim_t* h, const float* seg_dev, int32_t n_segments, int32_
     P.S = n_segments;
     P.per_env = per_env ? 1 : 0;
     // bit 1: the per-env segment stream of one step (N x S x 16 B) exceeds 1.25 x the 256 MiB Infinity Cache -> the persistent
-    // kernels load it non-temporally too (step_body: seg_nt)
+    // kernels load it non-temporally too (the PAIR == 2 instantiations)
     if (per_env && (size_t)P.N * (size_t)n_segments * sizeof(float4) >= (size_t)320 << 20) P.per_env |= 2;
     // bit 2: it does not fit the 8 x 4 MiB of L2 -> the one-launch-per-step kernel loads it non-temporally
     if (per_env && (size_t)P.N * (size_t)n_segments * sizeof(float4) >= (size_t)32 << 20) P.per_env |= 4;
@@ -2438,9 +2452,10 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
         if (sens) hipLaunchKernelGGL((rollout_big_kernel<64, true, 16, BOXES_, PAIR_>), grid, block, 0, st, ka);   \
         else hipLaunchKernelGGL((rollout_big_kernel<64, false, 16, BOXES_, PAIR_>), grid, block, 0, st, ka);       \
     } while (0)
-        if (boxes) NAVSIM_BIG(true, false);
-        else if (pair) NAVSIM_BIG(false, true);
-        else NAVSIM_BIG(false, false);
+        if (boxes) NAVSIM_BIG(true, 0);
+        else if (pair && (h->P.per_env & 2)) NAVSIM_BIG(false, 2);   // one step's per-env stream exceeds 1.25 x the Infinity Cache
+        else if (pair) NAVSIM_BIG(false, 1);
+        else NAVSIM_BIG(false, 0);
 #undef NAVSIM_BIG
         HIP_TRY(hipGetLastError());
         return NAVSIM_OK;
