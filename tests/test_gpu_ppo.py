@@ -544,3 +544,34 @@ def test_vecenv_rollout_mlp64_equals_the_trainers_rollout(N):
     with pytest.raises(Exception):
         env2.rollout_mlp64(flat[:100], T, var)
     env2.close()
+
+
+@pytest.mark.parametrize("N,epb", [(2048, None), (4160, None), (200, "64")])
+def test_persistent_rollout_with_arrival_respawn(N, epb, monkeypatch):
+    """The in-step policy derives the observation row a step will leave -- incl. WHICH reset record replaces it -- before the rules
+    lane has run (next_obs4).  With respawn_on_arrive the record depends on how the episode ended (record 1 behind an arrival's
+    re-spawn draw, environment_new.py:245-267; record 0 otherwise): arrivals (threshold 0.4: ~1 % of the goals lie that close to
+    the spawn pose), collisions and time-outs all occur here, in both rollout kernels; every buffer must equal the per-step path."""
+    from navbot_ppo_amd import ppo
+    from navbot_ppo_amd.env import VecEnv
+    if epb:
+        monkeypatch.setenv("NAVSIM_EPB", epb)
+    outs = []
+    for persistent in (True, False):
+        env = VecEnv(N, map="stage_1", max_episode_steps=70, seed=4, is_training=False, respawn_on_arrive=True)
+        cfg = ppo.PPOConfig(rollout_len=150, max_episode_steps=70, n_updates_per_iteration=1, policy="mlp64x2", seed=6,
+                            persistent_rollout=persistent, use_graph=False)
+        tr = ppo.PPOTrainer(env, cfg)
+        with torch.no_grad():
+            tr.actor.layer3.bias.add_(2.0)   # drive forward: collisions as well as arrivals and time-outs
+        tr.rollout()
+        torch.cuda.synchronize()
+        outs.append(([b.clone() for b in (tr.obs_buf, tr.act_buf, tr.logp_buf, tr.rew_buf, tr.done_buf, tr.arrive_buf, tr.ended_buf)],
+                     env.sim.get_state()))
+        env.close()
+    (a, sa), (b, sb) = outs
+    assert int(a[5].sum()) > 0 and int(a[4].sum()) > 0 and int(a[6].sum()) > int(a[4].sum()) + int(a[5].sum())
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k])
