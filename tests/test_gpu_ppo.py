@@ -575,3 +575,28 @@ def test_persistent_rollout_with_arrival_respawn(N, epb, monkeypatch):
         assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y)
     for k in sa:
         np.testing.assert_array_equal(sa[k], sb[k])
+
+
+def test_persistent_rollout_on_a_streamed_map():
+    """16384 envs x 1280 segments per env = 335 MB per step: beyond 1.25 x the Infinity Cache, where navsim_set_map selects the
+    non-temporal instantiations of the 128-segment pass in the persistent kernels too (rollout_big_kernel<..., PAIR = 2>); the
+    rows must equal the per-step path's bit for bit, like everywhere else."""
+    from navbot_ppo_amd import maps, ppo
+    from navbot_ppo_amd.env import VecEnv
+    N, T = 16384, 6
+    seg = torch.from_numpy(maps.replicate_per_env(maps.stage_2(sides=312), N, seed=5)).cuda()
+    assert seg.shape[1] == 1280 and seg.numel() * 4 >= 320 << 20
+    outs = []
+    for persistent in (True, False):
+        env = VecEnv(N, map=seg, max_episode_steps=4, seed=9)
+        cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=4, n_updates_per_iteration=1, policy="mlp64x2", seed=2,
+                            persistent_rollout=persistent, use_graph=False)
+        tr = ppo.PPOTrainer(env, cfg)
+        tr.rollout()
+        torch.cuda.synchronize()
+        outs.append([b.clone() for b in (tr.obs_buf, tr.act_buf, tr.logp_buf, tr.rew_buf, tr.done_buf, tr.arrive_buf, tr.ended_buf)])
+        env.close()
+        del tr
+    assert int(outs[0][6].sum()) >= N
+    for x, y in zip(*outs):
+        assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y)
