@@ -24,7 +24,7 @@ rep("    __syncthreads();  // barrier C:", "    STAMP(5);\n    __syncthreads(); 
 # slot 6: the wave has seen the exact pose published (front waves: before part 2; ray waves: at their first stage-B pass)
 if "            pose_ok = true;\n" in t:
     rep("            pose_ok = true;\n", "            pose_ok = true;\n            STAMP(6);\n")
-idx = t.index("template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, bool PAIR = false>\n__global__ __launch_bounds__(64 * NW) void step_kernel(")
+idx = t.index("template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, int PAIR = 0>\n__global__ __launch_bounds__(64 * NW) void step_kernel(")
 j = t.rfind("}\n\n", 0, idx)
 t = t[:j] + "    STAMP(7);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk[blockIdx.x * 3 + 1] = wall_clock64();\n" + t[j:]
 rep("int navsim_version(void) { return NAVSIM_ABI_VERSION; }",
