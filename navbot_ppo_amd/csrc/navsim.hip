@@ -1987,9 +1987,21 @@ bool g_pair_cast = true;   // NAVSIM_PAIR_CAST=0: 64-segment passes for every ma
 // Envs per workgroup.  Bigger workgroups make the float64 lanes of the geometry / rules phases denser (a wave instruction
 // costs the same with 16 or 64 active lanes) and start fewer workgroups, but need N / EPB >= the number of CUs to fill the
 // chip: measured (tools/time_step.py) 16384 envs: 18.5 / 16.7 / 15.9 us with 16 / 32 / 64; 8192: 69.8 / 64.8 / 73.9; 4096: 8.9 / 8.6 / 9.8.
-static int pick_epb(int n_envs) {
+// Round 4 swept shard size x shape x beam count on shared maps (tools/epb_sweep.py, profiles/r04_epb_sweep.txt), us per step,
+// shapes 8 / 16 / 32:
+//   36 beams, tape form    1024 envs 6.3 / 10.0 / 9.9   2048: 6.5 / 10.1 / 9.8   4096: 7.0 / 10.2 / 9.9   8192: 13.0 / 11.0 / 10.0
+//   36 beams, one launch   1024: 10.5 / 12.9 / 12.7     2048: 11.0 / 13.1 / 12.9  4096: 11.9 / 13.5 / 13.1  8192: 13.9 / 14.6 / 13.5
+//   10 beams, tape form    1024:  4.45 / 5.06 / 4.72    2048: 4.49 / 5.09 / 4.70  4096: 4.94 / 5.27 / 4.81
+//   10 beams, one launch   1024:  8.6 / 7.6 / 7.2       2048: 8.8 / 7.8 / 7.3     4096: 9.2 / 8.0 / 7.6
+// With 36 beams a workgroup's chain is long (36 beam directions per env in the pose phase, stage B per beam group) and eight envs
+// on four waves, two to four workgroups per CU, overlap their chains: up to 4096 envs the 8-env shape; small 10-beam shards take it
+// in the tape form only (a launch per step pays for 4 x as many workgroups to start) and the 32-env shape otherwise.
+static int pick_epb(int n_envs, int n_beams, bool tape) {
     if (g_epb >= 8) return g_epb;
-    return n_envs >= 16384 ? 64 : (n_envs >= 4096 ? 32 : 16);
+    if (n_beams > 16) return n_envs <= 4096 ? 8 : 32;
+    if (n_envs >= 16384) return 64;
+    if (n_envs >= 4096) return 32;
+    return tape ? 8 : 32;
 }
 
 template <int NB>
@@ -2001,7 +2013,7 @@ static void launch_step(const navsim* h, const float* action, const float* past,
     auto go = [&](auto kernel, int epb, int nw) {
         hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
     };
-    const int epb = pick_epb(h->P.N);
+    const int epb = pick_epb(h->P.N, NB, false);
     const bool boxes = h->P.tile_box != nullptr;   // shared map with tile bounding boxes (navsim_set_map)
     // maps of 65+ segments without tile boxes (per-env maps; shared maps beyond 4096 segments): 128 segments per pass
     const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
@@ -2045,7 +2057,7 @@ static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st) {
     auto go = [&](auto kernel, int epb, int nw) {
         hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
     };
-    const int epb = pick_epb(h->P.N);   // the shapes and cast variants of launch_step
+    const int epb = pick_epb(h->P.N, NB, true);   // the shapes and cast variants of launch_step
     const bool boxes = h->P.tile_box != nullptr;
     const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
     const bool nt = (h->P.per_env & 2) != 0;   // navsim_set_map: one step's per-env stream exceeds 1.25 x the Infinity Cache
