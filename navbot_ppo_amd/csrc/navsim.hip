@@ -1996,9 +1996,15 @@ bool g_pair_cast = true;   // NAVSIM_PAIR_CAST=0: 64-segment passes for every ma
 // With 36 beams a workgroup's chain is long (36 beam directions per env in the pose phase, stage B per beam group) and eight envs
 // on four waves, two to four workgroups per CU, overlap their chains: up to 4096 envs the 8-env shape; small 10-beam shards take it
 // in the tape form only (a launch per step pays for 4 x as many workgroups to start) and the 32-env shape otherwise.
-static int pick_epb(int n_envs, int n_beams, bool tape) {
+// The same on the shared 2048-segment house map (tile boxes; EPB_MAP=house): 8 / 32 envs per workgroup, tape form 1024-4096 envs
+// 18.5-20.2 / 29.1-29.8 us per step, 8192: 25.0 / 30.7; one launch per step 1024-4096: 20.8-22.6 / 31.3-32.2, 8192: 38.2 / 32.6;
+// 16384 envs: the 64-env shape (35 / 37 us) ahead of every smaller one.
+// Per-env stage_2 maps (EPB_MAP=per_env), 8 / 32: tape 1024-2048 envs 5.6 / 7.2, 4096: 6.2 / 7.3, 8192: 11.5 / 7.7; a launch per step 9.2-10.2 / 9.2-9.4.
+static int pick_epb(int n_envs, int n_beams, bool tape, bool boxes, bool per_env) {
     if (g_epb >= 8) return g_epb;
     if (n_beams > 16) return n_envs <= 4096 ? 8 : 32;
+    if (boxes && (n_envs <= 4096 || (tape && n_envs <= 8192))) return 8;
+    if (per_env && tape && n_envs <= 4096) return 8;
     if (n_envs >= 16384) return 64;
     if (n_envs >= 4096) return 32;
     return tape ? 8 : 32;
@@ -2013,8 +2019,8 @@ static void launch_step(const navsim* h, const float* action, const float* past,
     auto go = [&](auto kernel, int epb, int nw) {
         hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
     };
-    const int epb = pick_epb(h->P.N, NB, false);
     const bool boxes = h->P.tile_box != nullptr;   // shared map with tile bounding boxes (navsim_set_map)
+    const int epb = pick_epb(h->P.N, NB, false, boxes, h->P.per_env != 0);
     // maps of 65+ segments without tile boxes (per-env maps; shared maps beyond 4096 segments): 128 segments per pass
     const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
 #define NAVSIM_GO(EPB_, NW_)                                                                         \
@@ -2057,8 +2063,8 @@ static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st) {
     auto go = [&](auto kernel, int epb, int nw) {
         hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
     };
-    const int epb = pick_epb(h->P.N, NB, true);   // the shapes and cast variants of launch_step
     const bool boxes = h->P.tile_box != nullptr;
+    const int epb = pick_epb(h->P.N, NB, true, boxes, h->P.per_env != 0);   // the shapes and cast variants of launch_step
     const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
     const bool nt = (h->P.per_env & 2) != 0;   // navsim_set_map: one step's per-env stream exceeds 1.25 x the Infinity Cache
 #define NAVSIM_GO(EPB_, NW_)                                                                          \
