@@ -5,7 +5,8 @@ import numpy as np, torch
 from navbot_ppo_amd import maps
 from navbot_ppo_amd.env import NavSim
 from oracle import navsim_oracle as O
-def soak(N, seg, per_env, K, B=10, cap=60, seed=0, sampler=None, amax=1.0):
+_S0 = int(os.environ.get("SOAK_SEED", "0"))   # another goal stream, action stream and policy for every configuration
+def soak(N, seg, per_env, K, B=10, cap=60, seed=_S0, sampler=None, amax=1.0):
     gpu = NavSim(N, n_beams=B, max_episode_steps=cap, auto_reset=True, seed=seed)
     cpu = O.OracleSim(N, n_beams=B, max_episode_steps=cap, auto_reset=True, seed=seed)
     for s in (gpu, cpu):
@@ -38,7 +39,7 @@ if "--rollout" not in sys.argv:   # (--rollout: only the closed-loop part below)
     soak(2048, maps.replicate_per_env(maps.stage_2(sides=56), 2048, seed=3), True, 300, amax=3.0)
 
 
-def soak_rollout(N, seg, per_env, T, iters=2, cap=60, seed=0, sampler=None):
+def soak_rollout(N, seg, per_env, T, iters=2, cap=60, seed=_S0, sampler=None):
     """The persistent rollout CLOSED-LOOP (navsim_rollout_mlp64: rollout_big_kernel beyond 4096 envs): the actions the in-kernel policy
     chose are replayed on the oracle for EVERY env; every observation row, flag and reward of every step is compared."""
     from navbot_ppo_amd import ppo
