@@ -1371,8 +1371,13 @@ typedef const StepKArgs __attribute__((address_space(4))) * StepKArgsPtr;
 static_assert(std::is_trivially_copyable<StepKArgs>::value && offsetof(StepKArgs, P) == 0 && sizeof(StepIO) == 10 * sizeof(void*),
               "kernarg mirror of step_kernel");
 
+// Eight envs on eight waves (the 36-beam shape up to 4096 envs, pick_epb): two workgroups per CU overlap their chains only if
+// both fit the register file, i.e. four waves per SIMD -- the second launch bound caps the allocation at 128 VGPRs there
+// (the tape kernel took 133-153 without it, one workgroup per CU, 4096 envs in two rounds).  0 = no bound.
+constexpr int min_waves_per_simd(int epb, int nw) { return (epb == 8 && nw == 8) ? 4 : 0; }
+
 template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, int PAIR = 0>
-__global__ __launch_bounds__(64 * NW) void step_kernel(StepKArgs) {
+__global__ __launch_bounds__(64 * NW, min_waves_per_simd(EPB, NW)) void step_kernel(StepKArgs) {
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
     // the parameter is read through the kernarg segment pointer (see step_body): scalar loads at each use
@@ -1543,7 +1548,7 @@ typedef const SeqKArgs __attribute__((address_space(4))) * SeqKArgsPtr;
 static_assert(std::is_trivially_copyable<SeqKArgs>::value && offsetof(SeqKArgs, P) == 0, "kernarg mirror of steps_kernel");
 
 template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, int PAIR = 0>
-__global__ __launch_bounds__(64 * NW) void steps_kernel(SeqKArgs) {   // the segment IS the struct (see step_kernel)
+__global__ __launch_bounds__(64 * NW, min_waves_per_simd(EPB, NW)) void steps_kernel(SeqKArgs) {   // the segment IS the struct (see step_kernel)
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
     // parameters through the kernarg segment pointer, as in step_kernel (scalar loads at each use, no spilled SGPRs)
@@ -1996,6 +2001,9 @@ bool g_pair_cast = true;   // NAVSIM_PAIR_CAST=0: 64-segment passes for every ma
 // With 36 beams a workgroup's chain is long (36 beam directions per env in the pose phase, stage B per beam group) and eight envs
 // on four waves, two to four workgroups per CU, overlap their chains: up to 4096 envs the 8-env shape; small 10-beam shards take it
 // in the tape form only (a launch per step pays for 4 x as many workgroups to start) and the 32-env shape otherwise.
+// The 36-beam 8-env shape then went from four to eight waves (one env's beam groups per wave; min_waves_per_simd keeps two
+// workgroups on a CU): tape form 1024 / 2048 / 4096 envs 6.3 / 6.5 / 7.0 -> 5.2 / 5.4 / 6.3 us per step, a launch per step
+// unchanged (10.4 / 11.0 / 12.0); with 10 beams eight waves gain 2-3 % at 1024-2048 envs and nothing at 4096: four stay.
 // The same on the shared 2048-segment house map (tile boxes; EPB_MAP=house): 8 / 32 envs per workgroup, tape form 1024-4096 envs
 // 18.5-20.2 / 29.1-29.8 us per step, 8192: 25.0 / 30.7; one launch per step 1024-4096: 20.8-22.6 / 31.3-32.2, 8192: 38.2 / 32.6;
 // 16384 envs: the 64-env shape (35 / 37 us) ahead of every smaller one.
@@ -2043,8 +2051,9 @@ static void launch_step(const navsim* h, const float* action, const float* past,
         }                                                                                            \
     } while (0)
     const bool nt = (h->P.per_env & 4) != 0;   // navsim_set_map: the per-env stream does not fit the L2s
-    if (epb == 8) {
-        NAVSIM_GO(8, 4);
+    if (epb == 8) {   // 36 beams: eight waves (one env's stage B per wave); 10 beams: four
+        if constexpr (NB > 16) NAVSIM_GO(8, 8);
+        else NAVSIM_GO(8, 4);
     } else if (epb == 32 || (epb == 64 && NB > 10)) {   // 8-wave workgroups of 32 envs: float64 geometry / rules lanes twice as dense
         NAVSIM_GO(32, 8);
     } else if (epb == 64) {   // 16-wave workgroups of 64 envs (10 beams: the 36-beam tile does not fit the LDS)
@@ -2086,8 +2095,9 @@ static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st) {
             else go(steps_kernel<NB, EPB_, false, NW_, false>, EPB_, NW_);                            \
         }                                                                                             \
     } while (0)
-    if (epb == 8) {
-        NAVSIM_GO(8, 4);
+    if (epb == 8) {   // 36 beams: eight waves (one env's stage B per wave); 10 beams: four
+        if constexpr (NB > 16) NAVSIM_GO(8, 8);
+        else NAVSIM_GO(8, 4);
     } else if (epb == 32 || (epb == 64 && NB > 10)) {
         NAVSIM_GO(32, 8);
     } else if (epb == 64) {

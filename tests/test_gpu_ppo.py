@@ -329,15 +329,10 @@ def test_fused_multi_rank_epoch_equals_single_rank(tmp_path, overlap):
     """The N > 1 update path on the GPU (fused passes -> one all-reduce of the flat gradient -> scale + Adam kernel; overlap: the
     two-stage per-net pipeline, each net's all-reduce under the other net's pass) with two ranks on shards of the G7 batch == the
     single-rank path (fused passes + in-kernel Adam) on the whole batch."""
-    import socket
-    import torch.multiprocessing as mp
+    from _ranks import spawn_ranks
     from navbot_ppo_amd import nets, ppo
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     path = str(tmp_path / "dpg")
-    mp.spawn(_dp_gpu_worker, args=(2, port, path, overlap), nprocs=2, join=True)
+    spawn_ranks(_dp_gpu_worker, 2, lambda port: (2, port, path, overlap))
     r0, r1 = torch.load(path + ".0"), torch.load(path + ".1")
     assert torch.equal(r0["flat"], r1["flat"])
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_update.npz"))
@@ -380,15 +375,10 @@ def test_update_through_rccl_single_rank(tmp_path, policy, overlap):
     two ranks on one device), process group created with device_id, fused passes -> one all-reduce of the flat gradient (with
     overlap: the per-net pipeline, each net's all-reduce under the other net's pass) -> navppo_adam_step, plus max-reduce /
     broadcast / barrier.  Must equal the single-process path (fused passes + in-kernel Adam) on the same batch."""
-    import socket
-    import torch.multiprocessing as mp
+    from _ranks import spawn_ranks
     from navbot_ppo_amd import nets, ppo
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     path = str(tmp_path / "rccl1.pt")
-    mp.spawn(_rccl_one_rank_worker, args=(port, path, policy, overlap), nprocs=1, join=True)
+    spawn_ranks(_rccl_one_rank_worker, 1, lambda port: (port, path, policy, overlap))
     r = torch.load(path)
     assert r["rccl"] and r["rccl"] != "unknown"
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_update.npz"))

@@ -252,14 +252,9 @@ def _dp_gpu_worker(rank, world, port, path):
 def test_fused_resmlp512_multi_rank_epoch_equals_single_rank(tmp_path):
     """N > 1 update path (fused passes -> one all-reduce of the flat gradient -> scale + Adam kernel) with two ranks on shards
     of the G7 batch == the single-rank path on the whole batch; the reported gradient norms are those of the MEAN gradient."""
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    from _ranks import spawn_ranks
     path = str(tmp_path / "dpg")
-    mp.spawn(_dp_gpu_worker, args=(2, port, path), nprocs=2, join=True)
+    spawn_ranks(_dp_gpu_worker, 2, lambda port: (2, port, path))
     r0, r1 = torch.load(path + ".0"), torch.load(path + ".1")
     assert torch.equal(r0["flat"], r1["flat"])
     d = np.load(os.path.join(G, "g7_update.npz"))

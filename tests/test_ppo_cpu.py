@@ -3,7 +3,6 @@ from the reference (G6, G7, G8), and the world_size-2 gloo data-parallel path.""
 import json
 import math
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -134,14 +133,6 @@ def test_g7_update_matches_reference_learn():
     assert n == 22  # actor: 4 fc + 2 heads (w,b) = 12 ; critic: 4 fc + 1 head = 10
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def _dp_worker(rank, world, port, path):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -165,9 +156,9 @@ def _dp_worker(rank, world, port, path):
 def test_data_parallel_gloo_equals_single_process(tmp_path, world):
     """world_size 2 and 8 (the node size of BASELINE configs[3]/[4]): contiguous shards of the G7 batch, flat-gradient
     all-reduce per epoch, all-reduced advantage moments == the single-process update on the whole batch."""
-    import torch.multiprocessing as mp
+    from _ranks import spawn_ranks
     path = str(tmp_path / "dp")
-    mp.spawn(_dp_worker, args=(world, _free_port(), path), nprocs=world, join=True)
+    spawn_ranks(_dp_worker, world, lambda port: (world, port, path))
     rs = [torch.load(f"{path}.{k}") for k in range(world)]
     r0, r1 = rs[0], rs[1]
     per = 512 // world

@@ -24,8 +24,10 @@ rep("    __syncthreads();  // barrier C:", "    STAMP(5);\n    __syncthreads(); 
 # slot 6: the wave has seen the exact pose published (front waves: before part 2; ray waves: at their first stage-B pass)
 if "            pose_ok = true;\n" in t:
     rep("            pose_ok = true;\n", "            pose_ok = true;\n            STAMP(6);\n")
-idx = t.index("template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, int PAIR = 0>\n__global__ __launch_bounds__(64 * NW) void step_kernel(")
+# end of step_body = the closing brace after the observation tile's store (next_obs4 follows it)
+idx = t.index("// Entries 4 kk .. 4 kk + 3 of the observation env `e` (local) will hold when this step is over")
 j = t.rfind("}\n\n", 0, idx)
+assert "o[k] = sm.obs[(k / D) * DP + (k % D)];" in t[j - 200:j], "end of step_body not where the timing patch expects it"
 t = t[:j] + "    STAMP(7);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk[blockIdx.x * 3 + 1] = wall_clock64();\n" + t[j:]
 rep("int navsim_version(void) { return NAVSIM_ABI_VERSION; }",
     "int navsim_version(void) { return NAVSIM_ABI_VERSION; }\n"
