@@ -2008,7 +2008,16 @@ bool g_pair_cast = true;   // NAVSIM_PAIR_CAST=0: 64-segment passes for every ma
 // 18.5-20.2 / 29.1-29.8 us per step, 8192: 25.0 / 30.7; one launch per step 1024-4096: 20.8-22.6 / 31.3-32.2, 8192: 38.2 / 32.6;
 // 16384 envs: the 64-env shape (35 / 37 us) ahead of every smaller one.
 // Per-env stage_2 maps (EPB_MAP=per_env), 8 / 32: tape 1024-2048 envs 5.6 / 7.2, 4096: 6.2 / 7.3, 8192: 11.5 / 7.7; a launch per step 9.2-10.2 / 9.2-9.4.
+// Waves of the 8-env workgroup.  Eight (one env per wave) halve each wave's cast chain: on the house map (tile boxes) the tape runs
+// 18.4 / 18.7 / 20.2 -> 12.1 / 12.6 / 15.0 us per step at 1024 / 2048 / 4096 envs and a launch per step 20.7 / 21.2 / 22.4 -> 14.8 /
+// 15.4 / 18.0; per-env stage_2 maps as a tape 5.5 / 5.6 / 6.1 -> 4.6 / 4.7 / 5.6; 36 beams see the comment above.  Two such
+// workgroups fit a CU (128 VGPRs each: min_waves_per_simd), so beyond 4096 envs the shape runs in rounds -- house map, 8192 envs as a
+// tape: 28.5 us per step against 24.7 on four waves, which stay for that case (10 beams, tile boxes: the only map kind pick_epb
+// sends to the 8-env shape beyond 4096 envs).
+static int waves_for_8_envs(int n_envs, int n_beams) { return (n_beams > 16 || n_envs <= 4096) ? 8 : 4; }
+
 static int pick_epb(int n_envs, int n_beams, bool tape, bool boxes, bool per_env) {
+    if (g_epb == 8 && n_envs > 4096 && n_beams <= 16 && !boxes) return 16;   // (the four-wave 8-env kernels exist for tile-box maps only)
     if (g_epb >= 8) return g_epb;
     if (n_beams > 16) return n_envs <= 4096 ? 8 : 32;
     if (boxes && (n_envs <= 4096 || (tape && n_envs <= 8192))) return 8;
@@ -2051,9 +2060,14 @@ static void launch_step(const navsim* h, const float* action, const float* past,
         }                                                                                            \
     } while (0)
     const bool nt = (h->P.per_env & 4) != 0;   // navsim_set_map: the per-env stream does not fit the L2s
-    if (epb == 8) {   // 36 beams: eight waves (one env's stage B per wave); 10 beams: four
-        if constexpr (NB > 16) NAVSIM_GO(8, 8);
-        else NAVSIM_GO(8, 4);
+    if (epb == 8) {   // eight waves (one env per wave) unless the shard needs more than two workgroups per CU (waves_for_8_envs)
+        if (waves_for_8_envs(h->P.N, NB) == 8) {
+            NAVSIM_GO(8, 8);
+        } else if constexpr (NB == 10) {   // 10 beams beyond 4096 envs: pick_epb sends only tile-box maps here
+            if (!boxes) NAVSIM_GO(16, 4);
+            else if (sens) go(step_kernel<NB, 8, true, 4, true>, 8, 4);
+            else go(step_kernel<NB, 8, false, 4, true>, 8, 4);
+        }
     } else if (epb == 32 || (epb == 64 && NB > 10)) {   // 8-wave workgroups of 32 envs: float64 geometry / rules lanes twice as dense
         NAVSIM_GO(32, 8);
     } else if (epb == 64) {   // 16-wave workgroups of 64 envs (10 beams: the 36-beam tile does not fit the LDS)
@@ -2095,9 +2109,14 @@ static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st) {
             else go(steps_kernel<NB, EPB_, false, NW_, false>, EPB_, NW_);                            \
         }                                                                                             \
     } while (0)
-    if (epb == 8) {   // 36 beams: eight waves (one env's stage B per wave); 10 beams: four
-        if constexpr (NB > 16) NAVSIM_GO(8, 8);
-        else NAVSIM_GO(8, 4);
+    if (epb == 8) {   // eight waves (one env per wave) unless the shard needs more than two workgroups per CU (waves_for_8_envs)
+        if (waves_for_8_envs(h->P.N, NB) == 8) {
+            NAVSIM_GO(8, 8);
+        } else if constexpr (NB == 10) {   // 10 beams beyond 4096 envs: pick_epb sends only tile-box maps here
+            if (!boxes) NAVSIM_GO(16, 4);
+            else if (sens) go(steps_kernel<NB, 8, true, 4, true>, 8, 4);
+            else go(steps_kernel<NB, 8, false, 4, true>, 8, 4);
+        }
     } else if (epb == 32 || (epb == 64 && NB > 10)) {
         NAVSIM_GO(32, 8);
     } else if (epb == 64) {
