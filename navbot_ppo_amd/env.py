@@ -366,7 +366,7 @@ class Env:
             seg = map
         self._sim.set_map(seg)
         # One pinned (host-mapped, device-visible) block carries a step's inputs and outputs: the kernel reads the action pair
-        # from it and stores observation, reward and flags into it, so a step is one launch + one stream wait, no copies.
+        # from it and stores observation, reward and flags into it, so a step is one launch + a poll of the block (_wait_results), no copies.
         self._pin = torch.zeros(48, dtype=torch.float32).pin_memory()
         self._pin_u8 = torch.zeros(16, dtype=torch.uint8).pin_memory()
         self._pin_np, self._pin_u8_np = self._pin.numpy(), self._pin_u8.numpy()
@@ -376,7 +376,7 @@ class Env:
         self._state = None   # host copy of pose / goal / past_distance, fetched when an attribute is read
         # One env step from Python is launch-latency bound (kernel 6 us, the rest is the way there and back): the argument list of
         # navsim_step / navsim_reset is built ONCE -- ctypes pointers of the pinned block, the stream the env was created on -- so
-        # that a step is one foreign call and one stream wait (building twelve c_void_p objects, looking up the current stream and
+        # that a step is one foreign call and one wait (building twelve c_void_p objects, looking up the current stream and
         # entering a device context per step were 5 of the 25 us).
         dev = self._sim.device
         self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -415,7 +415,28 @@ class Env:
         return float(self._st()["past_dist"][0])
 
     def _wait(self):
-        self._stream_obj.synchronize()   # the step's only synchronisation
+        self._stream_obj.synchronize()
+
+    # A step's results are waited for where they land.  The pinned block is host-coherent memory: the kernel's stores reach it while
+    # the kernel runs, so the caller plants a value the kernel never writes in every output slot (NaN in the reward and the
+    # observation, 0xFF in the flags) and polls until all of them are gone -- each slot checked for itself, no assumption on the
+    # order the stores arrive in.  Measured (tools/time_env_n1_parts.py): launch + stream.synchronize() 23.5 us, launch + this 14.1 us.
+    # A step that has not delivered after _POLLS polls (a stalled queue, a fault) falls back to the stream wait, which reports it.
+    _POLLS = 1 << 20
+
+    def _plant(self):
+        self._pin_np[16:33] = np.nan
+        self._pin_u8_np[0:3] = 255
+
+    def _wait_results(self, obs_only=False):
+        pin, u8 = self._pin_np, self._pin_u8_np
+        for _ in range(self._POLLS):
+            if pin[31] == pin[31] and (obs_only or (pin[32] == pin[32] and u8[0] != 255 and u8[1] != 255 and u8[2] != 255)) \
+                    and not np.isnan(pin[16:32]).any():
+                return
+        self._wait()
+        if np.isnan(pin[16:32]).any() or (not obs_only and (pin[32] != pin[32] or (u8[0:3] == 255).any())):
+            raise RuntimeError("the launch finished without delivering its results to the pinned block")
 
     def _call(self, fn, args, what):
         if torch.cuda.current_device() == self._dev_index:
@@ -425,8 +446,9 @@ class Env:
                 check(fn(*args), what)
 
     def reset(self):
+        self._pin_np[16:32] = np.nan
         self._call(self._lib.navsim_reset, self._reset_args, "navsim_reset")
-        self._wait()
+        self._wait_results(obs_only=True)
         self._state = None
         return self._pin_np[16:32].astype(np.float64)
 
@@ -437,8 +459,9 @@ class Env:
             raise IndexError("action and past_action need two components")  # as action[1] would in the reference
         self._pin_np[0:2] = a[:2]
         self._pin_np[2:4] = p[:2]
+        self._plant()
         self._call(self._lib.navsim_step, self._step_args, "navsim_step")
-        self._wait()
+        self._wait_results()
         self._state = None
         return (self._pin_np[16:32].astype(np.float64), float(self._pin_np[32]), bool(self._pin_u8_np[0]),
                 bool(self._pin_u8_np[1]))

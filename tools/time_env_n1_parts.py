@@ -52,3 +52,15 @@ for _ in range(n):
     while not ev.query():
         pass
 print(f"launch + event.query() spin {(time.perf_counter() - t0) / n * 1e6:.1f} us")
+# the same with a spin on the results themselves: the pinned block is host-coherent, the kernel's stores land in it while it runs;
+# a NaN planted in the reward and in the last observation entry (stored last, after barrier C) is overwritten when the step is done
+pin = env._pin_np
+nan = np.float32(np.nan)
+t0 = time.perf_counter(); spins = 0
+for _ in range(n):
+    pin[32] = nan; pin[31] = nan
+    env._call(env._lib.navsim_step, env._step_args, "navsim_step")
+    while pin[31] != pin[31] or pin[32] != pin[32]:
+        spins += 1
+print(f"launch + spin on the pinned results {(time.perf_counter() - t0) / n * 1e6:.1f} us ({spins / n:.1f} polls per step)")
+torch.cuda.synchronize()
