@@ -910,12 +910,12 @@ def _seq_vs_steps(N, seg, per_env, T, B=10, sampler=None, rects=None, **kw):
     return a
 
 
-@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg4", "cfg5", "small", "ragged", "sens", "no_reset"])
+@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg4", "cfg5", "house_4096", "small", "ragged", "sens", "no_reset"])
 def test_step_seq_equals_step_launches(case):
     """One launch for a whole action tape (navsim_step_seq: env state on chip between the steps) == one navsim_step launch per
     step, bit for bit, in every workgroup shape and cast variant: configs[1] (32-env shape, shared 32 segments), configs[2]
     (64-env shape, per-env 128 segments, two-segments-per-lane passes), configs[3]'s shard (36 beams), configs[4]'s shard (tile
-    boxes, f16 observations, start / goal tables), a 16-env-shape case, ragged N, the sensor options, and no auto-reset."""
+    boxes, f16 observations, start / goal tables), the house map on a 4000-env shard (eight-wave 8-env shape), a 16-env-shape case, ragged N, the sensor options, and no auto-reset."""
     if case == "cfg2":
         a = _seq_vs_steps(4096, maps.stage_1(), False, 40, max_episode_steps=25, auto_reset=True, respawn_on_arrive=True)
     elif case == "cfg3":
@@ -928,6 +928,11 @@ def test_step_seq_equals_step_launches(case):
         st, g, lo, hi = maps.spawn_tables("small_house")
         a = _seq_vs_steps(8192, seg, False, 24, sampler=maps.open_tables(seg, st, g) + (lo, hi), max_episode_steps=15, auto_reset=True,
                           obs_f16=True)
+    elif case == "house_4096":   # tile boxes on the eight-wave 8-env shape, both forms, with the sensor options
+        seg = maps.house(2048)
+        st, g, lo, hi = maps.spawn_tables("small_house")
+        a = _seq_vs_steps(4000, seg, False, 24, sampler=maps.open_tables(seg, st, g) + (lo, hi), max_episode_steps=15, auto_reset=True,
+                          lidar_noise_sigma=0.01, lidar_below_min="gazebo")
     elif case == "small":
         a = _seq_vs_steps(96, maps.replicate_per_env(maps.stage_2(), 96, seed=1), True, 60, max_episode_steps=30, auto_reset=True,
                           respawn_on_arrive=True)
@@ -1002,7 +1007,7 @@ def _seq_vs_oracle(N, seg, per_env, T, blocks, rects=None, sampler=None, acts_se
     return n_end
 
 
-@pytest.mark.parametrize("case", ["small", "cfg3", "cfg5_house", "cfg4_36beams", "hbm_stream"])
+@pytest.mark.parametrize("case", ["small", "cfg3", "cfg5_house", "house_4096", "cfg4_36beams", "hbm_stream"])
 def test_step_seq_against_the_oracle(case):
     """navsim_step_seq checked DIRECTLY against the CPU oracle (not only against the per-step launches), in the instantiations the
     BASELINE shards run: `small` 512 envs on per-env stage_2 maps with auto-reset and arrival re-spawn (16-env shape); `cfg3`
@@ -1024,6 +1029,11 @@ def test_step_seq_against_the_oracle(case):
         st, g, lo, hi = maps.spawn_tables("small_house")
         _seq_vs_oracle(8192, seg, False, 30, [(0, 64), (4090, 100), (8192 - 40, 40)], sampler=maps.open_tables(seg, st, g) + (lo, hi),
                        max_episode_steps=18, auto_reset=True, seed=6)
+    elif case == "house_4096":   # the same map on a 4096-env shard: 8-env workgroups on EIGHT waves (cfg5_house: on four), tile boxes
+        seg = maps.house(2048)
+        st, g, lo, hi = maps.spawn_tables("small_house")
+        _seq_vs_oracle(4096, seg, False, 30, [(0, 72), (2044, 90), (4096 - 24, 24)], sampler=maps.open_tables(seg, st, g) + (lo, hi),
+                       max_episode_steps=18, auto_reset=True, seed=12)
     elif case == "cfg4_36beams":
         _seq_vs_oracle(4096, maps.stage_4(), False, 40, [(0, 64), (2040, 80), (4096 - 32, 32)], rects="stage_4", n_beams=36,
                        max_episode_steps=25, auto_reset=True, seed=7)
