@@ -2011,20 +2011,22 @@ bool g_pair_cast = true;   // NAVSIM_PAIR_CAST=0: 64-segment passes for every ma
 // Waves of the 8-env workgroup.  Eight (one env per wave) halve each wave's cast chain: on the house map (tile boxes) the tape runs
 // 18.4 / 18.7 / 20.2 -> 12.1 / 12.6 / 15.0 us per step at 1024 / 2048 / 4096 envs and a launch per step 20.7 / 21.2 / 22.4 -> 14.8 /
 // 15.4 / 18.0; per-env stage_2 maps as a tape 5.5 / 5.6 / 6.1 -> 4.6 / 4.7 / 5.6; 36 beams see the comment above.  Two such
-// workgroups fit a CU (128 VGPRs each: min_waves_per_simd), so beyond 4096 envs the shape runs in rounds -- house map, 8192 envs as a
-// tape: 28.5 us per step against 24.7 on four waves, which stay for that case (10 beams, tile boxes: the only map kind pick_epb
-// sends to the 8-env shape beyond 4096 envs).
-static int waves_for_8_envs(int n_envs, int n_beams) { return (n_beams > 16 || n_envs <= 4096) ? 8 : 4; }
-
+// workgroups fit a CU (128 VGPRs each: min_waves_per_simd), so beyond 4096 envs the shape runs in rounds and is not chosen.
+// The 16-env workgroup went from four to eight waves the same way (two envs per wave; us per step, the rule before / 16 envs on eight waves):
+//   stage_1, 10 beams, tape form   1024: 4.30 / 3.90   2048: 4.36 / 3.91   4096: 4.80 / 4.09   8192: 4.97 / 4.97   (a launch per step: equal)
+//   per-env maps, a launch per step 1024: 9.13 / 7.86   2048: 9.24 / 8.18   4096: 9.42 / 8.47   8192: 10.5 / 10.0   (tape: the 8-env shape stays)
+//   36 beams, a launch per step    1024: 10.3 / 9.3    2048: 11.0 / 9.7    4096: 12.1 / 10.1   8192: 13.6 / 11.8   16384: 25.0 / 21.3
+//   house map, tape form           8192: 24.6 (8 envs on four waves) / 23.6 -- the last user of a four-wave shape, which is gone
 static int pick_epb(int n_envs, int n_beams, bool tape, bool boxes, bool per_env) {
-    if (g_epb == 8 && n_envs > 4096 && n_beams <= 16 && !boxes) return 16;   // (the four-wave 8-env kernels exist for tile-box maps only)
     if (g_epb >= 8) return g_epb;
-    if (n_beams > 16) return n_envs <= 4096 ? 8 : 32;
-    if (boxes && (n_envs <= 4096 || (tape && n_envs <= 8192))) return 8;
+    if (n_beams > 16) return tape ? (n_envs <= 4096 ? 8 : 32) : (n_envs <= 16384 ? 16 : 32);
+    if (boxes && n_envs <= 4096) return 8;
+    if (boxes && tape && n_envs <= 8192) return 16;
     if (per_env && tape && n_envs <= 4096) return 8;
+    if (per_env && !tape && n_envs <= 8192) return 16;
     if (n_envs >= 16384) return 64;
-    if (n_envs >= 4096) return 32;
-    return tape ? 8 : 32;
+    if (tape && !boxes && !per_env && n_envs <= 4096) return 16;
+    return 32;
 }
 
 template <int NB>
@@ -2060,20 +2062,14 @@ static void launch_step(const navsim* h, const float* action, const float* past,
         }                                                                                            \
     } while (0)
     const bool nt = (h->P.per_env & 4) != 0;   // navsim_set_map: the per-env stream does not fit the L2s
-    if (epb == 8) {   // eight waves (one env per wave) unless the shard needs more than two workgroups per CU (waves_for_8_envs)
-        if (waves_for_8_envs(h->P.N, NB) == 8) {
-            NAVSIM_GO(8, 8);
-        } else if constexpr (NB == 10) {   // 10 beams beyond 4096 envs: pick_epb sends only tile-box maps here
-            if (!boxes) NAVSIM_GO(16, 4);
-            else if (sens) go(step_kernel<NB, 8, true, 4, true>, 8, 4);
-            else go(step_kernel<NB, 8, false, 4, true>, 8, 4);
-        }
+    if (epb == 8) {   // eight waves: one env per wave
+        NAVSIM_GO(8, 8);
     } else if (epb == 32 || (epb == 64 && NB > 10)) {   // 8-wave workgroups of 32 envs: float64 geometry / rules lanes twice as dense
         NAVSIM_GO(32, 8);
     } else if (epb == 64) {   // 16-wave workgroups of 64 envs (10 beams: the 36-beam tile does not fit the LDS)
         if constexpr (NB == 10) NAVSIM_GO(64, 16);
     } else {
-        NAVSIM_GO(16, 4);
+        NAVSIM_GO(16, 8);   // two envs per wave
     }
 #undef NAVSIM_GO
 }
@@ -2109,20 +2105,14 @@ static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st) {
             else go(steps_kernel<NB, EPB_, false, NW_, false>, EPB_, NW_);                            \
         }                                                                                             \
     } while (0)
-    if (epb == 8) {   // eight waves (one env per wave) unless the shard needs more than two workgroups per CU (waves_for_8_envs)
-        if (waves_for_8_envs(h->P.N, NB) == 8) {
-            NAVSIM_GO(8, 8);
-        } else if constexpr (NB == 10) {   // 10 beams beyond 4096 envs: pick_epb sends only tile-box maps here
-            if (!boxes) NAVSIM_GO(16, 4);
-            else if (sens) go(steps_kernel<NB, 8, true, 4, true>, 8, 4);
-            else go(steps_kernel<NB, 8, false, 4, true>, 8, 4);
-        }
+    if (epb == 8) {   // eight waves: one env per wave
+        NAVSIM_GO(8, 8);
     } else if (epb == 32 || (epb == 64 && NB > 10)) {
         NAVSIM_GO(32, 8);
     } else if (epb == 64) {
         if constexpr (NB == 10) NAVSIM_GO(64, 16);
     } else {
-        NAVSIM_GO(16, 4);
+        NAVSIM_GO(16, 8);   // two envs per wave
     }
 #undef NAVSIM_GO
 }
