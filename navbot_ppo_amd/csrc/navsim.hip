@@ -1371,13 +1371,22 @@ typedef const StepKArgs __attribute__((address_space(4))) * StepKArgsPtr;
 static_assert(std::is_trivially_copyable<StepKArgs>::value && offsetof(StepKArgs, P) == 0 && sizeof(StepIO) == 10 * sizeof(void*),
               "kernarg mirror of step_kernel");
 
-// Eight envs on eight waves (the 36-beam shape up to 4096 envs, pick_epb): two workgroups per CU overlap their chains only if
-// both fit the register file, i.e. four waves per SIMD -- the second launch bound caps the allocation at 128 VGPRs there
-// (the tape kernel took 133-153 without it, one workgroup per CU, 4096 envs in two rounds).  0 = no bound.
-constexpr int min_waves_per_simd(int epb, int nw) { return (epb == 8 && nw == 8) ? 4 : 0; }
+// Eight envs on eight waves: two workgroups per CU overlap their chains only if both fit the register file, i.e. four waves per
+// SIMD -- the second launch bound caps the allocation at 128 VGPRs there (the tape kernel took 133-153 without it, one workgroup
+// per CU, 4096 envs in two rounds).  Sixteen envs on eight waves carry the bound only where the instantiation needs more than 128
+// VGPRs AND the rule runs it with two workgroups per CU (pick_epb, 8192-env shards): a launch per step at 10 beams without the
+// 128-segment passes (131 VGPRs; house map 8192 envs 38.8 -> 25.8 us, stage_1 4096 envs 7.6 -> 7.2) and the tape form at 36 beams
+// or with the 128-segment passes (131-172; 36 beams 8192 envs 13.2 -> 8.2 us per step, per-env maps 11.6 -> 6.9).  On the other
+// 16-env instantiations the bound changes nothing it should (they fit) and cost 2-5 % (the scheduler's occupancy target).  0 = none.
+constexpr int min_waves_per_simd(int nb, int epb, int nw, int pair, bool tape) {
+    if (nw != 8) return 0;
+    if (epb == 8) return 4;
+    if (epb == 16) return (tape ? (nb > 16 || pair != 0) : (nb == 10 && pair == 0)) ? 4 : 0;
+    return 0;
+}
 
 template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, int PAIR = 0>
-__global__ __launch_bounds__(64 * NW, min_waves_per_simd(EPB, NW)) void step_kernel(StepKArgs) {
+__global__ __launch_bounds__(64 * NW, min_waves_per_simd(NB, EPB, NW, PAIR, false)) void step_kernel(StepKArgs) {
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
     // the parameter is read through the kernarg segment pointer (see step_body): scalar loads at each use
@@ -1548,7 +1557,7 @@ typedef const SeqKArgs __attribute__((address_space(4))) * SeqKArgsPtr;
 static_assert(std::is_trivially_copyable<SeqKArgs>::value && offsetof(SeqKArgs, P) == 0, "kernarg mirror of steps_kernel");
 
 template <int NB, int EPB, bool SENS, int NW = 4, bool BOXES = false, int PAIR = 0>
-__global__ __launch_bounds__(64 * NW, min_waves_per_simd(EPB, NW)) void steps_kernel(SeqKArgs) {   // the segment IS the struct (see step_kernel)
+__global__ __launch_bounds__(64 * NW, min_waves_per_simd(NB, EPB, NW, PAIR, true)) void steps_kernel(SeqKArgs) {   // the segment IS the struct (see step_kernel)
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
     // parameters through the kernarg segment pointer, as in step_kernel (scalar loads at each use, no spilled SGPRs)
@@ -2017,15 +2026,17 @@ bool g_pair_cast = true;   // NAVSIM_PAIR_CAST=0: 64-segment passes for every ma
 //   per-env maps, a launch per step 1024: 9.13 / 7.86   2048: 9.24 / 8.18   4096: 9.42 / 8.47   8192: 10.5 / 10.0   (tape: the 8-env shape stays)
 //   36 beams, a launch per step    1024: 10.3 / 9.3    2048: 11.0 / 9.7    4096: 12.1 / 10.1   8192: 13.6 / 11.8   16384: 25.0 / 21.3
 //   house map, tape form           8192: 24.6 (8 envs on four waves) / 23.6 -- the last user of a four-wave shape, which is gone
+// With the 128-VGPR bound on the 16-env instantiations that need it (min_waves_per_simd), the rule before / 16 envs: 36 beams, tape
+// 8192: 9.95 / 8.16   16384: 19.7 / 16.0; house map, a launch per step 8192: 32.7 / 25.8; per-env maps, tape 8192: 7.58 / 6.89;
+// stage_1, a launch per step 1024: 7.17 / 6.77   4096: 7.59 / 7.23   8192: 7.96 / 8.00.
 static int pick_epb(int n_envs, int n_beams, bool tape, bool boxes, bool per_env) {
     if (g_epb >= 8) return g_epb;
-    if (n_beams > 16) return tape ? (n_envs <= 4096 ? 8 : 32) : (n_envs <= 16384 ? 16 : 32);
-    if (boxes && n_envs <= 4096) return 8;
-    if (boxes && tape && n_envs <= 8192) return 16;
-    if (per_env && tape && n_envs <= 4096) return 8;
+    if (n_beams > 16) return (tape && n_envs <= 4096) ? 8 : (n_envs <= 16384 ? 16 : 32);
+    if (boxes && n_envs <= 8192) return n_envs <= 4096 ? 8 : 16;
+    if (per_env && tape && n_envs <= 8192) return n_envs <= 4096 ? 8 : 16;
     if (per_env && !tape && n_envs <= 8192) return 16;
     if (n_envs >= 16384) return 64;
-    if (tape && !boxes && !per_env && n_envs <= 4096) return 16;
+    if (!boxes && !per_env && n_envs <= 4096) return 16;
     return 32;
 }
 
