@@ -1,16 +1,22 @@
 /*
- * navppo.h -- C ABI of the fused PPO loss + gradient kernel for the 16-64-64 heads (libnavsim.so).
+ * navppo.h -- C ABI of the fused PPO loss + gradient kernel for the D-64-64 heads (libnavsim.so).
  *
  * Replaces one pass of the reference's update loop body -- PPO.evaluate() (project_ppo/src/ppo.py:708-737),
  * the ratio / clipped-surrogate / MSE losses (ppo.py:316-343) and both backward() calls (ppo.py:349,386) --
- * for the "mlp64x2" policy (actor: Linear(16,64)-ReLU-Linear(64,64)-ReLU-{sigmoid(Linear(64,1)), tanh(Linear(64,1))},
+ * for the "mlp64x2" policy (actor: Linear(D,64)-ReLU-Linear(64,64)-ReLU-{sigmoid(Linear(64,1)), tanh(Linear(64,1))},
  * critic: ...-Linear(64,1); net_actor.py:147-189, graph_code/ppo_for_beginners/network.py:11-50).
  * The optimiser step (Adam, ppo.py:381,392) and the gradient all-reduce stay with the caller.
  *
+ * Observation rows (every `obs_dev` below): `obs_dim` = D = n_beams + 6 columns -- 16 (10 beams: main.py:18, BASELINE
+ * configs[0..2] and [4]) or 42 (36 beams: configs[3]) -- of float32 (`obs_f16` = 0) or float16 (`obs_f16` = 1, configs[4]'s
+ * "fp16 obs buffers", navsim_cfg.obs_f16), row-major and dense.  Half rows are widened to float32 as they are loaded; all
+ * arithmetic behind the load is float32 either way.
+ *
  * All pointers are DEVICE pointers owned by the caller; calls are asynchronous on `stream` (hipStream_t as void*);
- * return 0 or a negative code, message in navppo_last_error().  float32 throughout (f32-input MFMA: exact f32 fma
- * chains); no CPU fallback.  Alignment: params_dev / actor_params_dev and obs_dev 16 bytes, act_dev 8 bytes (rows are
- * read as dwordx4 / dwordx2; torch allocations are 256-byte aligned), checked at the call.
+ * return 0 or a negative code, message in navppo_last_error().  float32 arithmetic throughout (f32-input MFMA: exact f32 fma
+ * chains); no CPU fallback.  Alignment: params_dev / actor_params_dev 16 bytes, act_dev 8 bytes, obs_dev 16 bytes for
+ * 16 columns, 8 bytes for 42 float32 columns, 4 bytes for 42 float16 columns (torch allocations are 256-byte aligned),
+ * checked at the call.
  */
 #ifndef NAVPPO_H
 #define NAVPPO_H
@@ -22,27 +28,30 @@
 extern "C" {
 #endif
 
-#define NAVPPO_MLP64_ACTOR_PARAMS 5378  /* 16*64+64 + 64*64+64 + 64+1 + 64+1 */
-#define NAVPPO_MLP64_CRITIC_PARAMS 5313 /* 16*64+64 + 64*64+64 + 64+1 */
+#define NAVPPO_MLP64_ACTOR_PARAMS_D(d) ((d) * 64 + 64 + 64 * 64 + 64 + 64 + 1 + 64 + 1)  /* D = 16: 5378, D = 42: 7042 */
+#define NAVPPO_MLP64_CRITIC_PARAMS_D(d) ((d) * 64 + 64 + 64 * 64 + 64 + 64 + 1)          /* D = 16: 5313, D = 42: 6977 */
+#define NAVPPO_MLP64_ACTOR_PARAMS NAVPPO_MLP64_ACTOR_PARAMS_D(16)
+#define NAVPPO_MLP64_CRITIC_PARAMS NAVPPO_MLP64_CRITIC_PARAMS_D(16)
 #define NAVPPO_MLP64_MAX_BLOCKS 512     /* rows of the workspace (the kernel launches one persistent workgroup per CU) */
 
 const char* navppo_last_error(void);
 
-/* bytes of scratch `workspace_dev` must provide (per-workgroup partial gradients) */
-size_t navppo_mlp64_workspace_bytes(void);
+/* bytes of scratch `workspace_dev` must provide (per-workgroup partial gradients) for rows of obs_dim columns; 0 = bad obs_dim */
+size_t navppo_mlp64_workspace_bytes(int32_t obs_dim);
 
 /*
- *   params_dev   [5378 + 5313] f32   actor then critic, each in nn.Module.named_parameters() order:
- *                                    layer1.weight[64,16], layer1.bias[64], layer2.weight[64,64], layer2.bias[64],
+ *   params_dev   [PA + PC] f32       actor then critic (PA = NAVPPO_MLP64_ACTOR_PARAMS_D(D), PC = ..._CRITIC_PARAMS_D(D); D = 16:
+ *                                    5378 + 5313), each in nn.Module.named_parameters() order:
+ *                                    layer1.weight[64,D], layer1.bias[64], layer2.weight[64,64], layer2.bias[64],
  *                                    layer3.weight[1,64], layer3.bias[1] (, layer4.weight[1,64], layer4.bias[1])
- *   obs_dev      [n,16]  batch_obs        act_dev [n,2] batch_acts (the clamped actions, ppo.py:546)
+ *   obs_dev      [n,D]   batch_obs (f32 | f16, see above)      act_dev [n,2] batch_acts (the clamped actions, ppo.py:546)
  *   logp_old_dev [n]     batch_log_probs  rtg_dev [n]   batch_rtgs      adv_dev [n] normalised advantages A_k (ppo.py:284)
  *   var          diagonal of cov_mat (ppo.py:123-124)   clip   PPO clip (ppo.py:770)
- *   grad_dev     [5378 + 5313] f32  out: d(actor_loss)/d(actor params), d(critic_loss)/d(critic params), losses being
+ *   grad_dev     [PA + PC] f32      out: d(actor_loss)/d(actor params), d(critic_loss)/d(critic params), losses being
  *                                    MEANS over the n samples (ppo.py:342-343) -- overwritten, not accumulated
  *   stats_dev    [8] f32            out: [0] actor_loss [1] approx_kl [2] clip_frac (ppo.py:326,335) [4] critic_loss
  */
-int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const float* act_dev,
+int navppo_mlp64_loss_grad(const float* params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16, const float* act_dev,
                            const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples,
                            float var, float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
 
@@ -51,9 +60,10 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
  * grad_dev and its statistics only.  The multi-GPU epoch launches the actor's pass, starts the all-reduce of the actor's
  * gradient slice, and runs the critic's pass while that all-reduce is in flight (same arguments as navppo_mlp64_loss_grad).
  */
-int navppo_mlp64_loss_grad_net(int32_t net, const float* params_dev, const float* obs_dev, const float* act_dev,
-                               const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var,
-                               float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
+int navppo_mlp64_loss_grad_net(int32_t net, const float* params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16,
+                               const float* act_dev, const float* logp_old_dev, const float* rtg_dev, const float* adv_dev,
+                               int64_t n_samples, float var, float clip, float* grad_dev, float* stats_dev, void* workspace_dev,
+                               void* stream);
 
 /*
  * torch.optim.Adam's step (defaults: no weight decay, no amsgrad) on a flat buffer with the gradient scaled first: the
@@ -73,32 +83,33 @@ int navppo_episode_sums(const uint8_t* ended_dev, const uint8_t* arrive_dev, con
                         const float* ep_return_dev, int64_t n, double* sums_dev, void* workspace_dev, void* stream);
 
 /* V = critic(obs).squeeze() (ppo.py:275, :724) for n rows: the forward half of the critic's fused pass.  value_dev [n] f32. */
-int navppo_mlp64_value(const float* critic_params_dev, const float* obs_dev, int64_t n_samples, float* value_dev, void* stream);
+int navppo_mlp64_value(const float* critic_params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16, int64_t n_samples,
+                       float* value_dev, void* stream);
 
 /*
  * One whole update epoch of ppo.py:305-392 on one GPU: navppo_mlp64_loss_grad followed by the two Adam steps of
  * ppo.py:381,392 (torch.optim.Adam defaults: no weight decay, no amsgrad) applied in place by the kernel that sums the
- * workgroups' partial gradients.  step = 1, 2, ... (Adam's bias correction); adam_m_dev / adam_v_dev [5378 + 5313] f32 are
+ * workgroups' partial gradients.  step = 1, 2, ... (Adam's bias correction); adam_m_dev / adam_v_dev [PA + PC] f32 are
  * the optimiser's moments (zero before the first step).  grad_dev and stats_dev are filled as by navppo_mlp64_loss_grad.
  * Multi-GPU runs use navppo_mlp64_loss_grad + an all-reduce + their own optimiser step instead.
  */
-int navppo_mlp64_update_epoch(float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
-                              const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
-                              float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
-                              float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
+int navppo_mlp64_update_epoch(float* params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16, const float* act_dev,
+                              const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var,
+                              float clip, float lr, float beta1, float beta2, float eps, int32_t step, float* adam_m_dev,
+                              float* adam_v_dev, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
 
 /*
  * PPO.get_action() (ppo.py:673-706) for all envs of a shard in one launch: mean = actor(obs) (net_actor forward),
  * sample MVN(mean, var*I), clamp a0 to [0,1] and a1 to [-1,1] (ppo.py:700-703), log-prob of the CLAMPED action (:704).
- *   actor_params_dev [5378]   obs_dev [n,16]   act_dev [n,2] out   logp_dev [n] out   mean_dev [n,2] out, nullable
+ *   actor_params_dev [PA]   obs_dev [n,D] (f32 | f16)   act_dev [n,2] out   logp_dev [n] out   mean_dev [n,2] out, nullable
  *   noise_dev [n,2] standard normal draws, nullable: NULL = Philox4x32-10 keyed by (seed, env_id_base + i, step) +
  *   Box-Muller inside the kernel (the reference uses torch's global generator, unseeded by default: ppo.py:805-811);
  *   step = *step_base_dev (nullable = 0) + step_offset.  var_dev and step_base_dev are DEVICE scalars so that a
  *   captured hipGraph of T launches sees the current variance and a fresh noise stream on every replay.
  * The exploration-covariance decay of ppo.py:694-695 is the caller's (it changes `var` between launches).
  */
-int navppo_mlp64_act(const float* actor_params_dev, const float* obs_dev, const float* noise_dev, int64_t n_envs,
-                     const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
+int navppo_mlp64_act(const float* actor_params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16, const float* noise_dev,
+                     int64_t n_envs, const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
                      uint32_t step_offset, float* act_dev, float* logp_dev, float* mean_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NAVSIM_ABI_VERSION 4
+#define NAVSIM_ABI_VERSION 5
 
 #define NAVSIM_OK 0
 #define NAVSIM_E_ARG (-1)   /* bad argument / unsupported configuration */
@@ -74,9 +74,36 @@ const char* navsim_last_error(void);
 /* Fills *cfg with the reference defaults (N=1, B=10, train threshold, stage_1 spawn and goal box). */
 void navsim_default_cfg(navsim_cfg* cfg);
 
-/* Env.__init__  (environment_new.py:27-47).  Allocates per-env state in HBM on the current device. */
+/* Env.__init__  (environment_new.py:27-47).  Allocates per-env state in HBM on the current device.  Reads nothing from the
+ * process environment: everything a handle does follows from cfg, its map and navsim_set_shape. */
 int navsim_create(const navsim_cfg* cfg, navsim_t** out);
 void navsim_destroy(navsim_t* h);
+
+/*
+ * Kernel-shape overrides of ONE handle (tests, A/B timing; no reference counterpart -- results never depend on them, every
+ * shape writes the same rows).  envs_per_workgroup: 0 = the built-in rule (by shard size, beam count, map kind and entry
+ * point), or 4 (navsim_rollout_mlp64 only) | 8 | 16 | 32 | 64.  pair_cast: -1 = the rule, 0 = 64-segment passes for every
+ * map, 1 = 128-segment passes where the rule allows them.  Takes effect from the next launch.
+ */
+int navsim_set_shape(navsim_t* h, int32_t envs_per_workgroup, int32_t pair_cast);
+
+/*
+ * What the handle is and which kernel instantiation each entry point would launch right now (a profile can then name the
+ * kernel it timed).  `*_epb` = envs per workgroup, `*_waves` = waves per workgroup, `*_cast`: 0 = 64-segment passes,
+ * 1 = 128-segment passes, 2 = 128-segment passes with non-temporal loads, 3 = tile bounding boxes.
+ * rollout_kind: 0 = navsim_rollout_mlp64 unavailable for this handle, 1 = rollout_kernel (EPB envs on 8 waves),
+ * 2 = rollout_big_kernel (64 envs on 16 waves).
+ */
+typedef struct navsim_info {
+    int32_t abi_version, n_envs, n_beams, obs_f16;
+    int32_t n_segments, per_env_map, tile_boxes, has_map;
+    int32_t forced_epb, forced_pair_cast;
+    int32_t step_epb, step_waves, step_cast;       /* navsim_step */
+    int32_t seq_epb, seq_waves, seq_cast;          /* navsim_step_seq */
+    int32_t rollout_kind, rollout_epb, rollout_waves, rollout_cast;   /* navsim_rollout_mlp64 */
+    int32_t reserved[12];
+} navsim_info;
+int navsim_get_info(navsim_t* h, navsim_info* out);
 
 /*
  * The static world the reference gets from Gazebo (worlds/train_world_new.world:85-416):
@@ -198,23 +225,25 @@ int navsim_gae_scan(const float* rew_dev, const uint8_t* ended_dev, const float*
                     int32_t N, double gamma, double lam, float* adv_dev, float* ret_dev, void* stream);
 
 /*
- * The hot loop of PPO.rollout (project_ppo/src/ppo.py:505-594) for the 16-64-64 policy, all n_steps steps in ONE launch:
+ * The hot loop of PPO.rollout (project_ppo/src/ppo.py:505-594) for the (B + 6)-64-64 policy, all n_steps steps in ONE launch:
  * per step PPO.get_action (ppo.py:673-706; what navppo_mlp64_act computes, include/navppo.h) followed by what navsim_step
  * computes, for every env, with the rows of step t written at offset t * N of each [n_steps, N, .] buffer.  A workgroup
  * keeps its envs for the whole rollout, so there is no kernel boundary and no observation round trip between steps; the
  * results are bit-identical to n_steps pairs of navppo_mlp64_act / navsim_step calls with the same seeds.
- *   actor_params_dev [5378] f32  the actor in the layout of navppo.h
- *   obs_buf_dev  [n_steps + 1, N, 16] f32   row 0 in: the observations the rollout starts from (navsim_reset); rows 1.. out
+ *   actor_params_dev [NAVPPO_MLP64_ACTOR_PARAMS_D(B + 6)] f32  the actor in the layout of navppo.h (10 beams: 5378, 36: 7042)
+ *   obs_buf_dev  [n_steps + 1, N, B + 6] f32 (f16 if cfg.obs_f16)   row 0 in: the observations the rollout starts from
+ *                (navsim_reset); rows 1.. out.  With f16 buffers the policy reads every row as a reader of the buffer would:
+ *                rounded to half (so the rows still equal the per-step path's bit for bit).
  *   act_buf_dev  [n_steps, N, 2]   logp_buf_dev [n_steps, N]   reward_dev [n_steps, N]   done / arrive / ended [n_steps, N] u8
  *   ep_return_dev / ep_length_dev / ep_path_dev  [n_steps, N], nullable, written where ended (as in navsim_step)
  *   var_dev  device scalar: exploration variance (ppo.py:123-124)
  *   act_seed, step_base_dev (device scalar, nullable = 0): action noise = Philox(act_seed, env id, *step_base_dev + t)
- * Needs n_beams == 10 and float32 observations.  Two workgroup shapes, same rows bit for bit: 16 envs on 8 waves (a latency chain per
- * workgroup, one round of workgroups up to 4096 envs; no tile boxes in the cast) and, beyond 4096 envs per GPU, 64 envs on 16 waves
- * with the cast variants of navsim_step (tile boxes of shared 65..4096-segment maps, 128-segment passes of per-env maps): the
- * closed-loop form of navsim_step_seq (NAVSIM_EPB = 4 | 8 | 16 | 64 forces a shape).
+ * Workgroup shapes, same rows bit for bit: 16 envs on 8 waves (a latency chain per workgroup, one round of workgroups up to
+ * 4096 envs; no tile boxes in the cast; the only shape with 36 beams) and, with 10 beams beyond 4096 envs per GPU, 64 envs on
+ * 16 waves with the cast variants of navsim_step (tile boxes of shared 65..4096-segment maps, 128-segment passes of per-env
+ * maps): the closed-loop form of navsim_step_seq (navsim_set_shape: 4 | 8 | 16 | 64 forces a shape; navsim_get_info reports it).
  */
-int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_buf_dev, float* act_buf_dev,
+int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, void* obs_buf_dev, float* act_buf_dev,
                          float* logp_buf_dev, float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,
                          float* ep_return_dev, int32_t* ep_length_dev, float* ep_path_dev, const float* var_dev,
                          uint64_t act_seed, const uint32_t* step_base_dev, int32_t n_steps, void* stream);

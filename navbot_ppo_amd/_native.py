@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NAVSIM_LIB: another build of the same library (tools/build_variant.py A/B timing); never a different implementation
 LIB_PATH = os.environ.get("NAVSIM_LIB") or os.path.join(_HERE, "libnavsim.so")
 
-NAVSIM_ABI_VERSION = 4
+NAVSIM_ABI_VERSION = 5
 
 
 class NavsimError(RuntimeError):
@@ -35,6 +35,14 @@ class NavsimCfg(C.Structure):
     ]
 
 
+class NavsimInfo(C.Structure):
+    """navsim_info (include/navsim.h): what the handle is and which kernel instantiation each entry point launches."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "n_envs", "n_beams", "obs_f16", "n_segments", "per_env_map", "tile_boxes", "has_map",
+        "forced_epb", "forced_pair_cast", "step_epb", "step_waves", "step_cast", "seq_epb", "seq_waves", "seq_cast",
+        "rollout_kind", "rollout_epb", "rollout_waves", "rollout_cast")] + [("reserved", C.c_int32 * 12)]
+
+
 # every symbol include/navsim.h declares: (name, restype, argtypes)
 _vp, _i32, _d = C.c_void_p, C.c_int32, C.c_double
 SYMBOLS = [
@@ -43,6 +51,8 @@ SYMBOLS = [
     ("navsim_default_cfg", None, [C.POINTER(NavsimCfg)]),
     ("navsim_create", C.c_int, [C.POINTER(NavsimCfg), C.POINTER(_vp)]),
     ("navsim_destroy", None, [_vp]),
+    ("navsim_set_shape", C.c_int, [_vp, _i32, _i32]),
+    ("navsim_get_info", C.c_int, [_vp, C.POINTER(NavsimInfo)]),
     ("navsim_set_map", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     ("navsim_set_goal_rects", C.c_int, [_vp, _i32, _vp, _i32]),
     ("navsim_set_spawn_sampler", C.c_int, [_vp, _vp, _i32, _vp, _i32, _d, _d, _vp]),
@@ -58,14 +68,14 @@ SYMBOLS = [
     ("navsim_step_seq", C.c_int, [_vp, _vp, _i32] + [_vp] * 9),
     # include/navppo.h
     ("navppo_last_error", C.c_char_p, []),
-    ("navppo_mlp64_workspace_bytes", C.c_size_t, []),
-    ("navppo_mlp64_loss_grad", C.c_int, [_vp] * 6 + [C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
-    ("navppo_mlp64_loss_grad_net", C.c_int, [_i32] + [_vp] * 6 + [C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
+    ("navppo_mlp64_workspace_bytes", C.c_size_t, [_i32]),
+    ("navppo_mlp64_loss_grad", C.c_int, [_vp, _vp, _i32, _i32] + [_vp] * 4 + [C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
+    ("navppo_mlp64_loss_grad_net", C.c_int, [_i32, _vp, _vp, _i32, _i32] + [_vp] * 4 + [C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     ("navppo_adam_step", C.c_int, [_vp, _vp, _vp, _vp, C.c_int64] + [C.c_float] * 5 + [_i32, _vp]),
-    ("navppo_mlp64_value", C.c_int, [_vp, _vp, C.c_int64, _vp, _vp]),
+    ("navppo_mlp64_value", C.c_int, [_vp, _vp, _i32, _i32, C.c_int64, _vp, _vp]),
     ("navppo_episode_sums", C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
-    ("navppo_mlp64_update_epoch", C.c_int, [_vp] * 6 + [C.c_int64] + [C.c_float] * 6 + [_i32] + [_vp] * 6),
-    ("navppo_mlp64_act", C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, _vp, _vp, _vp, _vp]),
+    ("navppo_mlp64_update_epoch", C.c_int, [_vp, _vp, _i32, _i32] + [_vp] * 4 + [C.c_int64] + [C.c_float] * 6 + [_i32] + [_vp] * 6),
+    ("navppo_mlp64_act", C.c_int, [_vp, _vp, _i32, _i32, _vp, C.c_int64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, _vp, _vp, _vp, _vp]),
     ("navppo_resmlp512_workspace_bytes", C.c_size_t, [C.c_int64]),
     ("navppo_resmlp512_loss_grad", C.c_int, [_vp] * 6 + [C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     ("navppo_resmlp512_update_epoch", C.c_int, [_vp] * 6 + [C.c_int64] + [C.c_float] * 6 + [_i32] + [_vp] * 6),

@@ -466,7 +466,7 @@ struct StepIO {
 };
 // Hook: called by EVERY wave right behind barrier B2 (the observation rows are complete but for a reset, which the rules lanes of
 // wave 0 work out next): the persistent rollout kernels run the policy of the NEXT step there, on waves that would otherwise
-// wait for the rules, reading the rows through next_obs4 below.  NoHook: nothing (step_kernel, steps_kernel).
+// wait for the rules, reading the rows through next_obs_n below.  NoHook: nothing (step_kernel, steps_kernel).
 struct NoHook {
     __device__ __forceinline__ void operator()(int, int) const {}
 };
@@ -1315,19 +1315,19 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     }
 }
 
-// Entries 4 kk .. 4 kk + 3 of the observation env `e` (local) will hold when this step is over, readable from barrier B2 on --
-// i.e. BEFORE the rules lane of part 3 has run: the row in sm.obs as it stands, unless the step ends the episode and auto_reset
-// replaces it by the reset observation (ppo.py:582-593).  Whether it does follows from three values that are final at barrier B2
-// -- the minimum of the scan (collision, environment_new.py:200), the goal distance (arrival, :204), the step count (time-out,
-// ppo.py:552) -- and the reset observation is the record the spec lanes staged in part 2.  The same expressions as part 3 on the
-// same operands, so the policy that reads its input through here sees exactly the row part 3 leaves in sm.obs.
-template <int NB, int EPB, int NW, bool SENS, class PRef>
-__device__ __forceinline__ float4 next_obs4(PRef P, const StepSmem<NB, EPB, NW>& sm, const int e, const int kk, const float sigma,
-                                            const int below_min) {
-    constexpr int DP = NB + 7;
-    static_assert(NB % 2 == 0 && (NB + 6) % 4 == 0, "rows of 4-entry groups");
-    const float* row = sm.obs + e * DP + 4 * kk;
-    float4 x = make_float4(row[0], row[1], row[2], row[3]);
+// Entries f0 .. f0 + KS - 1 of the observation env `e` (local) will hold when this step is over (entries past the row: 0), readable
+// from barrier B2 on -- i.e. BEFORE the rules lane of part 3 has run: the row in sm.obs as it stands, unless the step ends the
+// episode and auto_reset replaces it by the reset observation (ppo.py:582-593).  Whether it does follows from three values that are
+// final at barrier B2 -- the minimum of the scan (collision, environment_new.py:200), the goal distance (arrival, :204), the step
+// count (time-out, ppo.py:552) -- and the reset observation is the record the spec lanes staged in part 2.  The same expressions as
+// part 3 on the same operands, so the policy that reads its input through here sees exactly the row part 3 leaves in sm.obs.
+template <int NB, int EPB, int NW, bool SENS, int KS, class PRef>
+__device__ __forceinline__ void next_obs_n(PRef P, const StepSmem<NB, EPB, NW>& sm, const int e, const int f0, const float sigma,
+                                           const int below_min, float (&x)[KS]) {
+    constexpr int D = NB + 6, DP = NB + 7;
+    const float* row = sm.obs + e * DP;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) x[j] = (f0 + j < D) ? row[min(f0 + j, D - 1)] : 0.f;
     const float mn = (SENS && sm.neg[e]) ? -INFINITY : __uint_as_float(sm.mn_bits[e]);
     const bool d = (0.2 > (double)mn) && ((double)mn > 0);                                        // environment_new.py:200
     const bool a = sm.sv_d[6][e] <= P.thr;                                                       // :204
@@ -1336,29 +1336,28 @@ __device__ __forceinline__ float4 next_obs4(PRef P, const StepSmem<NB, EPB, NW>&
     if ((d || a || timeout) && P.auto_reset) {
         const int c = (a && P.respawn) ? 1 : 0;
         const float4 tl = sm.sp_tail[c][e];
-        float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = 4 * kk + j;
+        for (int j = 0; j < KS; ++j) {
+            const int idx = f0 + j;
             float val;
             if (idx < NB) {
-                val = sm.sp_scan[c][e][idx];
+                val = sm.sp_scan[c][e][min(idx, NB - 1)];
                 if (SENS) {   // write_lidar's entry: the start pose's nearest hit through this step's range noise
-                    float r = sensor_value(val, sigma, (sigma > 0.f) ? sm.noise[idx * EPB + e] : 0.f, below_min);
+                    float r = sensor_value(val, sigma, (sigma > 0.f) ? sm.noise[min(idx, NB - 1) * EPB + e] : 0.f, below_min);
                     if (r == INFINITY) r = 3.5f;
                     val = r / 3.5f;
                 }
             } else if (idx < NB + 2) {
                 val = 0.f;                                                                       // environment_new.py:372-373
-            } else {
+            } else if (idx < D) {
                 const int q = idx - NB - 2;
                 val = q == 0 ? tl.x : q == 1 ? tl.y : q == 2 ? tl.z : tl.w;
+            } else {
+                val = 0.f;
             }
-            v[j] = val;
+            x[j] = val;
         }
-        x = make_float4(v[0], v[1], v[2], v[3]);
     }
-    return x;
 }
 
 // The kernarg segment of step_kernel: the kernel takes this struct as its ONLY by-value parameter, so the segment IS the struct
@@ -1405,7 +1404,7 @@ __global__ __launch_bounds__(64 * NW, min_waves_per_simd(NB, EPB, NW, PAIR, fals
 // device functions, same Philox keys), so the two paths produce the same bits.
 struct RolloutArgs {
     const float* params;      // actor parameters (mlp64 layout)
-    float* obs_buf;           // [T + 1, N, 16]: row 0 = the reset observations (input), rows 1..T written here
+    void* obs_buf;            // [T + 1, N, B + 6] f32 (f16: navsim_cfg.obs_f16): row 0 = the reset observations (input), rows 1..T written here
     float* act_buf;           // [T, N, 2]
     float* logp_buf;          // [T, N]
     float* reward;            // [T, N]
@@ -1419,13 +1418,14 @@ struct RolloutArgs {
     int T;
 };
 
-template <int EPB, bool SENS, int NW>
+template <int NB, int EPB, bool SENS, int NW>
 __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs R) {
-    constexpr int NB = 10, D = NB + 6, DP = D + 1, kThreads = 64 * NW;
-    static_assert(D == mlp64::IN, "the 16-64-64 policy reads 16-wide observations");
+    constexpr int D = NB + 6, DP = D + 1, kThreads = 64 * NW;
+    using PL = mlp64::Layout<D>;   // the (B + 6)-64-64 policy: 16-wide rows with 10 beams, 42-wide with 36
+    constexpr int KS = PL::KS;
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
-    __shared__ __attribute__((aligned(16))) float wts[mlp64::P_ACTOR + 2];   // the actor, staged once for all T steps
+    __shared__ __attribute__((aligned(16))) float wts[PL::P_ACTOR + 2];   // the actor, staged once for all T steps
     __shared__ float2 pol_z[4][16];   // policy phase: per-tile partial sums of the two output units
     __shared__ float2 pol_eps[16];    // ... and the step's action noise
     __shared__ unsigned pol_cnt;      // arrivals of the in-step policy's five waves (the last one finishes)
@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
     const int base = blockIdx.x * EPB;
     const int nloc = min(EPB, P.N - base);
     const size_t N = (size_t)P.N;
-    for (int k = tid; k < mlp64::P_ACTOR; k += kThreads) wts[k] = R.params[k];
+    for (int k = tid; k < PL::P_ACTOR; k += kThreads) wts[k] = R.params[k];
     if (tid < nloc) {   // the envs' state: HBM -> LDS for the whole rollout
         const int e = tid, i = base + e;
         sm.st_d[0][e] = P.x[i]; sm.st_d[1][e] = P.y[i]; sm.st_d[2][e] = P.th[i]; sm.st_d[3][e] = P.gx[i]; sm.st_d[4][e] = P.gy[i];
@@ -1443,7 +1443,10 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
         sm.st_step[e] = (uint32_t)P.ep_step[i];
         sm.st_ctr[e] = P.rng_ctr[i];
     }
-    for (int k = tid; k < nloc * D; k += kThreads) sm.obs[(k / D) * DP + (k % D)] = R.obs_buf[(size_t)base * D + k];
+    const bool half_rows = P.obs_f16 != 0;   // float16 observation buffers: the policy reads what a reader of the buffers would
+    for (int k = tid; k < nloc * D; k += kThreads)
+        sm.obs[(k / D) * DP + (k % D)] = half_rows ? __half2float(reinterpret_cast<const __half*>(R.obs_buf)[(size_t)base * D + k])
+                                                   : reinterpret_cast<const float*>(R.obs_buf)[(size_t)base * D + k];
     for (int k = tid; k < 2 * NB; k += kThreads) sm.beam[k] = P.beam_cs[k];
     for (int k = tid; k < (int)(sizeof(Rects) / 8); k += kThreads)   // the goal rejection rectangles, for all T steps
         reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
@@ -1457,20 +1460,26 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
     const float sigma = SENS ? P.sigma : 0.f;
     const int below_min = SENS ? P.below_min_mode : 0;
     auto tile_part = [&](const int t2, auto in_step) __attribute__((always_inline)) {
-        const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]
+        const int e = lane & 15, kk = lane >> 4;   // lane (env, kk) feeds obs[env][KS kk .. KS kk + KS - 1]
         const bool valid = e < nloc;
-        float4 xq;
+        float xs[KS];
         if constexpr (decltype(in_step)::value) {   // inside a step, behind barrier B2: the rows the step will leave
-            xq = next_obs4<NB, EPB, NW, SENS, const Params&>(P, sm, min(e, nloc - 1), kk, sigma, below_min);
+            next_obs_n<NB, EPB, NW, SENS, KS, const Params&>(P, sm, min(e, nloc - 1), KS * kk, sigma, below_min, xs);
+            if (half_rows) {
+#pragma unroll
+                for (int j = 0; j < KS; ++j) xs[j] = __half2float(__float2half_rn(xs[j]));
+            }
         } else {
-            const float* row = sm.obs + min(e, nloc - 1) * DP + 4 * kk;
-            xq = make_float4(row[0], row[1], row[2], row[3]);
+            mlp64::policy_row<PL>(sm.obs + min(e, nloc - 1) * DP, kk, half_rows, xs);
         }
-        if (!valid) xq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!valid) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) xs[j] = 0.f;
+        }
         mlp64::f32x4 c1[4];
-        mlp64::policy_hidden1(wts, xq, lane, c1);
+        mlp64::policy_hidden1<PL>(wts, xs, lane, c1);
         float pz3, pz4;
-        mlp64::policy_tile2(wts, c1, lane, t2, pz3, pz4);
+        mlp64::policy_tile2<PL>(wts, c1, lane, t2, pz3, pz4);
         if (kk == 0) pol_z[t2][e] = make_float2(pz3, pz4);
     };
     auto draw_noise = [&](const uint32_t step) __attribute__((always_inline)) {
@@ -1484,7 +1493,7 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
         const float pz3[4] = {pol_z[0][e].x, pol_z[1][e].x, pol_z[2][e].x, pol_z[3][e].x};
         const float pz4[4] = {pol_z[0][e].y, pol_z[1][e].y, pol_z[2][e].y, pol_z[3][e].y};
         const float2 eps = pol_eps[e];
-        const mlp64::PolicyOut o = mlp64::policy_finish_pre(wts, pz3, pz4, var, sd, log_var, eps.x, eps.y);
+        const mlp64::PolicyOut o = mlp64::policy_finish_pre<PL>(wts, pz3, pz4, var, sd, log_var, eps.x, eps.y);
         sm.act_l[e] = make_float2(o.a0, o.a1);
         reinterpret_cast<float2*>(R.act_buf)[tn + base + e] = make_float2(o.a0, o.a1);
         R.logp_buf[tn + base + e] = o.logp;
@@ -1498,7 +1507,9 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
     for (int t = 0; t < R.T; ++t) {
         const size_t tn = (size_t)t * N;
         asm volatile("" ::: "memory");   // keeps the weight reads of the policy phase inside the loop (registers are scarce)
-        const StepIO io = {nullptr, nullptr, R.obs_buf + (tn + N) * D, R.reward + tn, R.done + tn, R.arrive + tn, R.ended + tn,
+        void* const obs_row = half_rows ? (void*)(reinterpret_cast<__half*>(R.obs_buf) + (tn + N) * D)
+                                        : (void*)(reinterpret_cast<float*>(R.obs_buf) + (tn + N) * D);
+        const StepIO io = {nullptr, nullptr, obs_row, R.reward + tn, R.done + tn, R.arrive + tn, R.ended + tn,
                            R.ep_return ? R.ep_return + tn : nullptr, R.ep_length ? R.ep_length + tn : nullptr,
                            R.ep_path ? R.ep_path + tn : nullptr};
         // The policy of step t + 1 runs INSIDE step t, behind barrier B2.  Wave 0 works through the rules there (a float64 latency
@@ -1507,7 +1518,7 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
         // so the one that reads 4 sees what the other four wrote) finishes and publishes the action -- all before barrier C,
         // so the next step starts right behind this one.  What the rules still have to decide about the observation tile --
         // whether an env's row is replaced by its reset observation -- the tile waves work out themselves from the values that
-        // are final at B2 (next_obs4), so they read exactly the rows the step leaves: same device functions on the same inputs,
+        // are final at B2 (next_obs_n), so they read exactly the rows the step leaves: same device functions on the same inputs,
         // the buffers keep their bits.  Round 3 ran the phase between the steps with the whole workgroup waiting (5.2 us per
         // step); stamps of this form in profiles/r04_rollout16_phase_stamps.txt.
         const bool more = t + 1 < R.T;
@@ -1619,7 +1630,9 @@ template <int EPB, bool SENS, int NW, bool BOXES = false, int PAIR = 0>
 __global__ __launch_bounds__(64 * NW) void rollout_big_kernel(BigKArgs) {   // the segment IS the struct (see step_kernel)
     constexpr int NB = 10, D = NB + 6, DP = D + 1, kThreads = 64 * NW;
     constexpr int TW = EPB / 16;   // policy tiles = MFMA waves of the policy phase
-    static_assert(D == mlp64::IN, "the 16-64-64 policy reads 16-wide observations");
+    using PL = mlp64::Layout<D>;
+    constexpr int KS = PL::KS;
+    static_assert(D == mlp64::IN, "64-env workgroups: the 10-beam tile (36 beams do not fit the LDS)");
     static_assert(EPB % 16 == 0 && EPB <= 64 && TW < NW, "policy phase: EPB / 16 tile waves + the noise wave");
     __shared__ StepSmem<NB, EPB, NW> sm;
     __shared__ int next_env;
@@ -1645,9 +1658,12 @@ __global__ __launch_bounds__(64 * NW) void rollout_big_kernel(BigKArgs) {   // t
         sm.st_step[e] = (uint32_t)P.ep_step[i];
         sm.st_ctr[e] = P.rng_ctr[i];
     }
+    const bool half_rows = P.obs_f16 != 0;   // float16 observation buffers: the policy reads what a reader of the buffers would
     {
-        const float* const ob = R.obs_buf;
-        for (int k = tid; k < nloc * D; k += kThreads) sm.obs[(k / D) * DP + (k % D)] = ob[(size_t)base * D + k];
+        const void* const ob = R.obs_buf;
+        for (int k = tid; k < nloc * D; k += kThreads)
+            sm.obs[(k / D) * DP + (k % D)] = half_rows ? __half2float(reinterpret_cast<const __half*>(ob)[(size_t)base * D + k])
+                                                       : reinterpret_cast<const float*>(ob)[(size_t)base * D + k];
     }
     for (int k = tid; k < 2 * NB; k += kThreads) sm.beam[k] = P.beam_cs[k];
     for (int k = tid; k < (int)(sizeof(Rects) / 8); k += kThreads)
@@ -1666,22 +1682,29 @@ __global__ __launch_bounds__(64 * NW) void rollout_big_kernel(BigKArgs) {   // t
     auto tile_policy = [&](const int k, const size_t tn, const int eps_row, auto in_step) __attribute__((always_inline)) {
         const int e = 16 * k + (lane & 15), kk = lane >> 4;   // lane (env, kk) feeds obs[env][4 kk .. 4 kk + 3]
         const bool valid = e < nloc;
-        float4 xq;
+        float xs[KS];
         if constexpr (decltype(in_step)::value) {   // inside a step, behind barrier B2: the rows the step will leave
-            xq = next_obs4<NB, EPB, NW, SENS, const Params __attribute__((address_space(4)))&>(P, sm, min(e, nloc - 1), kk, sigma, below_min);
+            next_obs_n<NB, EPB, NW, SENS, KS, const Params __attribute__((address_space(4)))&>(P, sm, min(e, nloc - 1), KS * kk, sigma,
+                                                                                               below_min, xs);
+            if (half_rows) {
+#pragma unroll
+                for (int j = 0; j < KS; ++j) xs[j] = __half2float(__float2half_rn(xs[j]));
+            }
         } else {
-            const float* row = sm.obs + min(e, nloc - 1) * DP + 4 * kk;
-            xq = make_float4(row[0], row[1], row[2], row[3]);
+            mlp64::policy_row<PL>(sm.obs + min(e, nloc - 1) * DP, kk, half_rows, xs);
         }
-        if (!valid) xq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!valid) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) xs[j] = 0.f;
+        }
         const float2 eps = pol_eps[eps_row][min(e, nloc - 1)];   // requested ahead of the MFMA chain, used behind it
         mlp64::f32x4 c1[4];
-        mlp64::policy_hidden1(wts, xq, lane, c1);
+        mlp64::policy_hidden1<PL>(wts, xs, lane, c1);
         float pz3[4], pz4[4];
 #pragma unroll
-        for (int t2 = 0; t2 < 4; ++t2) mlp64::policy_tile2(wts, c1, lane, t2, pz3[t2], pz4[t2]);
+        for (int t2 = 0; t2 < 4; ++t2) mlp64::policy_tile2<PL>(wts, c1, lane, t2, pz3[t2], pz4[t2]);
         if (kk == 0 && valid) {
-            const mlp64::PolicyOut o = mlp64::policy_finish_pre(wts, pz3, pz4, var, sd, log_var, eps.x, eps.y);
+            const mlp64::PolicyOut o = mlp64::policy_finish_pre<PL>(wts, pz3, pz4, var, sd, log_var, eps.x, eps.y);
             sm.act_l[e] = make_float2(o.a0, o.a1);
             reinterpret_cast<float2*>(R.act_buf)[tn + base + e] = make_float2(o.a0, o.a1);
             R.logp_buf[tn + base + e] = o.logp;
@@ -1706,7 +1729,7 @@ __global__ __launch_bounds__(64 * NW) void rollout_big_kernel(BigKArgs) {   // t
         asm volatile("" ::: "memory");   // keeps the weight reads of the policy phase inside the loop
         // The policy of step t + 1 runs INSIDE step t, behind barrier B2, while wave 0 works through the rules (a float64 latency
         // chain) and the other waves would only wait for it at barrier C.  Whether the rules replace an env's observation row by its
-        // reset observation (ppo.py:582-593) the tile waves work out themselves from the values that are final at B2 (next_obs4):
+        // reset observation (ppo.py:582-593) the tile waves work out themselves from the values that are final at B2 (next_obs_n):
         // they read exactly the rows the step leaves -- same device functions on the same inputs, the buffers keep their bits --
         // and the action is in LDS before barrier C, so the next step starts without a policy phase in front of it.  Round 3 ran
         // the phase between the steps, the whole workgroup waiting for it: + 1.6 us per step over the tape kernel.
@@ -1993,10 +2016,11 @@ struct navsim {
     double* goals_dev = nullptr;    // [G][2]
     const float* seg_dev = nullptr;
     bool has_map = false;
+    // kernel-shape overrides of THIS handle (navsim_set_shape; tests and A/B timing): envs per workgroup, 0 = the rule of pick_epb
+    // below; pair_cast false = 64-segment passes for every map
+    int force_epb = 0;
+    bool pair_cast = true;
 };
-
-int g_epb = 0;   // envs per workgroup: 0 = by shard size (below); NAVSIM_EPB = 8 | 16 | 32 | 64 forces one (tuning knob)
-bool g_pair_cast = true;   // NAVSIM_PAIR_CAST=0: 64-segment passes for every map (tuning knob)
 
 // Envs per workgroup.  Bigger workgroups make the float64 lanes of the geometry / rules phases denser (a wave instruction
 // costs the same with 16 or 64 active lanes) and start fewer workgroups, but need N / EPB >= the number of CUs to fill the
@@ -2029,8 +2053,8 @@ bool g_pair_cast = true;   // NAVSIM_PAIR_CAST=0: 64-segment passes for every ma
 // With the 128-VGPR bound on the 16-env instantiations that need it (min_waves_per_simd), the rule before / 16 envs: 36 beams, tape
 // 8192: 9.95 / 8.16   16384: 19.7 / 16.0; house map, a launch per step 8192: 32.7 / 25.8; per-env maps, tape 8192: 7.58 / 6.89;
 // stage_1, a launch per step 1024: 7.17 / 6.77   4096: 7.59 / 7.23   8192: 7.96 / 8.00.
-static int pick_epb(int n_envs, int n_beams, bool tape, bool boxes, bool per_env) {
-    if (g_epb >= 8) return g_epb;
+static int pick_epb(const navsim* h, int n_envs, int n_beams, bool tape, bool boxes, bool per_env) {
+    if (h->force_epb >= 8) return h->force_epb;
     if (n_beams > 16) return (tape && n_envs <= 4096) ? 8 : (n_envs <= 16384 ? 16 : 32);
     if (boxes && n_envs <= 8192) return n_envs <= 4096 ? 8 : 16;
     if (per_env && tape && n_envs <= 8192) return n_envs <= 4096 ? 8 : 16;
@@ -2039,6 +2063,55 @@ static int pick_epb(int n_envs, int n_beams, bool tape, bool boxes, bool per_env
     if (!boxes && !per_env && n_envs <= 4096) return 16;
     return 32;
 }
+
+// The instantiation navsim_step (tape = false) / navsim_step_seq (tape = true) launches for this handle: envs and waves per
+// workgroup and the cast variant -- 0 = 64-segment passes, 1 = 128-segment passes (maps of 65+ segments without tile boxes:
+// per-env maps, shared maps beyond 4096 segments), 2 = the same with non-temporal loads (the stream does not fit the caches,
+// navsim_set_map; exists for the big 10-beam shapes), 3 = tile bounding boxes (shared maps of 65..4096 segments).
+struct ShapePick {
+    int epb, waves, cast;
+};
+static ShapePick pick_shape(const navsim* h, bool tape) {
+    const int NB = h->P.B;
+    const bool boxes = h->P.tile_box != nullptr;
+    const int want = pick_epb(h, h->P.N, NB, tape, boxes, h->P.per_env != 0);
+    ShapePick sp;
+    if (want == 8) sp.epb = 8, sp.waves = 8;                                    // eight waves: one env per wave
+    else if (want == 32 || (want == 64 && NB > 10)) sp.epb = 32, sp.waves = 8;  // float64 geometry / rules lanes twice as dense
+    else if (want == 64) sp.epb = 64, sp.waves = 16;                            // (10 beams: the 36-beam tile does not fit the LDS)
+    else sp.epb = 16, sp.waves = 8;                                             // two envs per wave
+    const bool pair = h->pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
+    const bool nt = (h->P.per_env & (tape ? 2 : 4)) != 0;   // navsim_set_map: the per-env stream does not fit the L2s / the Infinity Cache
+    sp.cast = boxes ? 3 : (pair ? ((nt && NB == 10 && sp.epb >= 32) ? 2 : 1) : 0);
+    return sp;
+}
+
+// KERNEL: step_kernel | steps_kernel; `go(kernel, epb, waves)` launches
+#define NAVSIM_DISPATCH_CAST(KERNEL, EPB_, NW_)                                                            \
+    do {                                                                                                   \
+        if (sp.cast == 3) {                                                                                \
+            if (sens) go(KERNEL<NB, EPB_, true, NW_, true>, EPB_, NW_);                                    \
+            else go(KERNEL<NB, EPB_, false, NW_, true>, EPB_, NW_);                                        \
+        } else if (sp.cast == 2) {                                                                         \
+            constexpr int kNT = (NB == 10 && EPB_ >= 32) ? 2 : 1;   /* the streaming variant exists for the big shapes */ \
+            if (sens) go(KERNEL<NB, EPB_, true, NW_, false, kNT>, EPB_, NW_);                              \
+            else go(KERNEL<NB, EPB_, false, NW_, false, kNT>, EPB_, NW_);                                  \
+        } else if (sp.cast == 1) {                                                                         \
+            if (sens) go(KERNEL<NB, EPB_, true, NW_, false, 1>, EPB_, NW_);                                \
+            else go(KERNEL<NB, EPB_, false, NW_, false, 1>, EPB_, NW_);                                    \
+        } else {                                                                                           \
+            if (sens) go(KERNEL<NB, EPB_, true, NW_, false>, EPB_, NW_);                                   \
+            else go(KERNEL<NB, EPB_, false, NW_, false>, EPB_, NW_);                                       \
+        }                                                                                                  \
+    } while (0)
+#define NAVSIM_DISPATCH_SHAPE(KERNEL)                                              \
+    do {                                                                           \
+        if (sp.epb == 8) NAVSIM_DISPATCH_CAST(KERNEL, 8, 8);                       \
+        else if (sp.epb == 32) NAVSIM_DISPATCH_CAST(KERNEL, 32, 8);                \
+        else if (sp.epb == 64) {                                                   \
+            if constexpr (NB == 10) NAVSIM_DISPATCH_CAST(KERNEL, 64, 16);          \
+        } else NAVSIM_DISPATCH_CAST(KERNEL, 16, 8);                                \
+    } while (0)
 
 template <int NB>
 static void launch_step(const navsim* h, const float* action, const float* past, void* obs, float* reward, uint8_t* done,
@@ -2049,40 +2122,8 @@ static void launch_step(const navsim* h, const float* action, const float* past,
     auto go = [&](auto kernel, int epb, int nw) {
         hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
     };
-    const bool boxes = h->P.tile_box != nullptr;   // shared map with tile bounding boxes (navsim_set_map)
-    const int epb = pick_epb(h->P.N, NB, false, boxes, h->P.per_env != 0);
-    // maps of 65+ segments without tile boxes (per-env maps; shared maps beyond 4096 segments): 128 segments per pass
-    const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
-#define NAVSIM_GO(EPB_, NW_)                                                                         \
-    do {                                                                                             \
-        if (boxes) {                                                                                 \
-            if (sens) go(step_kernel<NB, EPB_, true, NW_, true>, EPB_, NW_);                         \
-            else go(step_kernel<NB, EPB_, false, NW_, true>, EPB_, NW_);                             \
-        } else if (pair) {                                                                           \
-            constexpr int kNT = (NB == 10 && EPB_ >= 32) ? 2 : 1;   /* the streaming variant exists for the big shapes */ \
-            if (nt && kNT == 2) {                                                                    \
-                if (sens) go(step_kernel<NB, EPB_, true, NW_, false, kNT>, EPB_, NW_);               \
-                else go(step_kernel<NB, EPB_, false, NW_, false, kNT>, EPB_, NW_);                   \
-            } else {                                                                                 \
-                if (sens) go(step_kernel<NB, EPB_, true, NW_, false, 1>, EPB_, NW_);                 \
-                else go(step_kernel<NB, EPB_, false, NW_, false, 1>, EPB_, NW_);                     \
-            }                                                                                        \
-        } else {                                                                                     \
-            if (sens) go(step_kernel<NB, EPB_, true, NW_, false>, EPB_, NW_);                        \
-            else go(step_kernel<NB, EPB_, false, NW_, false>, EPB_, NW_);                            \
-        }                                                                                            \
-    } while (0)
-    const bool nt = (h->P.per_env & 4) != 0;   // navsim_set_map: the per-env stream does not fit the L2s
-    if (epb == 8) {   // eight waves: one env per wave
-        NAVSIM_GO(8, 8);
-    } else if (epb == 32 || (epb == 64 && NB > 10)) {   // 8-wave workgroups of 32 envs: float64 geometry / rules lanes twice as dense
-        NAVSIM_GO(32, 8);
-    } else if (epb == 64) {   // 16-wave workgroups of 64 envs (10 beams: the 36-beam tile does not fit the LDS)
-        if constexpr (NB == 10) NAVSIM_GO(64, 16);
-    } else {
-        NAVSIM_GO(16, 8);   // two envs per wave
-    }
-#undef NAVSIM_GO
+    const ShapePick sp = pick_shape(h, false);
+    NAVSIM_DISPATCH_SHAPE(step_kernel);
 }
 
 // navsim_step_seq: the same shapes and cast variants, all steps of the tape in one launch
@@ -2093,41 +2134,38 @@ static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st) {
     auto go = [&](auto kernel, int epb, int nw) {
         hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
     };
-    const bool boxes = h->P.tile_box != nullptr;
-    const int epb = pick_epb(h->P.N, NB, true, boxes, h->P.per_env != 0);   // the shapes and cast variants of launch_step
-    const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
-    const bool nt = (h->P.per_env & 2) != 0;   // navsim_set_map: one step's per-env stream exceeds 1.25 x the Infinity Cache
-#define NAVSIM_GO(EPB_, NW_)                                                                          \
-    do {                                                                                              \
-        if (boxes) {                                                                                  \
-            if (sens) go(steps_kernel<NB, EPB_, true, NW_, true>, EPB_, NW_);                         \
-            else go(steps_kernel<NB, EPB_, false, NW_, true>, EPB_, NW_);                             \
-        } else if (pair) {                                                                            \
-            constexpr int kNT = (NB == 10 && EPB_ >= 32) ? 2 : 1;                                     \
-            if (nt && kNT == 2) {                                                                     \
-                if (sens) go(steps_kernel<NB, EPB_, true, NW_, false, kNT>, EPB_, NW_);               \
-                else go(steps_kernel<NB, EPB_, false, NW_, false, kNT>, EPB_, NW_);                   \
-            } else {                                                                                  \
-                if (sens) go(steps_kernel<NB, EPB_, true, NW_, false, 1>, EPB_, NW_);                 \
-                else go(steps_kernel<NB, EPB_, false, NW_, false, 1>, EPB_, NW_);                     \
-            }                                                                                         \
-        } else {                                                                                      \
-            if (sens) go(steps_kernel<NB, EPB_, true, NW_, false>, EPB_, NW_);                        \
-            else go(steps_kernel<NB, EPB_, false, NW_, false>, EPB_, NW_);                            \
-        }                                                                                             \
-    } while (0)
-    if (epb == 8) {   // eight waves: one env per wave
-        NAVSIM_GO(8, 8);
-    } else if (epb == 32 || (epb == 64 && NB > 10)) {
-        NAVSIM_GO(32, 8);
-    } else if (epb == 64) {
-        if constexpr (NB == 10) NAVSIM_GO(64, 16);
-    } else {
-        NAVSIM_GO(16, 8);   // two envs per wave
-    }
-#undef NAVSIM_GO
+    const ShapePick sp = pick_shape(h, true);
+    NAVSIM_DISPATCH_SHAPE(steps_kernel);
 }
+#undef NAVSIM_DISPATCH_SHAPE
+#undef NAVSIM_DISPATCH_CAST
 
+// navsim_rollout_mlp64's kernel for this handle: kind 0 = unavailable, 1 = rollout_kernel (EPB envs on 8 waves, any beam
+// count), 2 = rollout_big_kernel (64 envs on 16 waves, 10 beams, the cast variants of the step kernel).
+// A 16-env workgroup is ONE latency chain per step whatever its size: measured (tools/time_rollout.py, 512 steps) 4096 / 2048 /
+// 1024 / 512 envs take 2.92 / 2.90 / 2.89 / 2.97 ms with 16 envs per workgroup, 3.05-3.06 ms with 8 and 2.96 ms with 4 wherever the
+// grid still fits one round of 256 CUs (a second round doubles the time: 256 registers x 8 waves fill a CU) -- spreading a small
+// shard over more CUs buys nothing.  Beyond 4096 envs (10 beams): the tape kernel's 64-env workgroup with the policy phase inside
+// every step -- the 16-env shape needs a second round of workgroups there (measured, us per step, 16-env / 64-env shape: 4608 envs
+// 10.6 / 7.3, 8192 10.5 / 7.4, 12288 15.5 / 7.4, 16384 20.5 / 7.6; 4096: 5.3 / 7.5), while a 64-env workgroup costs the same
+// 7.3-7.6 us whether 72 or 256 CUs hold one.  36 beams: the 16-env shape at every size (the 64-env tile does not fit the LDS).
+struct RolloutPick {
+    int kind, epb, waves, cast;
+};
+static RolloutPick pick_rollout(const navsim* h) {
+    RolloutPick rp = {0, 0, 0, 0};
+    if (h->P.B != 10 && h->P.B != 36) return rp;
+    const bool boxes = h->P.tile_box != nullptr;
+    const bool pair = h->pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
+    if (h->P.B == 10 && (h->force_epb == 64 || (h->force_epb == 0 && h->P.N > 16 * 256))) {
+        rp.kind = 2; rp.epb = 64; rp.waves = 16;
+        rp.cast = boxes ? 3 : (pair ? ((h->P.per_env & 2) ? 2 : 1) : 0);   // 2: one step's per-env stream exceeds 1.25 x the Infinity Cache
+        return rp;
+    }
+    rp.kind = 1; rp.waves = 8; rp.cast = 0;
+    rp.epb = (h->P.B == 10 && (h->force_epb == 4 || h->force_epb == 8)) ? h->force_epb : 16;
+    return rp;
+}
 
 static int invalidate_records(navsim* h, hipStream_t st) {
     hipLaunchKernelGGL(invalidate_records_kernel, dim3((h->P.N + 255) / 256), dim3(256), 0, st, h->P.ep_step, h->P.N);
@@ -2254,11 +2292,6 @@ int navsim_create(const navsim_cfg* cfg, navsim_t** out) {
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(NAVSIM_E_HIP, "navsim_create: no HIP device (there is no CPU path)");
 
-    if (const char* e = std::getenv("NAVSIM_EPB")) {
-        const int v = std::atoi(e);
-        if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) g_epb = v;   // 4: the persistent rollout kernel only
-    }
-    if (const char* e = std::getenv("NAVSIM_PAIR_CAST")) g_pair_cast = std::atoi(e) != 0;
     navsim* h = new navsim();
     const int rc = init_handle(h, cfg);
     if (rc != NAVSIM_OK) {
@@ -2282,6 +2315,34 @@ void navsim_destroy(navsim_t* h) {
     (void)hipFree(h->starts_sc_dev);
     (void)hipFree(h->goals_dev);
     delete h;
+}
+
+int navsim_set_shape(navsim_t* h, int32_t envs_per_workgroup, int32_t pair_cast) {
+    if (!h) return fail(NAVSIM_E_ARG, "navsim_set_shape: null handle");
+    const int v = envs_per_workgroup;
+    if (!(v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) || pair_cast < -1 || pair_cast > 1)
+        return fail(NAVSIM_E_ARG, "navsim_set_shape: envs_per_workgroup is 0 | 4 | 8 | 16 | 32 | 64, pair_cast -1 | 0 | 1");
+    h->force_epb = v;
+    h->pair_cast = pair_cast != 0;
+    return NAVSIM_OK;
+}
+
+int navsim_get_info(navsim_t* h, navsim_info* out) {
+    if (!h || !out) return fail(NAVSIM_E_ARG, "navsim_get_info: null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->abi_version = NAVSIM_ABI_VERSION;
+    out->n_envs = h->P.N; out->n_beams = h->P.B; out->obs_f16 = h->P.obs_f16;
+    out->n_segments = h->P.S; out->per_env_map = h->P.per_env & 1; out->tile_boxes = h->P.tile_box != nullptr;
+    out->has_map = h->has_map;
+    out->forced_epb = h->force_epb; out->forced_pair_cast = h->pair_cast ? -1 : 0;
+    if (h->has_map) {
+        const ShapePick a = pick_shape(h, false), b = pick_shape(h, true);
+        out->step_epb = a.epb; out->step_waves = a.waves; out->step_cast = a.cast;
+        out->seq_epb = b.epb; out->seq_waves = b.waves; out->seq_cast = b.cast;
+        const RolloutPick r = pick_rollout(h);
+        out->rollout_kind = r.kind; out->rollout_epb = r.epb; out->rollout_waves = r.waves; out->rollout_cast = r.cast;
+    }
+    return NAVSIM_OK;
 }
 
 int navsim_set_goal_rects(navsim_t* h, int32_t which, const double* rects_host, int32_t n_rects) {
@@ -2456,7 +2517,7 @@ int navsim_step(navsim_t* h, const float* action_dev, const float* past_action_d
     return NAVSIM_OK;
 }
 
-int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_buf_dev, float* act_buf_dev,
+int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, void* obs_buf_dev, float* act_buf_dev,
                          float* logp_buf_dev, float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,
                          float* ep_return_dev, int32_t* ep_length_dev, float* ep_path_dev, const float* var_dev,
                          uint64_t act_seed, const uint32_t* step_base_dev, int32_t n_steps, void* stream) {
@@ -2464,8 +2525,8 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
         !ended_dev || !var_dev || n_steps < 0)
         return fail(NAVSIM_E_ARG, "navsim_rollout_mlp64: bad argument");
     if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_rollout_mlp64: call navsim_set_map first");
-    if (h->P.B != 10 || h->P.obs_f16)
-        return fail(NAVSIM_E_ARG, "navsim_rollout_mlp64: the 16-64-64 policy needs 10 beams and float32 observations");
+    const RolloutPick rp = pick_rollout(h);
+    if (rp.kind == 0) return fail(NAVSIM_E_ARG, "navsim_rollout_mlp64: the (B + 6)-64-64 policy needs 10 or 36 beams");
     if (((uintptr_t)actor_params_dev & 15) || ((uintptr_t)act_buf_dev & 7))
         return fail(NAVSIM_E_ARG, "navsim_rollout_mlp64: params must be 16-byte and act 8-byte aligned");
     if (n_steps == 0) return NAVSIM_OK;
@@ -2475,22 +2536,13 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
     R.ep_length = ep_length_dev; R.ep_path = ep_path_dev; R.var_ptr = var_dev; R.step_base = step_base_dev;
     R.seed = act_seed; R.T = n_steps;
     const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
-    // Envs per workgroup (NAVSIM_EPB = 4 | 8 | 16 forces one).  A workgroup is ONE latency chain per step whatever its size:
-    // measured (tools/time_rollout.py, 512 steps) 4096 / 2048 / 1024 / 512 envs take 2.92 / 2.90 / 2.89 / 2.97 ms with 16 envs
-    // per workgroup, 3.05-3.06 ms with 8 and 2.96 ms with 4 wherever the grid still fits one round of 256 CUs (a second
-    // round doubles the time: 256 registers x 8 waves fill a CU) -- spreading a small shard over more CUs buys nothing.
     hipStream_t st = (hipStream_t)stream;
-    // Shards beyond 4096 envs (NAVSIM_EPB=64 forces it): the tape kernel's 64-env workgroup with the policy phase in front of every
-    // step (rollout_big_kernel), with the cast variants of launch_step (tile boxes, 128-segment passes).  The 16-env shape is one
-    // latency chain per workgroup and one workgroup per CU: from 4097 envs it needs a second round of workgroups (measured, us per
-    // step, 16-env / 64-env shape: 4608 envs 10.6 / 7.3, 8192 10.5 / 7.4, 12288 15.5 / 7.4, 16384 20.5 / 7.6; 4096: 5.3 / 7.5), while
-    // a 64-env workgroup costs the same 7.3-7.6 us whether 72 or 256 CUs hold one.
-    const bool boxes = h->P.tile_box != nullptr;
-    const bool pair = g_pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
-    if (g_epb == 64 || (g_epb == 0 && h->P.N > 16 * 256)) {
+    if (rp.kind == 2) {   // 64 envs on 16 waves, the cast variants of launch_step (see pick_rollout)
+        const size_t D = (size_t)h->P.B + 6;
         StepIO io;
         io.action = nullptr; io.past_override = nullptr;
-        io.obs_out = obs_buf_dev + (size_t)h->P.N * 16;
+        io.obs_out = h->P.obs_f16 ? (void*)(reinterpret_cast<__half*>(obs_buf_dev) + (size_t)h->P.N * D)
+                                  : (void*)(reinterpret_cast<float*>(obs_buf_dev) + (size_t)h->P.N * D);
         io.reward = reward_dev; io.done = done_dev; io.arrive = arrive_dev; io.ended = ended_dev;
         io.ep_return = ep_return_dev; io.ep_length = ep_length_dev; io.ep_path_out = ep_path_dev;
         const dim3 grid((h->P.N + 63) / 64), block(64 * 16);
@@ -2500,27 +2552,29 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, float* obs_
         if (sens) hipLaunchKernelGGL((rollout_big_kernel<64, true, 16, BOXES_, PAIR_>), grid, block, 0, st, ka);   \
         else hipLaunchKernelGGL((rollout_big_kernel<64, false, 16, BOXES_, PAIR_>), grid, block, 0, st, ka);       \
     } while (0)
-        if (boxes) NAVSIM_BIG(true, 0);
-        else if (pair && (h->P.per_env & 2)) NAVSIM_BIG(false, 2);   // one step's per-env stream exceeds 1.25 x the Infinity Cache
-        else if (pair) NAVSIM_BIG(false, 1);
+        if (rp.cast == 3) NAVSIM_BIG(true, 0);
+        else if (rp.cast == 2) NAVSIM_BIG(false, 2);
+        else if (rp.cast == 1) NAVSIM_BIG(false, 1);
         else NAVSIM_BIG(false, 0);
 #undef NAVSIM_BIG
         HIP_TRY(hipGetLastError());
         return NAVSIM_OK;
     }
-    const int epb = (g_epb == 4 || g_epb == 8 || g_epb == 16) ? g_epb : 16;
     // 8 waves per workgroup: more ray waves shorten the cast
     constexpr int kRollWaves = 8;
-    const dim3 grid((h->P.N + epb - 1) / epb), block(64 * kRollWaves);
-    if (epb == 4) {
-        if (sens) hipLaunchKernelGGL((rollout_kernel<4, true, kRollWaves>), grid, block, 0, st, h->P, R);
-        else hipLaunchKernelGGL((rollout_kernel<4, false, kRollWaves>), grid, block, 0, st, h->P, R);
-    } else if (epb == 8) {
-        if (sens) hipLaunchKernelGGL((rollout_kernel<8, true, kRollWaves>), grid, block, 0, st, h->P, R);
-        else hipLaunchKernelGGL((rollout_kernel<8, false, kRollWaves>), grid, block, 0, st, h->P, R);
+    const dim3 grid((h->P.N + rp.epb - 1) / rp.epb), block(64 * kRollWaves);
+    if (h->P.B == 36) {
+        if (sens) hipLaunchKernelGGL((rollout_kernel<36, 16, true, kRollWaves>), grid, block, 0, st, h->P, R);
+        else hipLaunchKernelGGL((rollout_kernel<36, 16, false, kRollWaves>), grid, block, 0, st, h->P, R);
+    } else if (rp.epb == 4) {
+        if (sens) hipLaunchKernelGGL((rollout_kernel<10, 4, true, kRollWaves>), grid, block, 0, st, h->P, R);
+        else hipLaunchKernelGGL((rollout_kernel<10, 4, false, kRollWaves>), grid, block, 0, st, h->P, R);
+    } else if (rp.epb == 8) {
+        if (sens) hipLaunchKernelGGL((rollout_kernel<10, 8, true, kRollWaves>), grid, block, 0, st, h->P, R);
+        else hipLaunchKernelGGL((rollout_kernel<10, 8, false, kRollWaves>), grid, block, 0, st, h->P, R);
     } else {
-        if (sens) hipLaunchKernelGGL((rollout_kernel<16, true, kRollWaves>), grid, block, 0, st, h->P, R);
-        else hipLaunchKernelGGL((rollout_kernel<16, false, kRollWaves>), grid, block, 0, st, h->P, R);
+        if (sens) hipLaunchKernelGGL((rollout_kernel<10, 16, true, kRollWaves>), grid, block, 0, st, h->P, R);
+        else hipLaunchKernelGGL((rollout_kernel<10, 16, false, kRollWaves>), grid, block, 0, st, h->P, R);
     }
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;

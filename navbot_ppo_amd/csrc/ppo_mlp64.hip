@@ -28,9 +28,13 @@
 // At the end every workgroup writes its partial gradient (one row of `partial`), and `reduce_adam` sums rows.
 #include <hip/hip_runtime.h>
 
+#include <hip/hip_fp16.h>
+
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <string>
+#include <type_traits>
 
 #include "navppo.h"
 #include "navppo_internal.h"
@@ -40,6 +44,8 @@ namespace {
 
 using namespace mlp64;
 static_assert(P_ACTOR == NAVPPO_MLP64_ACTOR_PARAMS && P_CRITIC == NAVPPO_MLP64_CRITIC_PARAMS, "layout");
+static_assert(Layout<42>::P_ACTOR == NAVPPO_MLP64_ACTOR_PARAMS_D(42) && Layout<42>::P_CRITIC == NAVPPO_MLP64_CRITIC_PARAMS_D(42) &&
+              Layout<16>::P_ACTOR == NAVPPO_MLP64_ACTOR_PARAMS_D(16), "layout");
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -68,7 +74,22 @@ __device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r 
 //   pass through three 32x32 wave-private LDS tiles and come back as k-contiguous ds_read_b128 operands; the same
 //   operand registers give db2 / db1, and one more tile round trip of H2^T gives dW3 / dW4.
 // LDS: W1 5 KB + W2 and W2^T 17 KB each + vectors 1 KB + 8 x 13.75 KB wave tiles = 150 KB -> one workgroup per CU.
-constexpr int LW1 = 20;                   // row strides (floats): 16-byte aligned rows, conflict-free ds_read_b128
+//
+// Observation width (template IN) and row type (F16): IN = 16 is BASELINE configs[1] / [2] / [4] (10 beams), IN = 42 configs[3]
+// (36 beams: 42-D rows, padded to 48 columns on chip -- three 16-column tiles of dW1, 24 k-steps of F1 per half; W1 takes 13 KB
+// of LDS, 158 KB in all).  F16: the rows are float16 (configs[4], navsim_cfg.obs_f16) and are widened to float32 as they are
+// loaded; everything behind the load is the same float32 arithmetic.  The 16-wide float32 instantiation is the round-2 kernel
+// unchanged (next tile's rows prefetched into registers, X kept in registers for G1); the 42-wide ones load a tile's rows at its
+// start and read X again -- from L2, directly in G1's operand layout -- when G1 needs it: 48 registers of dW1 accumulators
+// leave no room for 2 x 24 registers of rows held across the tile.
+template <int IN>
+struct Pad {
+    static constexpr int INP = (IN == 16) ? 16 : 48;   // columns on chip
+    static constexpr int KH = INP / 2;                 // features per lane half in F1 (32x32x2: k = lane >> 5)
+    static constexpr int NC = INP / 16;                // 16-column tiles of dW1
+    static constexpr int LW1 = INP + 4;                // row stride of W1 in LDS (floats): 16-byte aligned rows, conflict-free ds_read_b128
+    static_assert(IN == 16 || IN == 42, "observation widths of the reference's sensor configurations: 10 or 36 beams + 6");
+};
 constexpr int LW2 = 68;
 constexpr int LT = 36;
 constexpr int TILE_F = 32 * LT;
@@ -77,16 +98,17 @@ constexpr int kWWaves = 8;
 constexpr int kWThreads = 64 * kWWaves;
 constexpr int kWMaxBlocks = 256;          // one persistent workgroup per CU
 
+template <int IN>
 struct SmemW {
-    float W1s[H * LW1];
+    float W1s[H * Pad<IN>::LW1];
     float W2s[H * LW2];
     float W2Ts[H * LW2];
     float b1[H], b2[H], w3[H], w4[H];
     float wv[kWWaves * WAVE_F];
 };
-static_assert(sizeof(SmemW) <= 160 * 1024, "LDS");
+static_assert(sizeof(SmemW<16>) <= 160 * 1024 && sizeof(SmemW<42>) <= 160 * 1024, "LDS");
 static_assert(2 * kWMaxBlocks <= NAVPPO_MLP64_MAX_BLOCKS, "workspace rows for both nets");
-static_assert(kWWaves * WAVE_F >= P_ACTOR + 4, "reduction buffer");
+static_assert(offsetof(SmemW<42>, wv) == offsetof(SmemW<42>, W2s) + sizeof(float) * (2 * H * LW2 + 4 * H), "reduction rows span W2s .. wv");
 
 __device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void wave_lds_fence() {
@@ -95,9 +117,64 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// The KH observation entries X[m][KH lhi .. KH lhi + KH - 1] of one sample as the lane (m, lhi) of a tile holds them: requested
+// into raw dwords (float32, or packed pairs of float16), widened to float32 at the use.  Entries past the row (IN = 42: columns
+// 42 .. 47) are zero.  Rows are 16-byte (IN = 16) / 8-byte (IN = 42 float32) / 4-byte (IN = 42 float16) aligned.
+template <int IN, bool F16>
+struct XRow {
+    static constexpr int KH = Pad<IN>::KH;
+    static constexpr int NRAW = F16 ? KH / 2 : KH;
+    uint32_t raw[NRAW];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int j = 0; j < NRAW; ++j) raw[j] = 0u;
+    }
+    __device__ __forceinline__ void request(const void* __restrict__ obs, const long long m, const int lhi) {
+        if constexpr (IN == 16 && !F16) {
+            const uint4* xp = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(obs) + m * IN + 8 * lhi);
+            const uint4 q0 = xp[0], q1 = xp[1];
+            raw[0] = q0.x; raw[1] = q0.y; raw[2] = q0.z; raw[3] = q0.w; raw[4] = q1.x; raw[5] = q1.y; raw[6] = q1.z; raw[7] = q1.w;
+        } else if constexpr (IN == 16 && F16) {
+            const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(obs) + m * IN + 8 * lhi);
+            raw[0] = q.x; raw[1] = q.y; raw[2] = q.z; raw[3] = q.w;
+        } else if constexpr (!F16) {   // 42 float32 columns: pairs, the half lhi = 1 holds 18 of them
+            const uint2* xp = reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(obs) + m * IN + KH * lhi);
+#pragma unroll
+            for (int j = 0; j < KH / 2; ++j) {
+                uint2 q = make_uint2(0u, 0u);
+                if (KH * lhi + 2 * j < IN) q = xp[j];
+                raw[2 * j] = q.x;
+                raw[2 * j + 1] = q.y;
+            }
+        } else {
+            const uint32_t* xp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const __half*>(obs) + m * IN + KH * lhi);
+#pragma unroll
+            for (int j = 0; j < KH / 2; ++j) raw[j] = (KH * lhi + 2 * j < IN) ? xp[j] : 0u;
+        }
+    }
+    __device__ __forceinline__ void get(float (&x)[KH]) const {
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            if constexpr (F16) {
+                const uint32_t w = raw[j >> 1];
+                x[j] = __half2float(__ushort_as_half((unsigned short)((j & 1) ? (w >> 16) : (w & 0xffffu))));
+            } else {
+                x[j] = __uint_as_float(raw[j]);
+            }
+        }
+    }
+};
+
+// one observation entry as float32
+template <bool F16>
+__device__ __forceinline__ float obs_at(const void* __restrict__ obs, const long long idx) {
+    if constexpr (F16) return __half2float(reinterpret_cast<const __half*>(obs)[idx]);
+    else return reinterpret_cast<const float*>(obs)[idx];
+}
+
 // FWD: forward only (critic): V[m] = critic(obs[m]) is written to v_out and everything behind the output unit is skipped.
-template <bool ACTOR, bool FWD = false>
-__device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ params, const float* __restrict__ obs,
+template <bool ACTOR, bool FWD = false, int IN = 16, bool F16 = false>
+__device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict__ params, const void* __restrict__ obs,
                                           const float* __restrict__ act, const float* __restrict__ logp_old,
                                           const float* __restrict__ rtg, const float* __restrict__ adv,
                                           long long M, float var, float clip, float inv_n,
@@ -105,13 +182,20 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
                                           float* __restrict__ grad_zero, float* __restrict__ stats_zero,
                                           float* __restrict__ v_out = nullptr) {
     static_assert(!(FWD && ACTOR), "forward-only pass is the critic's");
-    constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
+    using L = Layout<IN>;
+    constexpr int OFF_W1 = L::OFF_W1, OFF_B1 = L::OFF_B1, OFF_W2 = L::OFF_W2, OFF_B2 = L::OFF_B2, OFF_W3 = L::OFF_W3,
+                  OFF_B3 = L::OFF_B3, OFF_W4 = L::OFF_W4, OFF_B4 = L::OFF_B4;
+    constexpr int P = ACTOR ? L::P_ACTOR : L::P_CRITIC;
+    constexpr int INP = Pad<IN>::INP, KH = Pad<IN>::KH, NC = Pad<IN>::NC, LW1 = Pad<IN>::LW1;
+    constexpr bool kKeepX = (IN == 16);   // X stays in registers from F1 to G1, the next tile's rows are prefetched (see Pad)
     constexpr int NT = kWThreads;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15, kk = lane >> 4;
 
     (void)grad_zero;
     (void)stats_zero;
+    if constexpr (INP != IN)
+        for (int k = tid; k < H * (INP - IN); k += NT) sm.W1s[(k / (INP - IN)) * LW1 + IN + (k % (INP - IN))] = 0.f;
     for (int k = tid; k < H * IN; k += NT) sm.W1s[(k / IN) * LW1 + (k % IN)] = params[OFF_W1 + k];
     for (int k = tid; k < H * H; k += NT) {
         const float w = params[OFF_W2 + k];
@@ -137,33 +221,34 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
     const int rd32 = l31 * LT + 16 * lhi;      // row l31, samples 16 lhi .. + 15 (32x32x2 operands: k = sample)
     const int rd16 = l15 * LT + 8 * kk;        // row l15, samples 8 kk .. + 7   (16x16x4 operands)
     const int vec_off = 4 * lhi;               // b1 / b2 / w3 / w4 [32 t + 8 g + 4 lhi + j]
-    const float* const w1row = sm.W1s + l31 * LW1 + 8 * lhi;
+    const float* const w1row = sm.W1s + l31 * LW1 + KH * lhi;
     const float* const w2row = sm.W2s + l31 * LW2 + 4 * lhi;
     const float* const w2trow = sm.W2Ts + l31 * LW2 + 4 * lhi;
 
     // accumulators that persist over this wave's tiles
     f32x16 aW2[2][2];   // dW2 quadrant [n2 tile][n tile]
-    f32x4 aW1[4];       // dW1 rows 16 u .. + 15
+    f32x4 aW1[4][NC];   // dW1 rows 16 u .. + 15, columns 16 c .. + 15
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) aW2[a][b] = zero16();
 #pragma unroll
-    for (int u = 0; u < 4; ++u) aW1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) aW1[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float adb2[2] = {0.f, 0.f}, adw3[2] = {0.f, 0.f}, adw4[2] = {0.f, 0.f}, adb1[4] = {0.f, 0.f, 0.f, 0.f};
     float adb3 = 0.f, adb4 = 0.f, st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
 
     const long long n_tiles = (M + 31) / 32;
     const long long gw = (long long)blockIdx.x * kWWaves + wave, stride = (long long)gridDim.x * kWWaves;
-    float4 xp0 = make_float4(0.f, 0.f, 0.f, 0.f), xp1 = xp0;
+    XRow<IN, F16> xpre;
+    xpre.zero();
     float pre_a0 = 0.f, pre_a1 = 0.f, pre_lp = 0.f, pre_t = 0.f;
     auto prefetch_tile = [&](long long tile) {   // next tile's rows stream in while the current one is computed
         const long long m = tile * 32 + l31;
-        xp0 = xp1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        xpre.zero();
         if (m < M) {
-            const float4* xp = reinterpret_cast<const float4*>(obs + m * IN + 8 * lhi);
-            xp0 = xp[0];
-            xp1 = xp[1];
+            xpre.request(obs, m, lhi);
             if (ACTOR) {
                 const float2 a = reinterpret_cast<const float2*>(act)[m];
                 pre_a0 = a.x;
@@ -178,29 +263,35 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
     if (gw < n_tiles) prefetch_tile(gw);
     for (long long tile = gw; tile < n_tiles; tile += stride) {
         const bool valid = tile * 32 + l31 < M;
-        const float xr[8] = {xp0.x, xp0.y, xp0.z, xp0.w, xp1.x, xp1.y, xp1.z, xp1.w};  // X[m][8 lhi + s]
+        float xr[KH];   // X[m][KH lhi + s]
+        xpre.get(xr);
         const float cur_a0 = pre_a0, cur_a1 = pre_a1, cur_lp = pre_lp, cur_t = pre_t;
-        if (tile + stride < n_tiles) prefetch_tile(tile + stride);
+        if (kKeepX && tile + stride < n_tiles) prefetch_tile(tile + stride);
 
-        // ---- F1: both 32-row tiles of H1^T interleaved (independent accumulators)
+        // ---- F1: both 32-row tiles of H1^T interleaved (independent accumulators), eight k-steps per group of operand reads
         f32x16 c1[2];
         {
-            float wa[2][8];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 b = lds4(sm.b1 + 32 * t + 8 * g + vec_off);
                     c1[t][4 * g] = b.x; c1[t][4 * g + 1] = b.y; c1[t][4 * g + 2] = b.z; c1[t][4 * g + 3] = b.w;
                 }
-                const float4 w0 = lds4(w1row + 32 * t * LW1), w1 = lds4(w1row + 32 * t * LW1 + 4);
-                wa[t][0] = w0.x; wa[t][1] = w0.y; wa[t][2] = w0.z; wa[t][3] = w0.w;
-                wa[t][4] = w1.x; wa[t][5] = w1.y; wa[t][6] = w1.z; wa[t][7] = w1.w;
-            }
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                c1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], xr[s], c1[0], 0, 0, 0);
-                c1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], xr[s], c1[1], 0, 0, 0);
+            for (int ch = 0; ch < KH / 8; ++ch) {
+                float wa[2][8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float4 w0 = lds4(w1row + 32 * t * LW1 + 8 * ch), w1 = lds4(w1row + 32 * t * LW1 + 8 * ch + 4);
+                    wa[t][0] = w0.x; wa[t][1] = w0.y; wa[t][2] = w0.z; wa[t][3] = w0.w;
+                    wa[t][4] = w1.x; wa[t][5] = w1.y; wa[t][6] = w1.z; wa[t][7] = w1.w;
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    c1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], xr[8 * ch + s], c1[0], 0, 0, 0);
+                    c1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], xr[8 * ch + s], c1[1], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -267,6 +358,7 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
             if (ACTOR) z4 += __shfl_xor(z4, 32, 64);
             if (FWD) {
                 if (valid && lhi == 0) v_out[tile * 32 + l31] = z3 + b3;   // critic(obs).squeeze(), ppo.py:275,724
+                if (!kKeepX && tile + stride < n_tiles) prefetch_tile(tile + stride);
                 continue;
             }
             const float own = (lhi == 0) ? 1.f : 0.f;   // statistics are counted once per sample
@@ -399,16 +491,37 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
             c3[1][r] = (T1[o] > 0.f) ? c3[1][r] : 0.f;
         }
         wave_lds_fence();
-        // ---- G1: X goes to T0 as [k][m] (the H1^T tiles are no longer needed), dH1^T through TD 32 rows at a time
+        // ---- G1: dH1^T through TD 32 rows at a time; X as [k = sample][column]: IN = 16 from the registers through T0 (the H1^T
+        // tiles are no longer needed), IN = 42 read again from L2 straight in the operand layout (lane (l15, kk): samples 8 kk + s),
+        // one 16-column tile at a time, the next tile's eight values requested ahead of the current tile's MFMAs
+        if constexpr (kKeepX) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) T0[(8 * lhi + s) * LT + l31] = xr[s];
+            for (int s = 0; s < 8; ++s) T0[(8 * lhi + s) * LT + l31] = xr[s];
+        }
+        int xrow[8];   // (IN = 42) row offsets of the lane's eight samples; rows past the batch re-read the last one (dH1 is zero there)
+        if constexpr (!kKeepX) {
+            const long long m0 = tile * 32 + 8 * kk;
+            const int lim = (int)((M - 1 - m0 < 7) ? ((M - 1 - m0 < 0) ? 0 : M - 1 - m0) : 7);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) xrow[s] = min(s, lim) * IN;
+        }
+        const long long xbase = (tile * 32 + 8 * kk < M ? tile * 32 + 8 * kk : M - 1) * IN + l15;
+        auto load_xb = [&](const int c, float (&dst)[8]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) dst[s] = (16 * c + l15 < IN) ? obs_at<F16>(obs, xbase + xrow[s] + 16 * c) : 0.f;
+        };
+        float xb[2][8];   // X[m = 8 kk + s][16 c + l15], two column tiles in turn
+        if constexpr (!kKeepX) load_xb(0, xb[0]);
 #pragma unroll
         for (int t1 = 0; t1 < 2; ++t1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) TD[wr_base + (8 * (r >> 2) + (r & 3)) * LT] = c3[t1][r];
             wave_lds_fence();
-            const float4 x0 = lds4(T0 + rd16), x1 = lds4(T0 + rd16 + 4);
-            const float xb[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};   // X[m = 8 kk + s][k = l15]
+            if constexpr (kKeepX) {
+                const float4 x0 = lds4(T0 + rd16), x1 = lds4(T0 + rd16 + 4);
+                xb[0][0] = x0.x; xb[0][1] = x0.y; xb[0][2] = x0.z; xb[0][3] = x0.w;
+                xb[0][4] = x1.x; xb[0][5] = x1.y; xb[0][6] = x1.z; xb[0][7] = x1.w;   // X[m = 8 kk + s][k = l15]
+            }
             {
                 const float4 d0 = lds4(TD + rd16), d1 = lds4(TD + rd16 + 4);
                 const float4 e0 = lds4(TD + 16 * LT + rd16), e1 = lds4(TD + 16 * LT + rd16 + 4);
@@ -417,13 +530,23 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
                 adb1[2 * t1] += ((d0.x + d0.y) + (d0.z + d0.w)) + ((d1.x + d1.y) + (d1.z + d1.w));
                 adb1[2 * t1 + 1] += ((e0.x + e0.y) + (e0.z + e0.w)) + ((e1.x + e1.y) + (e1.z + e1.w));
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    aW1[2 * t1] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[s], xb[s], aW1[2 * t1], 0, 0, 0);
-                    aW1[2 * t1 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], xb[s], aW1[2 * t1 + 1], 0, 0, 0);
+                for (int c = 0; c < NC; ++c) {
+                    const int cur = kKeepX ? 0 : ((t1 * NC + c) & 1);
+                    if constexpr (!kKeepX) {
+                        if (t1 * NC + c + 1 < 2 * NC) load_xb((c + 1) % NC, xb[cur ^ 1]);
+                        __builtin_amdgcn_sched_barrier(0);   // keep the requests above the MFMAs they overlap with
+                    }
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        aW1[2 * t1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[s], xb[cur][s], aW1[2 * t1][c], 0, 0, 0);
+                        aW1[2 * t1 + 1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], xb[cur][s], aW1[2 * t1 + 1][c], 0, 0, 0);
+                    }
+                    if constexpr (!kKeepX) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             wave_lds_fence();
         }
+        if (!kKeepX && tile + stride < n_tiles) prefetch_tile(tile + stride);
     }
 
     if (FWD) return;
@@ -435,7 +558,9 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
     // two sample halves, the loss statistics) are combined with shuffles first.
     __syncthreads();
     constexpr int RP = (P + 3 + 3) & ~3;   // row pitch (floats): P parameters + 3 statistics, a multiple of 4
-    static_assert(4 * RP <= kWWaves * WAVE_F, "reduction rows fit the wave tiles");
+    // the four rows lie over the wave tiles; the 42-wide nets' rows (4 x 7048 floats) start at W2s, which nothing reads any more
+    float* const red_base = (IN == 16) ? sm.wv : sm.W2s;
+    static_assert(4 * RP <= kWWaves * WAVE_F + ((IN == 16) ? 0 : 2 * H * LW2 + 4 * H), "reduction rows fit");
     float s3 = adb3, s4 = adb4, sA = ACTOR ? st0 : st1, sB = st2, sC = st3;   // held per lane (lhi == 0 lanes non-zero)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -456,7 +581,7 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
         v += __shfl_xor(v, 32, 64);
         qb1[u] = v;
     }
-    float* const row = sm.wv + (wave & 3) * RP;
+    float* const row = red_base + (wave & 3) * RP;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         if ((wave >> 2) == pass) {
@@ -477,7 +602,10 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) put(OFF_W1 + (16 * u + 4 * kk + r) * IN + l15, aW1[u][r]);
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (INP == IN || 16 * c + l15 < IN) put(OFF_W1 + (16 * u + 4 * kk + r) * IN + 16 * c + l15, aW1[u][c][r]);
                 if (kk == 0) put(OFF_B1 + 16 * u + l15, qb1[u]);
             }
             if (lane == 0) {
@@ -491,42 +619,45 @@ __device__ __forceinline__ void pass_body(SmemW& sm, const float* __restrict__ p
         __syncthreads();
     }
     float* out = partial + (size_t)blockIdx.x * P;
-    const float* red = sm.wv;
+    const float* red = red_base;
     for (int k = tid; k < P; k += NT) out[k] = (red[k] + red[RP + k]) + (red[2 * RP + k] + red[3 * RP + k]);
     if (tid < 3) stats_partial[blockIdx.x * 4 + tid] = (red[P + tid] + red[RP + P + tid]) + (red[2 * RP + P + tid] + red[3 * RP + P + tid]);
 }
 
-template <bool ACTOR, bool FWD = false>
-__global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restrict__ params, const float* __restrict__ obs,
+template <bool ACTOR, bool FWD, int IN, bool F16>
+__global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restrict__ params, const void* __restrict__ obs,
                                                           const float* __restrict__ act, const float* __restrict__ logp_old,
                                                           const float* __restrict__ rtg, const float* __restrict__ adv,
                                                           long long M, float var, float clip, float inv_n,
                                                           float* __restrict__ partial, float* __restrict__ stats_partial,
                                                           float* __restrict__ grad_zero, float* __restrict__ stats_zero,
                                                           float* __restrict__ v_out = nullptr) {
-    __shared__ __attribute__((aligned(16))) SmemW sm;
-    pass_body<ACTOR, FWD>(sm, params, obs, act, logp_old, rtg, adv, M, var, clip, inv_n, partial, stats_partial, grad_zero,
-                          stats_zero, v_out);
+    __shared__ __attribute__((aligned(16))) SmemW<IN> sm;
+    pass_body<ACTOR, FWD, IN, F16>(sm, params, obs, act, logp_old, rtg, adv, M, var, clip, inv_n, partial, stats_partial, grad_zero,
+                                   stats_zero, v_out);
 }
 
 // both nets of one epoch in one launch (single-GPU path): the actor's tiles, then the critic's, by the same workgroups
-__global__ __launch_bounds__(kWThreads) void mlp64_pass_both(const float* __restrict__ params, const float* __restrict__ obs,
+template <int IN, bool F16>
+__global__ __launch_bounds__(kWThreads) void mlp64_pass_both(const float* __restrict__ params, const void* __restrict__ obs,
                                                              const float* __restrict__ act, const float* __restrict__ logp_old,
                                                              const float* __restrict__ rtg, const float* __restrict__ adv,
                                                              long long M, float var, float clip, float inv_n,
                                                              float* __restrict__ partial_a, float* __restrict__ stats_partial_a,
                                                              float* __restrict__ partial_c, float* __restrict__ stats_partial_c,
                                                              float* __restrict__ grad, float* __restrict__ stats) {
-    __shared__ __attribute__((aligned(16))) SmemW sm;
-    pass_body<true>(sm, params, obs, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_a, stats_partial_a, grad, stats);
+    __shared__ __attribute__((aligned(16))) SmemW<IN> sm;
+    pass_body<true, false, IN, F16>(sm, params, obs, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_a, stats_partial_a, grad,
+                                    stats);
     __syncthreads();
-    pass_body<false>(sm, params + P_ACTOR, obs, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_c, stats_partial_c,
-                     grad + P_ACTOR, stats + 4);
+    pass_body<false, false, IN, F16>(sm, params + Layout<IN>::P_ACTOR, obs, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_c,
+                                     stats_partial_c, grad + Layout<IN>::P_ACTOR, stats + 4);
 }
 
 // grad[p] = sum over the workgroups' partial rows, for BOTH nets; ADAM (single-GPU epoch): then torch.optim.Adam's update (ppo.py:116-117,381,392; defaults betas
 // (0.9, 0.999), eps 1e-8, no weight decay) applied in place -- one launch instead of two reductions + an optimiser launch.
-// One block owns 64 parameters and ALL rows (no atomics): grad[p] is stored, not accumulated.
+// One block owns 64 parameters and ALL rows (no atomics): grad[p] is stored, not accumulated.  pa / pc: parameters of the actor /
+// the critic (Layout<IN>), the pitch of their partial rows.
 constexpr int kRedGroups = 16;   // row groups per block: 1024 threads, every thread sums n_blocks / 16 rows, 4 loads in flight
 template <bool ADAM>
 __global__ __launch_bounds__(64 * kRedGroups) void reduce_adam(const float* __restrict__ partial_a, const float* __restrict__ stats_partial_a,
@@ -534,12 +665,12 @@ __global__ __launch_bounds__(64 * kRedGroups) void reduce_adam(const float* __re
                                                    int n_blocks, float inv_n, float* __restrict__ grad, float* __restrict__ stats,
                                                    float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
                                                    float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-                                                   int q_begin = 0, int q_end = P_ACTOR + P_CRITIC) {
+                                                   int pa, int pc, int q_begin, int q_end) {
     __shared__ float part[kRedGroups][64];
     const int lane = threadIdx.x & 63, q = q_begin + blockIdx.x * 64 + lane, g = threadIdx.x >> 6;   // q: index into actor | critic
-    const bool actor = q < P_ACTOR;
+    const bool actor = q < pa;
     const float* __restrict__ partial = actor ? partial_a : partial_c;
-    const int P = actor ? P_ACTOR : P_CRITIC, p = actor ? q : q - P_ACTOR;
+    const int P = actor ? pa : pc, p = actor ? q : q - pa;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (q < q_end) {
         int b = g;
@@ -567,7 +698,7 @@ __global__ __launch_bounds__(64 * kRedGroups) void reduce_adam(const float* __re
             params[q] -= (lr / bc1) * (mm / denom);
         }
     }
-    const bool net_here = (g < 4) ? (q_begin == 0) : (q_end > P_ACTOR);   // a one-net launch leaves the other net's statistics alone
+    const bool net_here = (g < 4) ? (q_begin == 0) : (q_end > pa);   // a one-net launch leaves the other net's statistics alone
     if (blockIdx.x == 0 && g < 8 && (g & 3) < 3 && net_here) {   // stats[0..2] actor, stats[4..6] critic: wave g sums statistic g over the rows
         const float* sp = (g < 4) ? stats_partial_a : stats_partial_c;
         float s = 0.f;
@@ -595,19 +726,32 @@ __global__ void adam_step_kernel(float* __restrict__ params, const float* __rest
 // ---------------------------------------------------------------- rollout-time policy step (PPO.get_action, ppo.py:673-706)
 // PPO.get_action for all envs, one launch: one wave = 16 envs, the policy step itself is mlp64_policy.h (shared with the
 // persistent rollout kernel of navsim.hip so that both produce the same bits)
-__global__ __launch_bounds__(64) void mlp64_act(const float* __restrict__ params, const float* __restrict__ obs,
+template <int IN, bool F16>
+__global__ __launch_bounds__(64) void mlp64_act(const float* __restrict__ params, const void* __restrict__ obs,
                                                 const float* __restrict__ noise, long long n,
                                                 const float* __restrict__ var_ptr, uint64_t seed, uint64_t env_id_base,
                                                 const uint32_t* __restrict__ step_base, uint32_t step_offset,
                                                 float* __restrict__ act, float* __restrict__ logp,
                                                 float* __restrict__ mean_out) {
+    using L = Layout<IN>;
     const int lane = threadIdx.x, l15 = lane & 15, kk = lane >> 4;
     const long long m = (long long)blockIdx.x * kActEnvs + l15;
     const bool valid = m < n;
-    const float4 xq = valid ? *reinterpret_cast<const float4*>(obs + m * IN + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float xs[L::KS];
+    if constexpr (IN == 16 && !F16) {
+        const float4 xq = valid ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(obs) + m * IN + 4 * kk)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        xs[0] = xq.x; xs[1] = xq.y; xs[2] = xq.z; xs[3] = xq.w;
+    } else {
+#pragma unroll
+        for (int s = 0; s < L::KS; ++s) {
+            const int f = L::KS * kk + s;
+            xs[s] = (valid && f < IN) ? obs_at<F16>(obs, m * IN + min(f, IN - 1)) : 0.f;
+        }
+    }
     const uint32_t step = (step_base ? *step_base : 0u) + step_offset;
-    const PolicyOut o = policy_wave16(params, xq, lane, *var_ptr, (noise && valid) ? noise + 2 * m : nullptr, step, seed,
-                                      env_id_base + (uint64_t)m);
+    const PolicyOut o = policy_wave16<L>(params, xs, lane, *var_ptr, (noise && valid) ? noise + 2 * m : nullptr, step, seed,
+                                         env_id_base + (uint64_t)m);
     if (kk == 0 && valid) {
         act[2 * m] = o.a0;
         act[2 * m + 1] = o.a1;
@@ -703,36 +847,85 @@ extern "C" {
 
 const char* navppo_last_error(void) { return g_err.c_str(); }
 
-size_t navppo_mlp64_workspace_bytes(void) {
-    return (size_t)NAVPPO_MLP64_MAX_BLOCKS * (NAVPPO_MLP64_ACTOR_PARAMS + 4) * sizeof(float);
+size_t navppo_mlp64_workspace_bytes(int32_t obs_dim) {
+    if (obs_dim != 16 && obs_dim != 42) return 0;
+    return (size_t)NAVPPO_MLP64_MAX_BLOCKS * (NAVPPO_MLP64_ACTOR_PARAMS_D(obs_dim) + 4) * sizeof(float);
 }
 
-int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const float* act_dev,
+}  // extern "C"
+#pragma GCC visibility pop
+
+namespace {
+
+// the instantiation for (observation width, row type): f(std::integral_constant<int, IN>, std::integral_constant<bool, F16>)
+template <class F>
+bool for_obs(int32_t obs_dim, int32_t obs_f16, F f) {
+    if (obs_dim == 16) {
+        if (obs_f16) f(std::integral_constant<int, 16>{}, std::true_type{});
+        else f(std::integral_constant<int, 16>{}, std::false_type{});
+        return true;
+    }
+    if (obs_dim == 42) {
+        if (obs_f16) f(std::integral_constant<int, 42>{}, std::true_type{});
+        else f(std::integral_constant<int, 42>{}, std::false_type{});
+        return true;
+    }
+    return false;
+}
+
+// rows of `obs` are read with 16-byte (16 columns), 8-byte (42 float32 columns) or 4-byte (42 float16 columns) loads
+bool obs_aligned(const void* obs, int32_t obs_dim, int32_t obs_f16) {
+    const uintptr_t mask = obs_dim == 16 ? 15 : (obs_f16 ? 3 : 7);
+    return ((uintptr_t)obs & mask) == 0;
+}
+
+struct PassPlan {
+    float *partial, *stats_partial, *partial_c, *stats_partial_c;
+    float inv_n;
+    int blocks, pa, pc;
+};
+PassPlan plan_pass(void* workspace_dev, int64_t n_samples, int32_t obs_dim) {
+    PassPlan pl;
+    pl.pa = NAVPPO_MLP64_ACTOR_PARAMS_D(obs_dim);
+    pl.pc = NAVPPO_MLP64_CRITIC_PARAMS_D(obs_dim);
+    pl.partial = reinterpret_cast<float*>(workspace_dev);
+    pl.stats_partial = pl.partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * pl.pa;
+    pl.partial_c = pl.partial + (size_t)kWMaxBlocks * pl.pa;   // the workspace has NAVPPO_MLP64_MAX_BLOCKS = 2 kWMaxBlocks rows
+    pl.stats_partial_c = pl.stats_partial + (size_t)kWMaxBlocks * 4;
+    pl.inv_n = 1.0f / (float)n_samples;
+    const long long wtiles = (n_samples + 31) / 32;
+    const long long want = (wtiles + kWWaves - 1) / kWWaves;
+    pl.blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
+    return pl;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int navppo_mlp64_loss_grad(const float* params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16, const float* act_dev,
                            const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples,
                            float var, float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
     if (!params_dev || !obs_dev || !act_dev || !logp_old_dev || !rtg_dev || !adv_dev || !grad_dev || !stats_dev ||
-        !workspace_dev || n_samples < 1 || !(var > 0.f)) {
-        g_err = "navppo_mlp64_loss_grad: bad argument";
+        !workspace_dev || n_samples < 1 || !(var > 0.f) || (obs_dim != 16 && obs_dim != 42)) {
+        g_err = "navppo_mlp64_loss_grad: bad argument (obs_dim is 16 or 42)";
+        return -1;
+    }
+    if (!obs_aligned(obs_dev, obs_dim, obs_f16) || ((uintptr_t)act_dev & 7)) {
+        g_err = "navppo_mlp64_loss_grad: obs must be 16-byte (42 columns: 8-byte, float16: 4-byte) and act 8-byte aligned";
         return -1;
     }
     hipStream_t st = (hipStream_t)stream;
-    float* partial = reinterpret_cast<float*>(workspace_dev);
-    float* stats_partial = partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * NAVPPO_MLP64_ACTOR_PARAMS;
-    const float inv_n = 1.0f / (float)n_samples;
-    if (((uintptr_t)obs_dev & 15) || ((uintptr_t)act_dev & 7)) {
-        g_err = "navppo_mlp64_loss_grad: obs must be 16-byte and act 8-byte aligned";
-        return -1;
-    }
-    const long long wtiles = (n_samples + 31) / 32;
-    const long long want = (wtiles + kWWaves - 1) / kWWaves;
-    const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
-    float* partial_c = partial + (size_t)kWMaxBlocks * P_ACTOR;        // the workspace has NAVPPO_MLP64_MAX_BLOCKS = 2 kWMaxBlocks rows
-    float* stats_partial_c = stats_partial + (size_t)kWMaxBlocks * 4;
-    hipLaunchKernelGGL(mlp64_pass_both, dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev,
-                       adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, partial_c, stats_partial_c, grad_dev,
-                       stats_dev);
-    hipLaunchKernelGGL(reduce_adam<false>, dim3((P_ACTOR + P_CRITIC + 63) / 64), dim3(64 * kRedGroups), 0, st, partial, stats_partial, partial_c,
-                       stats_partial_c, blocks, inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f);
+    const PassPlan pl = plan_pass(workspace_dev, n_samples, obs_dim);
+    for_obs(obs_dim, obs_f16, [&](auto in, auto f16) {
+        hipLaunchKernelGGL((mlp64_pass_both<decltype(in)::value, decltype(f16)::value>), dim3(pl.blocks), dim3(kWThreads), 0, st, params_dev,
+                           obs_dev, act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, pl.inv_n, pl.partial,
+                           pl.stats_partial, pl.partial_c, pl.stats_partial_c, grad_dev, stats_dev);
+    });
+    hipLaunchKernelGGL(reduce_adam<false>, dim3((pl.pa + pl.pc + 63) / 64), dim3(64 * kRedGroups), 0, st, pl.partial, pl.stats_partial,
+                       pl.partial_c, pl.stats_partial_c, pl.blocks, pl.inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f,
+                       0.f, 1.f, 1.f, pl.pa, pl.pc, 0, pl.pa + pl.pc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_loss_grad: ") + hipGetErrorString(e);
@@ -741,41 +934,37 @@ int navppo_mlp64_loss_grad(const float* params_dev, const float* obs_dev, const 
     return 0;
 }
 
-int navppo_mlp64_loss_grad_net(int32_t net, const float* params_dev, const float* obs_dev, const float* act_dev,
-                               const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var,
-                               float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
+int navppo_mlp64_loss_grad_net(int32_t net, const float* params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16,
+                               const float* act_dev, const float* logp_old_dev, const float* rtg_dev, const float* adv_dev,
+                               int64_t n_samples, float var, float clip, float* grad_dev, float* stats_dev, void* workspace_dev,
+                               void* stream) {
     if ((net != 0 && net != 1) || !params_dev || !obs_dev || !act_dev || !logp_old_dev || !rtg_dev || !adv_dev || !grad_dev ||
-        !stats_dev || !workspace_dev || n_samples < 1 || !(var > 0.f)) {
-        g_err = "navppo_mlp64_loss_grad_net: bad argument";
+        !stats_dev || !workspace_dev || n_samples < 1 || !(var > 0.f) || (obs_dim != 16 && obs_dim != 42)) {
+        g_err = "navppo_mlp64_loss_grad_net: bad argument (obs_dim is 16 or 42)";
         return -1;
     }
-    if (((uintptr_t)obs_dev & 15) || ((uintptr_t)act_dev & 7)) {
-        g_err = "navppo_mlp64_loss_grad_net: obs must be 16-byte and act 8-byte aligned";
+    if (!obs_aligned(obs_dev, obs_dim, obs_f16) || ((uintptr_t)act_dev & 7)) {
+        g_err = "navppo_mlp64_loss_grad_net: obs must be 16-byte (42 columns: 8-byte, float16: 4-byte) and act 8-byte aligned";
         return -1;
     }
     hipStream_t st = (hipStream_t)stream;
-    float* partial = reinterpret_cast<float*>(workspace_dev);
-    float* stats_partial = partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * NAVPPO_MLP64_ACTOR_PARAMS;
-    float* partial_c = partial + (size_t)kWMaxBlocks * P_ACTOR;
-    float* stats_partial_c = stats_partial + (size_t)kWMaxBlocks * 4;
-    const float inv_n = 1.0f / (float)n_samples;
-    const long long wtiles = (n_samples + 31) / 32;
-    const long long want = (wtiles + kWWaves - 1) / kWWaves;
-    const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
-    if (net == 0) {
-        hipLaunchKernelGGL((mlp64_pass_w<true>), dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev,
-                           adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, grad_dev, stats_dev, (float*)nullptr);
-        hipLaunchKernelGGL(reduce_adam<false>, dim3((P_ACTOR + 63) / 64), dim3(64 * kRedGroups), 0, st, partial, stats_partial, partial_c,
-                           stats_partial_c, blocks, inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 0,
-                           P_ACTOR);
-    } else {
-        hipLaunchKernelGGL((mlp64_pass_w<false>), dim3(blocks), dim3(kWThreads), 0, st, params_dev + P_ACTOR, obs_dev, act_dev, logp_old_dev,
-                           rtg_dev, adv_dev, (long long)n_samples, var, clip, inv_n, partial_c, stats_partial_c, grad_dev + P_ACTOR,
-                           stats_dev + 4, (float*)nullptr);
-        hipLaunchKernelGGL(reduce_adam<false>, dim3((P_CRITIC + 63) / 64), dim3(64 * kRedGroups), 0, st, partial, stats_partial, partial_c,
-                           stats_partial_c, blocks, inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f,
-                           P_ACTOR, P_ACTOR + P_CRITIC);
-    }
+    const PassPlan pl = plan_pass(workspace_dev, n_samples, obs_dim);
+    for_obs(obs_dim, obs_f16, [&](auto in, auto f16) {
+        constexpr int IN = decltype(in)::value;
+        constexpr bool F16 = decltype(f16)::value;
+        if (net == 0)
+            hipLaunchKernelGGL((mlp64_pass_w<true, false, IN, F16>), dim3(pl.blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev,
+                               logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, pl.inv_n, pl.partial, pl.stats_partial,
+                               grad_dev, stats_dev, (float*)nullptr);
+        else
+            hipLaunchKernelGGL((mlp64_pass_w<false, false, IN, F16>), dim3(pl.blocks), dim3(kWThreads), 0, st, params_dev + pl.pa, obs_dev,
+                               act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, pl.inv_n, pl.partial_c,
+                               pl.stats_partial_c, grad_dev + pl.pa, stats_dev + 4, (float*)nullptr);
+    });
+    const int q0 = net == 0 ? 0 : pl.pa, q1 = net == 0 ? pl.pa : pl.pa + pl.pc;
+    hipLaunchKernelGGL(reduce_adam<false>, dim3((q1 - q0 + 63) / 64), dim3(64 * kRedGroups), 0, st, pl.partial, pl.stats_partial, pl.partial_c,
+                       pl.stats_partial_c, pl.blocks, pl.inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f,
+                       pl.pa, pl.pc, q0, q1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_loss_grad_net: ") + hipGetErrorString(e);
@@ -802,17 +991,21 @@ int navppo_adam_step(float* params_dev, const float* grad_dev, float* adam_m_dev
     return 0;
 }
 
-int navppo_mlp64_value(const float* critic_params_dev, const float* obs_dev, int64_t n_samples, float* value_dev, void* stream) {
-    if (!critic_params_dev || !obs_dev || !value_dev || n_samples < 1 || ((uintptr_t)obs_dev & 15)) {
-        g_err = "navppo_mlp64_value: bad argument (obs must be 16-byte aligned)";
+int navppo_mlp64_value(const float* critic_params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16, int64_t n_samples,
+                       float* value_dev, void* stream) {
+    if (!critic_params_dev || !obs_dev || !value_dev || n_samples < 1 || (obs_dim != 16 && obs_dim != 42) ||
+        !obs_aligned(obs_dev, obs_dim, obs_f16)) {
+        g_err = "navppo_mlp64_value: bad argument (obs_dim is 16 or 42; obs 16-byte aligned, 42 columns: 8-byte, float16: 4-byte)";
         return -1;
     }
     const long long wtiles = (n_samples + 31) / 32;
     const long long want = (wtiles + kWWaves - 1) / kWWaves;
     const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
-    hipLaunchKernelGGL((mlp64_pass_w<false, true>), dim3(blocks), dim3(kWThreads), 0, (hipStream_t)stream, critic_params_dev, obs_dev,
-                       nullptr, nullptr, nullptr, nullptr, (long long)n_samples, 1.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr,
-                       value_dev);
+    for_obs(obs_dim, obs_f16, [&](auto in, auto f16) {
+        hipLaunchKernelGGL((mlp64_pass_w<false, true, decltype(in)::value, decltype(f16)::value>), dim3(blocks), dim3(kWThreads), 0,
+                           (hipStream_t)stream, critic_params_dev, obs_dev, nullptr, nullptr, nullptr, nullptr, (long long)n_samples, 1.f,
+                           0.f, 0.f, nullptr, nullptr, nullptr, nullptr, value_dev);
+    });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_value: ") + hipGetErrorString(e);
@@ -821,36 +1014,31 @@ int navppo_mlp64_value(const float* critic_params_dev, const float* obs_dev, int
     return 0;
 }
 
-int navppo_mlp64_update_epoch(float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
-                              const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
-                              float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
-                              float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
+int navppo_mlp64_update_epoch(float* params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16, const float* act_dev,
+                              const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var,
+                              float clip, float lr, float beta1, float beta2, float eps, int32_t step, float* adam_m_dev,
+                              float* adam_v_dev, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
     if (!params_dev || !obs_dev || !act_dev || !logp_old_dev || !rtg_dev || !adv_dev || !grad_dev || !stats_dev ||
-        !workspace_dev || !adam_m_dev || !adam_v_dev || n_samples < 1 || !(var > 0.f) || step < 1) {
-        g_err = "navppo_mlp64_update_epoch: bad argument";
+        !workspace_dev || !adam_m_dev || !adam_v_dev || n_samples < 1 || !(var > 0.f) || step < 1 || (obs_dim != 16 && obs_dim != 42)) {
+        g_err = "navppo_mlp64_update_epoch: bad argument (obs_dim is 16 or 42)";
         return -1;
     }
-    if (((uintptr_t)obs_dev & 15) || ((uintptr_t)act_dev & 7)) {
-        g_err = "navppo_mlp64_update_epoch: obs must be 16-byte and act 8-byte aligned";
+    if (!obs_aligned(obs_dev, obs_dim, obs_f16) || ((uintptr_t)act_dev & 7)) {
+        g_err = "navppo_mlp64_update_epoch: obs must be 16-byte (42 columns: 8-byte, float16: 4-byte) and act 8-byte aligned";
         return -1;
     }
     hipStream_t st = (hipStream_t)stream;
-    float* partial = reinterpret_cast<float*>(workspace_dev);
-    float* stats_partial = partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * NAVPPO_MLP64_ACTOR_PARAMS;
-    const float inv_n = 1.0f / (float)n_samples;
-    const long long wtiles = (n_samples + 31) / 32;
-    const long long want = (wtiles + kWWaves - 1) / kWWaves;
-    const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
+    const PassPlan pl = plan_pass(workspace_dev, n_samples, obs_dim);
     const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
     const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
-    float* partial_c = partial + (size_t)kWMaxBlocks * P_ACTOR;        // the workspace has NAVPPO_MLP64_MAX_BLOCKS = 2 kWMaxBlocks rows
-    float* stats_partial_c = stats_partial + (size_t)kWMaxBlocks * 4;
-    hipLaunchKernelGGL(mlp64_pass_both, dim3(blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev,
-                       adv_dev, (long long)n_samples, var, clip, inv_n, partial, stats_partial, partial_c, stats_partial_c, grad_dev,
-                       stats_dev);
-    hipLaunchKernelGGL(reduce_adam<true>, dim3((P_ACTOR + P_CRITIC + 63) / 64), dim3(64 * kRedGroups), 0, st, partial, stats_partial, partial_c,
-                       stats_partial_c, blocks, inv_n, grad_dev, stats_dev, params_dev, adam_m_dev, adam_v_dev, lr, beta1, beta2, eps,
-                       bc1, bc2_sqrt);
+    for_obs(obs_dim, obs_f16, [&](auto in, auto f16) {
+        hipLaunchKernelGGL((mlp64_pass_both<decltype(in)::value, decltype(f16)::value>), dim3(pl.blocks), dim3(kWThreads), 0, st, params_dev,
+                           obs_dev, act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, pl.inv_n, pl.partial,
+                           pl.stats_partial, pl.partial_c, pl.stats_partial_c, grad_dev, stats_dev);
+    });
+    hipLaunchKernelGGL(reduce_adam<true>, dim3((pl.pa + pl.pc + 63) / 64), dim3(64 * kRedGroups), 0, st, pl.partial, pl.stats_partial,
+                       pl.partial_c, pl.stats_partial_c, pl.blocks, pl.inv_n, grad_dev, stats_dev, params_dev, adam_m_dev, adam_v_dev, lr,
+                       beta1, beta2, eps, bc1, bc2_sqrt, pl.pa, pl.pc, 0, pl.pa + pl.pc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_update_epoch: ") + hipGetErrorString(e);
@@ -885,20 +1073,23 @@ int navppo_episode_sums(const uint8_t* ended_dev, const uint8_t* arrive_dev, con
     return 0;
 }
 
-int navppo_mlp64_act(const float* actor_params_dev, const float* obs_dev, const float* noise_dev, int64_t n_envs,
-                     const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
+int navppo_mlp64_act(const float* actor_params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16, const float* noise_dev,
+                     int64_t n_envs, const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
                      uint32_t step_offset, float* act_dev, float* logp_dev, float* mean_dev, void* stream) {
-    if (!actor_params_dev || !obs_dev || !act_dev || !logp_dev || n_envs < 1 || !var_dev) {
-        g_err = "navppo_mlp64_act: bad argument";
+    if (!actor_params_dev || !obs_dev || !act_dev || !logp_dev || n_envs < 1 || !var_dev || (obs_dim != 16 && obs_dim != 42)) {
+        g_err = "navppo_mlp64_act: bad argument (obs_dim is 16 or 42)";
         return -1;
     }
-    if (((uintptr_t)actor_params_dev & 15) || ((uintptr_t)obs_dev & 15)) {
-        g_err = "navppo_mlp64_act: params and obs must be 16-byte aligned";
+    if (((uintptr_t)actor_params_dev & 15) || !obs_aligned(obs_dev, obs_dim, obs_f16)) {
+        g_err = "navppo_mlp64_act: params must be 16-byte aligned, obs 16-byte (42 columns: 8-byte, float16: 4-byte)";
         return -1;
     }
     const int blocks = (int)((n_envs + kActEnvs - 1) / kActEnvs);
-    hipLaunchKernelGGL(mlp64_act, dim3(blocks), dim3(64), 0, (hipStream_t)stream, actor_params_dev, obs_dev, noise_dev,
-                       (long long)n_envs, var_dev, seed, env_id_base, step_base_dev, step_offset, act_dev, logp_dev, mean_dev);
+    for_obs(obs_dim, obs_f16, [&](auto in, auto f16) {
+        hipLaunchKernelGGL((mlp64_act<decltype(in)::value, decltype(f16)::value>), dim3(blocks), dim3(64), 0, (hipStream_t)stream,
+                           actor_params_dev, obs_dev, noise_dev, (long long)n_envs, var_dev, seed, env_id_base, step_base_dev, step_offset,
+                           act_dev, logp_dev, mean_dev);
+    });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_act: ") + hipGetErrorString(e);

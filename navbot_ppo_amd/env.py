@@ -11,13 +11,14 @@ PyTorch is used for device memory and streams only; all simulation happens in th
 """
 import ctypes as C
 import math
+import os
 import types
 
 import numpy as np
 import torch
 
 from . import maps as _maps
-from ._native import NavsimCfg, NavsimError, check, lib
+from ._native import NavsimCfg, NavsimError, NavsimInfo, check, lib
 
 __all__ = ["NavSim", "VecEnv", "Env", "NavsimError", "rtg_scan", "gae_scan"]
 
@@ -39,7 +40,11 @@ class NavSim:
 
     def __init__(self, n_envs, n_beams=10, max_episode_steps=0, auto_reset=False, respawn_on_arrive=False,
                  seed=0, env_id_base=0, threshold_arrive=0.2, spawn=(0.0, 0.0, 0.0), goal_box=(-3.6, 3.6),
-                 obs_f16=False, device=None, lidar_below_min="clamp", lidar_noise_sigma=0.0):
+                 obs_f16=False, device=None, lidar_below_min="clamp", lidar_noise_sigma=0.0, envs_per_workgroup=None,
+                 pair_cast=None):
+        """envs_per_workgroup / pair_cast: kernel-shape overrides of THIS handle (navsim_set_shape; tests and A/B timing --
+        results never depend on them).  None = the dev tools' NAVSIM_EPB / NAVSIM_PAIR_CAST environment variables if set
+        (read here, per handle; libnavsim itself reads nothing from the environment), else the built-in rule."""
         if not torch.cuda.is_available():
             raise NavsimError("navbot_ppo_amd needs a HIP device (MI355X); there is no CPU path")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -54,6 +59,24 @@ class NavSim:
             check(lib().navsim_create(C.byref(self.cfg), C.byref(self._h)), "navsim_create")
         self._seg = None  # keeps the map tensor alive: the handle only borrows the pointer
         self.generation = 0  # bumped whenever device pointers / scalars a captured hipGraph would have frozen change
+        if envs_per_workgroup is None and os.environ.get("NAVSIM_EPB"):
+            envs_per_workgroup = int(os.environ["NAVSIM_EPB"])
+        if pair_cast is None and os.environ.get("NAVSIM_PAIR_CAST"):
+            pair_cast = int(os.environ["NAVSIM_PAIR_CAST"]) != 0
+        if envs_per_workgroup is not None or pair_cast is not None:
+            self.set_shape(envs_per_workgroup or 0, pair_cast)
+
+    def set_shape(self, envs_per_workgroup=0, pair_cast=None):
+        """navsim_set_shape: force the workgroup shape (0 = rule; 4 | 8 | 16 | 32 | 64) / the 128-segment passes of this handle."""
+        check(lib().navsim_set_shape(self._h, int(envs_per_workgroup), -1 if pair_cast is None else int(bool(pair_cast))),
+              "navsim_set_shape")
+        self.generation += 1   # a captured hipGraph froze the old instantiation
+
+    def info(self):
+        """navsim_get_info as a dict: handle facts + the (envs, waves, cast variant) each entry point launches right now."""
+        inf = NavsimInfo()
+        check(lib().navsim_get_info(self._h, C.byref(inf)), "navsim_get_info")
+        return {n: getattr(inf, n) for n, _ in NavsimInfo._fields_ if n != "reserved"}
 
     def close(self):
         if getattr(self, "_h", None):
@@ -114,13 +137,46 @@ class NavSim:
             ep_path=torch.zeros(N, dtype=torch.float32, device=dev))
 
     # -- calls (all asynchronous on torch's current stream)
+    # The C ABI takes raw device pointers and cannot know what is behind them: every tensor is checked HERE -- device, dtype,
+    # element count, contiguity -- before its data_ptr() crosses the boundary (a float32 buffer handed to an f16 handle, or rows of
+    # the wrong width, would otherwise be overwritten or overrun silently).
+    def _chk(self, name, t, dtype, numel, optional=False):
+        if t is None:
+            if optional:
+                return
+            raise NavsimError(f"{name}: required")
+        if not torch.is_tensor(t) or t.device != self.device:
+            raise NavsimError(f"{name}: expected a tensor on {self.device}, got {getattr(t, 'device', type(t))}")
+        if t.dtype != dtype:
+            raise NavsimError(f"{name}: expected {dtype}, got {t.dtype}"
+                              + (" (this handle writes float16 observations: obs_f16=True)" if dtype == torch.float16 else ""))
+        if t.numel() != numel or not t.is_contiguous():
+            raise NavsimError(f"{name}: expected {numel} contiguous elements, got shape {tuple(t.shape)}"
+                              f"{'' if t.is_contiguous() else ' (not contiguous)'}")
+
+    def _chk_step_io(self, rows, obs, reward, done, arrive, ended, ep_return, ep_length, ep_path, what):
+        n = rows * self.N
+        self._chk(f"{what}: obs", obs, self.obs_dtype, n * self.D)
+        self._chk(f"{what}: reward", reward, torch.float32, n)
+        self._chk(f"{what}: done", done, torch.uint8, n)
+        self._chk(f"{what}: arrive", arrive, torch.uint8, n)
+        self._chk(f"{what}: ended", ended, torch.uint8, n, optional=True)
+        self._chk(f"{what}: ep_return", ep_return, torch.float32, n, optional=True)
+        self._chk(f"{what}: ep_length", ep_length, torch.int32, n, optional=True)
+        self._chk(f"{what}: ep_path", ep_path, torch.float32, n, optional=True)
+
     def reset(self, obs, mask=None):
+        self._chk("reset: obs", obs, self.obs_dtype, self.N * self.D)
+        self._chk("reset: mask", mask, torch.uint8, self.N, optional=True)
         with torch.cuda.device(self.device):
             check(lib().navsim_reset(self._h, _ptr(mask), _ptr(obs), _stream()), "navsim_reset")
         return obs
 
     def step(self, action, obs, reward, done, arrive, ended=None, ep_return=None, ep_length=None, past_action=None,
              ep_path=None):
+        self._chk("step: action", action, torch.float32, 2 * self.N)
+        self._chk("step: past_action", past_action, torch.float32, 2 * self.N, optional=True)
+        self._chk_step_io(1, obs, reward, done, arrive, ended, ep_return, ep_length, ep_path, "step")
         with torch.cuda.device(self.device):
             check(lib().navsim_step(self._h, _ptr(action), _ptr(past_action), _ptr(obs), _ptr(reward), _ptr(done),
                                     _ptr(arrive), _ptr(ended), _ptr(ep_return), _ptr(ep_length), _ptr(ep_path), _stream()),
@@ -132,9 +188,10 @@ class NavSim:
         observations they produce (recorded tapes, scripted / random policies): the workgroups keep their envs on chip
         between the steps, so the launch ramp and the kernel boundaries of T launches are paid once."""
         T = int(actions.shape[0])
-        assert actions.shape == (T, self.N, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
-        for buf in (obs, reward, done, arrive, ended, ep_return, ep_length, ep_path):
-            assert buf is None or (buf.shape[0] == T and buf.shape[1] == self.N and buf.is_contiguous())
+        if tuple(actions.shape) != (T, self.N, 2):
+            raise NavsimError(f"step_seq: actions must be [T, {self.N}, 2], got {tuple(actions.shape)}")
+        self._chk("step_seq: actions", actions, torch.float32, 2 * T * self.N)
+        self._chk_step_io(T, obs, reward, done, arrive, ended, ep_return, ep_length, ep_path, "step_seq")
         with torch.cuda.device(self.device):
             check(lib().navsim_step_seq(self._h, _ptr(actions), T, _ptr(obs), _ptr(reward), _ptr(done), _ptr(arrive), _ptr(ended),
                                         _ptr(ep_return), _ptr(ep_length), _ptr(ep_path), _stream()), "navsim_step_seq")
@@ -230,12 +287,12 @@ class VecEnv:
 
     def __init__(self, n_envs, map="stage_1", n_beams=10, max_episode_steps=500, auto_reset=True, is_training=True,
                  seed=0, env_id_base=0, per_env_map=False, map_seed=0, obs_f16=False, device=None, sampler=None,
-                 lidar_below_min="clamp", lidar_noise_sigma=0.0, respawn_on_arrive=False):
+                 lidar_below_min="clamp", lidar_noise_sigma=0.0, respawn_on_arrive=False, envs_per_workgroup=None, pair_cast=None):
         thr = 0.2 if is_training else 0.4  # environment_new.py:44-47
         self.sim = NavSim(n_envs, n_beams=n_beams, max_episode_steps=max_episode_steps, auto_reset=auto_reset,
                           respawn_on_arrive=respawn_on_arrive, seed=seed, env_id_base=env_id_base, threshold_arrive=thr,
                           obs_f16=obs_f16, device=device, lidar_below_min=lidar_below_min,
-                          lidar_noise_sigma=lidar_noise_sigma)
+                          lidar_noise_sigma=lidar_noise_sigma, envs_per_workgroup=envs_per_workgroup, pair_cast=pair_cast)
         self.N, self.B, self.D, self.device = self.sim.N, self.sim.B, self.sim.D, self.sim.device
         self.threshold_arrive = thr
         self.use_vision = False
@@ -286,22 +343,25 @@ class VecEnv:
 
 
     def rollout_mlp64(self, actor_params, n_steps, var, seed=0, step_base=0, obs0=None):
-        """PPO.rollout's hot loop (ppo.py:505-594) for the 16-64-64 policy in ONE launch (navsim_rollout_mlp64): per step
+        """PPO.rollout's hot loop (ppo.py:505-594) for the (B + 6)-64-64 policy in ONE launch (navsim_rollout_mlp64): per step
         PPO.get_action (ppo.py:673-706) on the observation the previous step left on chip, then the env step.
-        actor_params: flat float32 device tensor [5378] in nn.Module.named_parameters order (include/navppo.h); var: exploration
-        variance (float or device scalar); action noise = Philox(seed, global env id, step_base + t).  obs0 [N, 16]: the observations
-        to start from (default: a fresh reset).  Returns a namespace: obs [T + 1, N, 16] (row 0 = obs0), act [T, N, 2], logp / reward /
-        done / arrive / ended / ep_return / ep_length / ep_path [T, N] -- bit-identical to T pairs of navppo_mlp64_act / step calls."""
+        actor_params: flat float32 device tensor [5378] (10 beams) / [7042] (36 beams) in nn.Module.named_parameters order
+        (include/navppo.h); var: exploration variance (float or device scalar); action noise = Philox(seed, global env id,
+        step_base + t).  obs0 [N, B + 6]: the observations to start from (default: a fresh reset).  Returns a namespace: obs
+        [T + 1, N, B + 6] (row 0 = obs0; float16 on an obs_f16 env), act [T, N, 2], logp / reward / done / arrive / ended /
+        ep_return / ep_length / ep_path [T, N] -- bit-identical to T pairs of navppo_mlp64_act / step calls."""
         import ctypes as C
         from ._native import check, lib
-        if self.B != 10 or self.sim.obs_dtype != torch.float32:
-            raise NavsimError("rollout_mlp64 needs 10 beams and float32 observations")
-        T, N, dev = int(n_steps), self.N, self.device
+        if self.B not in (10, 36):
+            raise NavsimError("rollout_mlp64 needs 10 or 36 beams")
+        T, N, D, dev = int(n_steps), self.N, self.D, self.device
+        n_actor = 64 * D + 64 + 64 * 64 + 64 + 2 * (64 + 1)
         prm = actor_params.to(device=dev, dtype=torch.float32).contiguous()
-        if prm.numel() != 5378 or prm.data_ptr() % 16:
-            raise NavsimError("actor_params: 5378 float32 values, 16-byte aligned")
+        if prm.numel() != n_actor or prm.data_ptr() % 16:
+            raise NavsimError(f"actor_params: {n_actor} float32 values, 16-byte aligned")
         out = types.SimpleNamespace(
-            obs=torch.empty((T + 1, N, 16), device=dev), act=torch.empty((T, N, 2), device=dev), logp=torch.empty((T, N), device=dev),
+            obs=torch.empty((T + 1, N, D), dtype=self.sim.obs_dtype, device=dev), act=torch.empty((T, N, 2), device=dev),
+            logp=torch.empty((T, N), device=dev),
             reward=torch.empty((T, N), device=dev), done=torch.empty((T, N), dtype=torch.uint8, device=dev),
             arrive=torch.empty((T, N), dtype=torch.uint8, device=dev), ended=torch.empty((T, N), dtype=torch.uint8, device=dev),
             ep_return=torch.zeros((T, N), device=dev), ep_length=torch.zeros((T, N), dtype=torch.int32, device=dev),
@@ -370,6 +430,7 @@ class Env:
         self._pin = torch.zeros(48, dtype=torch.float32).pin_memory()
         self._pin_u8 = torch.zeros(16, dtype=torch.uint8).pin_memory()
         self._pin_np, self._pin_u8_np = self._pin.numpy(), self._pin_u8.numpy()
+        self._pin_i32 = self._pin_np.view(np.int32)   # the same block as bit patterns (the "not delivered yet" marker below)
         self._act_t, self._past_t = self._pin[0:2].view(1, 2), self._pin[2:4].view(1, 2)
         self._obs_t, self._rew_t = self._pin[16:32].view(1, 16), self._pin[32:33]
         self._done_t, self._arrive_t, self._ended_t = self._pin_u8[0:1], self._pin_u8[1:2], self._pin_u8[2:3]
@@ -377,7 +438,8 @@ class Env:
         # One env step from Python is launch-latency bound (kernel 6 us, the rest is the way there and back): the argument list of
         # navsim_step / navsim_reset is built ONCE -- ctypes pointers of the pinned block, the stream the env was created on -- so
         # that a step is one foreign call and one wait (building twelve c_void_p objects, looking up the current stream and
-        # entering a device context per step were 5 of the 25 us).
+        # entering a device context per step were 5 of the 25 us).  The stream is therefore FROZEN at construction: an Env built
+        # under torch.cuda.stream(s) launches on s for its whole life (as do its attribute reads, which wait on that stream).
         dev = self._sim.device
         self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         self._stream_obj = torch.cuda.current_stream(dev)
@@ -391,7 +453,8 @@ class Env:
     #    navsim_get_state per step at most, and none at all for callers that never look
     def _st(self):
         if self._state is None:
-            self._state = self._sim.get_state()
+            with torch.cuda.stream(self._stream_obj):   # the stream the steps were launched on (frozen at construction)
+                self._state = self._sim.get_state()
         return self._state
 
     @property
@@ -418,27 +481,34 @@ class Env:
         self._stream_obj.synchronize()
 
     # A step's results are waited for where they land.  The pinned block is host-coherent memory: the kernel's stores reach it while
-    # the kernel runs, so the caller plants a value the kernel never writes in every output slot (NaN in the reward and the
-    # observation, 0xFF in the flags) and polls until all of them are gone -- each slot checked for itself, no assumption on the
-    # order the stores arrive in.  Measured (tools/time_env_n1_parts.py): launch + stream.synchronize() 23.5 us, launch + this 14.1 us.
+    # the kernel runs, so the caller plants a bit pattern the kernel never writes in every output slot -- _PLANT, a quiet NaN with a
+    # payload no arithmetic produces (a diverged policy's NaN observation or reward is the canonical 0x7fc00000 / a propagated
+    # input payload, and is returned to the caller like the reference's Env.step returns it), 0xFF in the flags -- and polls until
+    # all of them are gone, each slot checked for itself, no assumption on the order the stores arrive in.
+    # Measured (tools/time_env_n1_parts.py): launch + stream.synchronize() 23.5 us, launch + this 14.1 us.
     # A step that has not delivered after _POLLS polls (a stalled queue, a fault) falls back to the stream wait, which reports it.
+    # The poll returns when the RESULTS have landed, which can be before the kernel has retired: later readers of the handle's
+    # device state are ordered behind it by the stream (get_state and every other call run on the stream the Env was built on).
     _POLLS = 1 << 20
+    _PLANT = np.int32(0x7FC0DEAD)
 
     def _plant(self):
-        self._pin_np[16:33] = np.nan
+        self._pin_i32[16:33] = self._PLANT
         self._pin_u8_np[0:3] = 255
 
     def _wait_results(self, obs_only=False):
-        pin, u8 = self._pin_np, self._pin_u8_np
+        pin, u8, plant = self._pin_i32, self._pin_u8_np, self._PLANT
         for _ in range(self._POLLS):
-            if pin[31] == pin[31] and (obs_only or (pin[32] == pin[32] and u8[0] != 255 and u8[1] != 255 and u8[2] != 255)) \
-                    and not np.isnan(pin[16:32]).any():
+            if pin[31] != plant and (obs_only or (pin[32] != plant and u8[0] != 255 and u8[1] != 255 and u8[2] != 255)) \
+                    and not (pin[16:32] == plant).any():
                 return
         self._wait()
-        if np.isnan(pin[16:32]).any() or (not obs_only and (pin[32] != pin[32] or (u8[0:3] == 255).any())):
+        if (pin[16:32] == plant).any() or (not obs_only and (pin[32] == plant or (u8[0:3] == 255).any())):
             raise RuntimeError("the launch finished without delivering its results to the pinned block")
 
     def _call(self, fn, args, what):
+        if args is None:
+            raise NavsimError(f"{what}: the env is closed")
         if torch.cuda.current_device() == self._dev_index:
             check(fn(*args), what)
         else:
@@ -446,7 +516,7 @@ class Env:
                 check(fn(*args), what)
 
     def reset(self):
-        self._pin_np[16:32] = np.nan
+        self._pin_i32[16:32] = self._PLANT
         self._call(self._lib.navsim_reset, self._reset_args, "navsim_reset")
         self._wait_results(obs_only=True)
         self._state = None
@@ -470,4 +540,5 @@ class Env:
         return None
 
     def close(self):
+        self._step_args = self._reset_args = None   # they hold the native handle: a step after close() raises instead of using it
         self._sim.close()

@@ -214,18 +214,21 @@ class PPOUpdater:
         self.stats = {}
         # HIP paths: fused f32-MFMA kernels instead of ~40 (mlp64x2) / ~120 (resmlp512) PyTorch kernels per epoch
         on_gpu = self.device.type == "cuda" and cfg.fused_update
+        # the D-64-64 heads: D = 16 (10 beams) or 42 (36 beams), rows float32 or float16 (obs_f16 envs) -- include/navppo.h
         self.fused_mlp64 = (on_gpu and cfg.policy == "mlp64x2" and isinstance(actor, nets.MLP64Actor)
-                            and actor.layer1.in_features == 16)
+                            and actor.layer1.in_features in (16, 42))
+        self.obs_dim = actor.layer1.in_features if isinstance(actor, nets.MLP64Actor) else actor.rb1.f_in
         self.fused_resmlp512 = (on_gpu and cfg.policy == "resmlp512" and isinstance(actor, nets.ResMLPActor)
                                 and actor.rb1.f_in == 16 and actor.rb1.fc1.out_features == 512)
         self.fused = "navppo_mlp64" if self.fused_mlp64 else "navppo_resmlp512" if self.fused_resmlp512 else None
         if self.fused:
             from ._native import lib
             self._n_actor = self.fp.module_numel[0]
-            assert tuple(self.fp.module_numel) == ((5378, 5313) if self.fused_mlp64 else (50290, 50257))
+            d = self.obs_dim
+            assert tuple(self.fp.module_numel) == ((64 * d + 4354, 64 * d + 4289) if self.fused_mlp64 else (50290, 50257))
             self._ws = None
             if self.fused_mlp64:
-                self._ws = torch.empty(lib().navppo_mlp64_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
+                self._ws = torch.empty(lib().navppo_mlp64_workspace_bytes(d) // 4, dtype=torch.float32, device=self.device)
             self._fstats = torch.zeros(8, dtype=torch.float32, device=self.device)
             self._fhist = torch.zeros((max(cfg.n_updates_per_iteration, 1), 8), dtype=torch.float32, device=self.device)
             # single GPU: Adam runs inside the kernel that sums the partial gradients (navppo_*_update_epoch)
@@ -243,6 +246,17 @@ class PPOUpdater:
                 self._ws = torch.empty(need, dtype=torch.float32, device=self.device)
         return self._ws
 
+    def _obs_args(self, obs):
+        """The observation arguments of the fused entry points: (pointer[, obs_dim, obs_f16]) after checking what is behind the
+        pointer -- rows of self.obs_dim columns, float32 (or float16 for the D-64-64 heads, which widen half rows as they load)."""
+        import ctypes as C
+        ok = (torch.float32, torch.float16) if self.fused_mlp64 else (torch.float32,)
+        if obs.dim() != 2 or obs.shape[1] != self.obs_dim or obs.dtype not in ok or not obs.is_contiguous():
+            raise ValueError(f"{self.fused}: observations must be contiguous [n, {self.obs_dim}] rows of {ok}, got "
+                             f"{tuple(obs.shape)} {obs.dtype}")
+        p = C.c_void_p(obs.data_ptr())
+        return (p, self.obs_dim, int(obs.dtype == torch.float16)) if self.fused_mlp64 else (p,)
+
     def _fused_loss_grad(self, obs, acts, logp_old, rtg, adv, var, stats=None):
         """evaluate + losses + backward of ppo.py:307-386 in the HIP kernels of csrc/ppo_mlp64.hip; gradients land
         in the flat gradient buffer, (actor_loss, approx_kl, clip_frac, -, critic_loss) in self._fstats."""
@@ -250,9 +264,9 @@ class PPOUpdater:
         from ._native import lib
         L = lib()
         ptr = lambda t: C.c_void_p(t.data_ptr())
-        for t in (obs, acts, logp_old, rtg, adv):
+        for t in (acts, logp_old, rtg, adv):
             assert t.is_contiguous() and t.dtype == torch.float32
-        rc = getattr(L, self.fused + "_loss_grad")(ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+        rc = getattr(L, self.fused + "_loss_grad")(ptr(self.fp.flat), *self._obs_args(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
                                                    int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad),
                                                    ptr(self._fstats if stats is None else stats), ptr(self._workspace(obs.shape[0])),
                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -265,7 +279,7 @@ class PPOUpdater:
         from ._native import lib
         L = lib()
         ptr = lambda t: C.c_void_p(t.data_ptr())
-        rc = L.navppo_mlp64_loss_grad_net(int(net), ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+        rc = L.navppo_mlp64_loss_grad_net(int(net), ptr(self.fp.flat), *self._obs_args(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
                                           int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad), ptr(stats),
                                           ptr(self._workspace(obs.shape[0])), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
@@ -323,10 +337,10 @@ class PPOUpdater:
         critic = C.c_void_p(self.fp.flat.data_ptr() + 4 * self._n_actor)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if self.fused_resmlp512:
-            rc = L.navppo_resmlp512_value(critic, C.c_void_p(obs.data_ptr()), int(obs.shape[0]), C.c_void_p(out.data_ptr()),
+            rc = L.navppo_resmlp512_value(critic, *self._obs_args(obs), int(obs.shape[0]), C.c_void_p(out.data_ptr()),
                                           C.c_void_p(self._workspace(obs.shape[0]).data_ptr()), st)
         else:
-            rc = L.navppo_mlp64_value(critic, C.c_void_p(obs.data_ptr()), int(obs.shape[0]), C.c_void_p(out.data_ptr()), st)
+            rc = L.navppo_mlp64_value(critic, *self._obs_args(obs), int(obs.shape[0]), C.c_void_p(out.data_ptr()), st)
         if rc != 0:
             raise RuntimeError(f"{self.fused}_value failed: {L.navppo_last_error().decode()}")
         return out
@@ -338,7 +352,7 @@ class PPOUpdater:
         L = lib()
         ptr = lambda t: C.c_void_p(t.data_ptr())
         self._adam_t += 1
-        rc = getattr(L, self.fused + "_update_epoch")(ptr(self.fp.flat), ptr(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+        rc = getattr(L, self.fused + "_update_epoch")(ptr(self.fp.flat), *self._obs_args(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
                                                       int(obs.shape[0]), float(var), float(self.cfg.clip), float(self.cfg.lr), 0.9,
                                                       0.999, 1e-8, int(self._adam_t), ptr(self._adam_m), ptr(self._adam_v),
                                                       ptr(self.fp.grad), ptr(stats), ptr(self._workspace(obs.shape[0])),
@@ -349,9 +363,9 @@ class PPOUpdater:
     def value(self, obs):
         """V = critic(obs).squeeze() (ppo.py:275) for [n, D] rows."""
         with torch.no_grad():
-            if self.fused and obs.is_contiguous() and obs.data_ptr() % 16 == 0:
+            if self.fused and obs.is_contiguous() and obs.data_ptr() % 16 == 0 and (obs.dtype == torch.float32 or self.fused_mlp64):
                 return self._fused_value(obs)
-            return self.critic(obs).squeeze(-1)
+            return self.critic(obs.float()).squeeze(-1)
 
     def update(self, obs, acts, logp_old, rtg, var, adv_raw=None, V0=None):
         """adv_raw / V0: advantages (before normalisation) and values computed by the caller (GAE); default = the reference's
@@ -369,6 +383,8 @@ class PPOUpdater:
         acc = torch.zeros(6, device=obs.device)                # sums over epochs of diagnostics
         self.loss_history = torch.zeros((n_ep, 2), device=obs.device)  # per-epoch (actor, critic) loss, ppo.py:396-397
         var_f = float(var) if self.fused else None
+        if not (self.fused_mlp64 and obs.dtype == torch.float16):
+            obs = obs.float()   # half rows (obs_f16 envs) are consumed as they are by the D-64-64 kernels only
         if self.fused:
             obs, acts, logp_old, rtg, adv = (t.contiguous() for t in (obs, acts, logp_old, rtg, adv))
             if self._fhist.shape[0] < n_ep:
@@ -445,7 +461,12 @@ class PPOTrainer:
         torch.manual_seed(cfg.seed * 1000003 + 17 + rank)  # exploration noise differs per shard
         dev = self.device
         f32, u8 = torch.float32, torch.uint8
-        self.obs_buf = torch.zeros((T + 1, N, D), dtype=f32, device=dev)
+        # the observation rows in the dtype the simulator writes them (float16 on an obs_f16 env: BASELINE configs[4]); half rows
+        # are read directly by the D-64-64 kernels, every other consumer (PyTorch policies, the 512-wide kernels) widens them
+        self.obs_buf = torch.zeros((T + 1, N, D), dtype=env.sim.obs_dtype, device=dev)
+        self._half_obs = env.sim.obs_dtype == torch.float16
+        if self._half_obs and self.updater.fused_resmlp512:
+            raise ValueError("resmlp512 fused kernels read float32 rows: build the VecEnv with obs_f16=False, or use policy='mlp64x2'")
         self.act_buf = torch.zeros((T, N, 2), dtype=f32, device=dev)
         self.logp_buf = torch.zeros((T, N), dtype=f32, device=dev)
         self.rew_buf = torch.zeros((T, N), dtype=f32, device=dev)
@@ -476,7 +497,7 @@ class PPOTrainer:
         from ._native import lib
         ptr = lambda x: None if x is None else C.c_void_p(x.data_ptr())
         L = lib()
-        rc = getattr(L, self.updater.fused + "_act")(ptr(self.updater.fp.flat), ptr(self.obs_buf[t]), ptr(noise), self.env.N,
+        rc = getattr(L, self.updater.fused + "_act")(ptr(self.updater.fp.flat), *self.updater._obs_args(self.obs_buf[t]), ptr(noise), self.env.N,
                                                      ptr(self.var), self._act_seed, self._env_id_base, ptr(self._step_base), t,
                                                      ptr(self.act_buf[t]), ptr(self.logp_buf[t]), None,
                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -490,7 +511,7 @@ class PPOTrainer:
             self.env.sim.step(self.act_buf[t], self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.arrive_buf[t],
                               self.ended_buf[t], self.epret_buf[t], self.eplen_buf[t], ep_path=self.eppath_buf[t])
             return
-        obs = self.obs_buf[t]
+        obs = self.obs_buf[t].float()
         mean = self.actor(obs)
         std = torch.sqrt(self.var)
         raw = torch.addcmul(mean, torch.randn_like(mean), std)          # dist.sample(), ppo.py:698
@@ -531,10 +552,12 @@ class PPOTrainer:
         # shared maps of 65..4096 segments carry tile bounding boxes (navsim_set_map); up to 4096 envs per GPU only the per-step
         # kernel's BOXES instantiation uses them to skip whole tiles, so there the hipGraph of per-step launches is the faster
         # rollout (beyond 4096 envs navsim_rollout_mlp64 runs rollout_big_kernel, which has the cast variants of the step kernel)
-        tile_boxes = ((not getattr(sim, "per_env", False)) and 65 <= getattr(sim, "S", 0) <= 4096
-                      and self.env.N <= 4096 and os.environ.get("NAVSIM_EPB") != "64")
-        if (cfg.persistent_rollout and self.updater.fused_mlp64 and self.env.B == 10
-                and sim.obs_dtype == torch.float32 and not tile_boxes):
+        tile_boxes = False
+        # (navsim_get_info names the kernel navsim_rollout_mlp64 would launch: kind 1 = the 16-env shape, cast without tile boxes)
+        if cfg.persistent_rollout and self.updater.fused_mlp64:
+            inf = sim.info()
+            tile_boxes = bool(inf["tile_boxes"]) and inf["rollout_kind"] == 1
+        if cfg.persistent_rollout and self.updater.fused_mlp64 and self.env.B in (10, 36) and not tile_boxes:
             self._persistent_rollout()
         elif cfg.use_graph and self.device.type == "cuda":
             if self._graph is not None and self._graph_gen != self.env.sim.generation:

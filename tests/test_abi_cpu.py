@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     bound = {n for n, _, _ in _native.SYMBOLS}
     assert set(declared) == bound, (set(declared) ^ bound)
-    assert lib.navsim_version() == 4
+    assert lib.navsim_version() == 5
 
 
 def test_default_cfg_matches_reference_constants():
@@ -65,3 +65,18 @@ def test_product_never_imports_the_oracle():
             txt = open(os.path.join(root, f), errors="ignore").read() if f.endswith((".py", ".hip", ".h")) else ""
             assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), (root, f)
             assert not re.search(r"#include.*oracle|libnavsim_oracle", txt), (root, f)
+
+
+def test_library_reads_no_shape_knobs_from_the_environment():
+    """The workgroup-shape overrides are per-handle state (navsim_set_shape, reported by navsim_get_info): nothing in
+    navsim_create -- or anywhere else in the library -- may read NAVSIM_EPB / NAVSIM_PAIR_CAST from the process environment
+    (a later handle's environment used to change the kernel shape of every earlier handle)."""
+    src = open(os.path.join(REPO, "navbot_ppo_amd", "csrc", "navsim.hip")).read()
+    code = re.sub(r"//[^\n]*", "", src)
+    assert "NAVSIM_EPB" not in code and "NAVSIM_PAIR_CAST" not in code
+    assert not re.search(r"\bg_epb\b|\bg_pair_cast\b", code)
+    from navbot_ppo_amd import _native
+    L = _native.lib()
+    # argument checks run without a device
+    assert L.navsim_set_shape(None, 16, -1) != 0
+    assert L.navsim_get_info(None, None) != 0

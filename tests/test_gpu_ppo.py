@@ -156,7 +156,7 @@ def test_fused_act_matches_pytorch_policy_step():
     ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     L = lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    assert L.navppo_mlp64_act(ptr(up.fp.flat), ptr(obs), ptr(eps), n, ptr(var), 7, 0, None, 0, ptr(act), ptr(lp), ptr(mean), st) == 0
+    assert L.navppo_mlp64_act(ptr(up.fp.flat), ptr(obs), 16, 0, ptr(eps), n, ptr(var), 7, 0, None, 0, ptr(act), ptr(lp), ptr(mean), st) == 0
     with torch.no_grad():
         m_ref = a(obs)
         raw = m_ref + torch.sqrt(var) * eps
@@ -171,14 +171,14 @@ def test_fused_act_matches_pytorch_policy_step():
     act, lp, mean = torch.empty((N, 2), device=dev), torch.empty(N, device=dev), torch.empty((N, 2), device=dev)
     big = torch.tensor(1e-4, device=dev)  # tiny variance: nothing clamps except at the sigmoid/tanh edges
     sb = torch.tensor(5, dtype=torch.int32, device=dev)
-    assert L.navppo_mlp64_act(ptr(up.fp.flat), ptr(obs), None, N, ptr(big), 9, 0, ptr(sb), 2, ptr(act), ptr(lp), ptr(mean), st) == 0
+    assert L.navppo_mlp64_act(ptr(up.fp.flat), ptr(obs), 16, 0, None, N, ptr(big), 9, 0, ptr(sb), 2, ptr(act), ptr(lp), ptr(mean), st) == 0
     e = ((act - mean) / 1e-2).cpu().numpy()
     ok = (np.abs(e) < 6).all(axis=1) & (act[:, 0].cpu().numpy() > 0) & (act[:, 0].cpu().numpy() < 1) & (np.abs(act[:, 1].cpu().numpy()) < 1)
     e = e[ok]
     assert ok.mean() > 0.9 and abs(e.mean()) < 0.02 and abs(e.std() - 1) < 0.02 and abs(np.corrcoef(e[:, 0], e[:, 1])[0, 1]) < 0.02
     act2 = torch.empty((N // 2, 2), device=dev)
     sb7 = torch.tensor(7, dtype=torch.int32, device=dev)
-    assert L.navppo_mlp64_act(ptr(up.fp.flat), ptr(obs[N // 2:].contiguous()), None, N // 2, ptr(big), 9, N // 2, ptr(sb7), 0,
+    assert L.navppo_mlp64_act(ptr(up.fp.flat), ptr(obs[N // 2:].contiguous()), 16, 0, None, N // 2, ptr(big), 9, N // 2, ptr(sb7), 0,
                               ptr(act2), ptr(lp), None, st) == 0
     assert torch.equal(act2, act[N // 2:])  # same (seed, global env id, step) -> same draw on another shard
 

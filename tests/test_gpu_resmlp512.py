@@ -200,7 +200,7 @@ def test_fused_resmlp512_act_matches_pytorch_policy_step():
     a64.to(dev), c64.to(dev)
     up64 = ppo.PPOUpdater(a64, c64, ppo.PPOConfig(policy="mlp64x2"), None, dev)
     act2, lp2, mean2 = torch.empty((N, 2), device=dev), torch.empty(N, device=dev), torch.empty((N, 2), device=dev)
-    assert L.navppo_mlp64_act(ptr(up64.fp.flat), ptr(obs), None, N, ptr(tiny), 9, 64, ptr(sb), 2, ptr(act2), ptr(lp2), ptr(mean2), st) == 0
+    assert L.navppo_mlp64_act(ptr(up64.fp.flat), ptr(obs), 16, 0, None, N, ptr(tiny), 9, 64, ptr(sb), 2, ptr(act2), ptr(lp2), ptr(mean2), st) == 0
     e2 = ((act2 - mean2) / 1e-2).cpu().numpy()
     ok = ((act > 1e-3) & (act < 1 - 1e-3)).all(1).cpu().numpy() & ((act2 > 1e-3) & (act2 < 1 - 1e-3)).all(1).cpu().numpy()
     assert ok.mean() > 0.3
