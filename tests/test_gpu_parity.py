@@ -375,10 +375,12 @@ def test_errors_are_reported_not_swallowed():
         s.set_map(np.zeros((3, 5), dtype=np.float32))
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg5"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg5", "cfg4_full", "cfg5_full"])
 def test_full_size_properties(cfg):
     """BASELINE sizes -- configs[1] 4096 shared stage_1 ; configs[2] 16384 per-env stage_2 ; configs[3] per GPU: 4096 envs,
-    stage_4, 36 beams ; configs[4] per GPU: 8192 envs, 2048-segment house map, f16 observations, start/goal tables --
+    stage_4, 36 beams ; configs[4] per GPU: 8192 envs, 2048-segment house map, f16 observations, start/goal tables ; and
+    configs[3] / configs[4] at their FULL size on one GPU (32768 x 36 beams: the 32-env / 36-beam instantiation pick_epb selects
+    beyond 16384 envs; 65536 x house x f16 x tables: the 64-env shape with tile boxes) --
     through size-independent properties:
     * a sample of 96 envs replayed on the oracle matches (flags exact, obs 1e-6; f16: the oracle's row rounded to half)
     * observation ranges of SURVEY A3#10
@@ -392,16 +394,20 @@ def test_full_size_properties(cfg):
     elif cfg == "cfg3":
         N, K, per_env = 16384, 24, True
         seg = maps.replicate_per_env(maps.stage_2(), N, seed=0)
-    elif cfg == "cfg4":
-        N, K, seg, per_env, B = 4096, 60, maps.stage_4(), False, 36
+    elif cfg in ("cfg4", "cfg4_full"):
+        N, K, seg, per_env, B = (4096, 60, maps.stage_4(), False, 36) if cfg == "cfg4" else (32768, 56, maps.stage_4(), False, 36)
     else:
-        N, K, seg, per_env, f16, cap = 8192, 30, maps.house(2048), False, True, 20
+        N, K, seg, per_env, f16, cap = (8192 if cfg == "cfg5" else 65536), 30, maps.house(2048), False, True, 20
         st, g, lo, hi = maps.spawn_tables("small_house")
         sampler = maps.open_tables(seg, st, g) + (lo, hi)
     s = NavSim(N, n_beams=B, max_episode_steps=cap, auto_reset=True, seed=1, obs_f16=f16)
     s.set_map(seg, per_env=per_env)
     if sampler:
         s.set_spawn_sampler(*sampler)
+    inf = s.info()   # the instantiation the rule picks at this size is the one under test
+    want_shape = {"cfg2": (16, 8, 0), "cfg3": (64, 16, 2), "cfg4": (16, 8, 0), "cfg5": (16, 8, 3), "cfg4_full": (32, 8, 0),
+                  "cfg5_full": (64, 16, 3)}[cfg]
+    assert (inf["step_epb"], inf["step_waves"], inf["step_cast"]) == want_shape, inf
     io = s.alloc_io()
     s.reset(io.obs)
     sample = np.sort(rng.choice(N, 96, replace=False))
@@ -717,6 +723,52 @@ def test_g10_reference_rollout_through_the_kernel():
                    float(d["gamma"])).cpu().numpy()[:, 0]
     check_against_g10(d, obs, rew, ended, flags, eplen, epret, eppath, rtg)
     assert int(sim.get_state()["rng_ctr"][0]) == int(d["rng_ctr_final"])
+
+
+@pytest.mark.parametrize("epb", [8, 16, 32])
+def test_workgroup_shapes_keep_parity_36_beams(epb):
+    """The 36-beam instantiations of every workgroup shape (8 / 16 / 32 envs: the rule picks them by shard size -- 32 only beyond
+    16384 envs, configs[3] at full size) forced onto a small ragged shard and run in lock step with the oracle, one launch per
+    step and as a tape (navsim_step_seq rows == the per-step rows bit for bit): shared stage_4 map, per-env maps, the
+    2048-segment house map with tile boxes and start / goal tables, sensor options."""
+    from navbot_ppo_amd.env import NavSim
+    rng = np.random.default_rng(150 + epb)
+    N = 200   # ragged against every shape
+    cases = [(maps.stage_4(), False, {}), (maps.replicate_per_env(maps.stage_2(), N, seed=5), True, {}),
+             (maps.house(1000), False, {}), (maps.stage_4(), False, dict(lidar_noise_sigma=0.01, lidar_below_min="gazebo"))]
+    for k, (seg, per_env, kw) in enumerate(cases):
+        gpu, cpu = _mk(N, seg, per_env=per_env, B=36, max_episode_steps=25, auto_reset=True, seed=6 + k, **kw)
+        gpu.set_shape(epb)
+        samp = None
+        if k == 2:
+            tb = maps.spawn_tables("small_house")
+            samp = maps.open_tables(maps.house(1000), tb[0], tb[1]) + tuple(tb[2:])
+            for s in (gpu, cpu):
+                s.set_spawn_sampler(*samp)
+        inf = gpu.info()
+        assert inf["step_epb"] == epb and inf["seq_epb"] == epb and inf["n_beams"] == 36, inf
+        acts = _actions(rng, 50, N)
+        stats = _lockstep(gpu, cpu, acts)
+        assert stats["ended"] > N // 2
+        # the same tape in one launch on a second handle of the same shape: rows bit-identical to the per-step launches
+        a, b = (NavSim(N, n_beams=36, max_episode_steps=25, auto_reset=True, seed=6 + k, envs_per_workgroup=epb, **kw) for _ in range(2))
+        for s in (a, b):
+            s.set_map(seg, per_env=per_env)
+            if samp:
+                s.set_spawn_sampler(*samp)
+        T = 30
+        at = torch.from_numpy(acts[:T]).cuda()
+        ioa, iob = a.alloc_io(), b.alloc_io()
+        a.reset(ioa.obs)
+        b.reset(iob.obs)
+        out = dict(obs=torch.empty((T, N, 42), device="cuda"), reward=torch.empty((T, N), device="cuda"),
+                   done=torch.empty((T, N), dtype=torch.uint8, device="cuda"), arrive=torch.empty((T, N), dtype=torch.uint8, device="cuda"),
+                   ended=torch.empty((T, N), dtype=torch.uint8, device="cuda"))
+        a.step_seq(at, out["obs"], out["reward"], out["done"], out["arrive"], out["ended"])
+        for t in range(T):
+            b.step(at[t], iob.obs, iob.reward, iob.done, iob.arrive, iob.ended)
+            assert torch.equal(out["obs"][t].view(torch.int32), iob.obs.view(torch.int32)), (k, t)
+            assert torch.equal(out["reward"][t].view(torch.int32), iob.reward.view(torch.int32)) and torch.equal(out["ended"][t], iob.ended)
 
 
 @pytest.mark.parametrize("epb", [8, 32, 64])
