@@ -72,6 +72,7 @@ def build_native(force=False, verbose=False, navsim_src=None, out=None, extra=()
     procs, objs = [], []
     srcs = SRCS if navsim_src is None else [navsim_src] + SRCS[1:]
     lib_out = LIB if out is None else out
+    hdrs = [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h")]
     for k, src in enumerate(srcs):   # the sources compile side by side
         obj = os.path.join(objdir, os.path.basename(SRCS[k]) + ".o")
         per_src = [] if os.environ.get("NAVSIM_NO_EXTRA_FLAGS") == "1" else EXTRA_FLAGS.get(os.path.basename(SRCS[k]), [])   # (A/B builds)
@@ -79,13 +80,22 @@ def build_native(force=False, verbose=False, navsim_src=None, out=None, extra=()
             per_src = []
         cmd = ([hipcc()] + compile_flags + per_src + (list(extra) if k == 0 else []) +
                ["-I", INC, "-I", os.path.join(HERE, "csrc"), "-c", src, "-o", obj])
+        objs.append(obj)
+        # incremental: an object newer than its source, the headers and this file, built by the same command line, is kept
+        stamp = obj + ".cmd"
+        fresh = (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(cmd) and
+                 all(os.path.getmtime(d) < os.path.getmtime(obj) for d in [src, os.path.abspath(__file__)] + hdrs))
+        if fresh:
+            continue
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for cmd, p in procs:
+        if os.path.exists(stamp):
+            os.remove(stamp)
+        procs.append((cmd, subprocess.Popen(cmd), stamp))
+    for cmd, p, stamp in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+        open(stamp, "w").write(" ".join(cmd))
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", lib_out]
     if verbose:
         print(" ".join(cmd))

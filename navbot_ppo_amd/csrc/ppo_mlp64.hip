@@ -654,6 +654,584 @@ __global__ __launch_bounds__(kWThreads) void mlp64_pass_both(const float* __rest
                                      stats_partial_c, grad + Layout<IN>::P_ACTOR, stats + 4);
 }
 
+// ================================================================ the split-bf16 pass ("bf16x3")
+// The same pass -- same tile, same order of operations, float32 results -- with every matrix product evaluated on the bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16: 16 x the contraction depth per unit time of the f32-input MFMA) from
+// operands split into three bf16 pieces:  a = a0 + a1 + a2 EXACTLY (a0 = bf16(a) round-to-nearest-even, a1 = bf16(a - a0),
+// a2 = a - a0 - a1, which has at most 8 significant bits left), and
+//     a b  ~  a2 b0 + a1 b1 + a0 b2 + a1 b0 + a0 b1 + a0 b0          (the three dropped terms are <= 2^-23 |a b|)
+// every bf16 x bf16 product exact in float32, float32 accumulation inside the MFMA.  Order: small terms first -- the five small
+// terms of ALL k-steps of a product, then its a0 b0 terms, then (on the vector unit) the bias -- so only a handful of accumulations
+// happen at the magnitude of the result.  Measured against float64 (tools/design/bf16_split_error.py,
+// profiles/r04_bf16_split_mfma_device.txt, profiles/r05_bf16x3_error.txt): not worse than the f32 MFMA chain on any of the
+// kernel's contraction shapes.  What is split where:
+//   X        once per update by mlp64_split_obs (the observations do not change over the 50 epochs): row-major pieces for F1 (lane =
+//            sample) and tile-transposed pieces for G1 (k = sample)
+//   W1, W2   once per launch into LDS (W2 also transposed for B2), k-permuted to match the accumulator layout (below)
+//   H1, dH2  as B operands of F2 / B2: split in-lane from the accumulator registers -- register r = 8 j + e of lane (m, hi) is row
+//            16 j + 8 (e >> 2) + 4 hi + (e & 3) of its 32-row tile, so k-step (t, j) takes registers 8 j .. 8 j + 7 as ITS eight
+//            k-slots and the weights are stored with the middle two quads of every 16 columns swapped
+//   H1, dH2, dH1  as operands of the weight-gradient products (contraction over samples): through the wave's float32 LDS tiles as
+//            in the f32 kernel (the only transposes), split after the read
+// LDS: weight pieces 55 KB + 8 x 12.25 KB wave tiles (32-float rows, 16-byte slots XOR-swizzled by the row instead of padded).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(const float lo, const float hi) {   // v_cvt_pk_bf16_f32: round to nearest even
+    const f32x2 v = {lo, hi};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
+}
+// (a, b) -> three packed pieces (a in the low half): 11 vector instructions
+__device__ __forceinline__ void split_pair(const float a, const float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+#ifdef X3_EXPERIMENT_NO_SPLIT   // (timing experiment: what the kernel costs without the splitting arithmetic; results are wrong)
+    p0 = __float_as_uint(a); p1 = __float_as_uint(b); p2 = p0 ^ p1;
+    return;
+#endif
+    p0 = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);   // exact
+    p1 = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);   // exact, <= 8 bits left
+    p2 = cvt_pk_bf16(sa, sb);
+}
+struct Pieces {
+    uint4 p[3];   // eight values: piece i, elements (0, 1) (2, 3) (4, 5) (6, 7) as packed pairs
+};
+__device__ __forceinline__ Pieces split8(const float (&v)[8]) {
+    Pieces P;
+    split_pair(v[0], v[1], P.p[0].x, P.p[1].x, P.p[2].x);
+    split_pair(v[2], v[3], P.p[0].y, P.p[1].y, P.p[2].y);
+    split_pair(v[4], v[5], P.p[0].z, P.p[1].z, P.p[2].z);
+    split_pair(v[6], v[7], P.p[0].w, P.p[1].w, P.p[2].w);
+    return P;
+}
+__device__ __forceinline__ bf16x8 as_bf(const uint4 u) {
+    bf16x8 v;
+    __builtin_memcpy(&v, &u, 16);
+    return v;
+}
+#ifdef X3_EXPERIMENT_NO_MFMA   // (timing experiment: the kernel without its MFMAs, operands kept alive; results are wrong)
+#define X3_MFMA32(a, b, c) ([&] { asm volatile("" ::"v"(a), "v"(b)); return c; }())
+#define X3_MFMA16(a, b, c) ([&] { asm volatile("" ::"v"(a), "v"(b)); return c; }())
+#else
+#define X3_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define X3_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+// Two accumulators take turns in every group below (an MFMA that reads the accumulator the MFMA right in front of it writes waits
+// for that result).
+// the five small terms of two products with a common B: acc_t += a2 b0 + a1 b1 + a0 b2 + a1 b0 + a0 b1
+__device__ __forceinline__ void mma5_small2(f32x16& acc0, f32x16& acc1, const Pieces& A0, const Pieces& A1, const Pieces& B) {
+    acc0 = X3_MFMA32(as_bf(A0.p[2]), as_bf(B.p[0]), acc0);
+    acc1 = X3_MFMA32(as_bf(A1.p[2]), as_bf(B.p[0]), acc1);
+    acc0 = X3_MFMA32(as_bf(A0.p[1]), as_bf(B.p[1]), acc0);
+    acc1 = X3_MFMA32(as_bf(A1.p[1]), as_bf(B.p[1]), acc1);
+    acc0 = X3_MFMA32(as_bf(A0.p[0]), as_bf(B.p[2]), acc0);
+    acc1 = X3_MFMA32(as_bf(A1.p[0]), as_bf(B.p[2]), acc1);
+    acc0 = X3_MFMA32(as_bf(A0.p[1]), as_bf(B.p[0]), acc0);
+    acc1 = X3_MFMA32(as_bf(A1.p[1]), as_bf(B.p[0]), acc1);
+    acc0 = X3_MFMA32(as_bf(A0.p[0]), as_bf(B.p[1]), acc0);
+    acc1 = X3_MFMA32(as_bf(A1.p[0]), as_bf(B.p[1]), acc1);
+}
+// the big term: acc += a0 b0
+__device__ __forceinline__ void mma1_big(f32x16& acc, const uint4 a0, const uint4 b0) {
+    acc = X3_MFMA32(as_bf(a0), as_bf(b0), acc);
+}
+// running accumulators (weight gradients: the sum over all tiles is already in them), small terms first; common A
+__device__ __forceinline__ void mma6_acc2(f32x16& acc0, f32x16& acc1, const Pieces& A, const Pieces& B0, const Pieces& B1) {
+    acc0 = X3_MFMA32(as_bf(A.p[2]), as_bf(B0.p[0]), acc0);
+    acc1 = X3_MFMA32(as_bf(A.p[2]), as_bf(B1.p[0]), acc1);
+    acc0 = X3_MFMA32(as_bf(A.p[1]), as_bf(B0.p[1]), acc0);
+    acc1 = X3_MFMA32(as_bf(A.p[1]), as_bf(B1.p[1]), acc1);
+    acc0 = X3_MFMA32(as_bf(A.p[0]), as_bf(B0.p[2]), acc0);
+    acc1 = X3_MFMA32(as_bf(A.p[0]), as_bf(B1.p[2]), acc1);
+    acc0 = X3_MFMA32(as_bf(A.p[1]), as_bf(B0.p[0]), acc0);
+    acc1 = X3_MFMA32(as_bf(A.p[1]), as_bf(B1.p[0]), acc1);
+    acc0 = X3_MFMA32(as_bf(A.p[0]), as_bf(B0.p[1]), acc0);
+    acc1 = X3_MFMA32(as_bf(A.p[0]), as_bf(B1.p[1]), acc1);
+    acc0 = X3_MFMA32(as_bf(A.p[0]), as_bf(B0.p[0]), acc0);
+    acc1 = X3_MFMA32(as_bf(A.p[0]), as_bf(B1.p[0]), acc1);
+}
+// 16 x 16 outputs, K = 32; common B
+__device__ __forceinline__ void mma6_acc16_2(f32x4& acc0, f32x4& acc1, const Pieces& A0, const Pieces& A1, const Pieces& B) {
+    acc0 = X3_MFMA16(as_bf(A0.p[2]), as_bf(B.p[0]), acc0);
+    acc1 = X3_MFMA16(as_bf(A1.p[2]), as_bf(B.p[0]), acc1);
+    acc0 = X3_MFMA16(as_bf(A0.p[1]), as_bf(B.p[1]), acc0);
+    acc1 = X3_MFMA16(as_bf(A1.p[1]), as_bf(B.p[1]), acc1);
+    acc0 = X3_MFMA16(as_bf(A0.p[0]), as_bf(B.p[2]), acc0);
+    acc1 = X3_MFMA16(as_bf(A1.p[0]), as_bf(B.p[2]), acc1);
+    acc0 = X3_MFMA16(as_bf(A0.p[1]), as_bf(B.p[0]), acc0);
+    acc1 = X3_MFMA16(as_bf(A1.p[1]), as_bf(B.p[0]), acc1);
+    acc0 = X3_MFMA16(as_bf(A0.p[0]), as_bf(B.p[1]), acc0);
+    acc1 = X3_MFMA16(as_bf(A1.p[0]), as_bf(B.p[1]), acc1);
+    acc0 = X3_MFMA16(as_bf(A0.p[0]), as_bf(B.p[0]), acc0);
+    acc1 = X3_MFMA16(as_bf(A1.p[0]), as_bf(B.p[0]), acc1);
+}
+
+// ---- the pre-split observations (navppo_mlp64_bf16x3_prepare): per 32-sample tile
+//   rows  [32 m][3 pieces][16 f] bf16   F1's B operand: lane (m, kh) reads the eight features 8 kh .. 8 kh + 7 of piece i (16 bytes)
+//   cols  [3 pieces][16 f][32 m] bf16   G1's B operand: lane (f, kb) reads the eight samples 8 kb .. 8 kb + 7 of feature f
+constexpr int kX3TileBytes = 2 * 32 * 3 * 16 * 2;   // 6144
+constexpr int kX3RowsBytes = 32 * 3 * 16 * 2;       // offset of `cols` inside a tile
+
+template <bool F16>
+__global__ __launch_bounds__(64) void mlp64_split_obs(const void* __restrict__ obs, long long M, unsigned char* __restrict__ prep) {
+    __shared__ __attribute__((aligned(16))) uint16_t colsT[3][16][32];
+    const int lane = threadIdx.x, m = lane & 31, kh = lane >> 5;
+    const long long tile = blockIdx.x, row = tile * 32 + m;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (row < M) ? obs_at<F16>(obs, row * 16 + 8 * kh + e) : 0.f;
+    const Pieces P = split8(v);
+    unsigned char* const t = prep + (size_t)tile * kX3TileBytes;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        *reinterpret_cast<uint4*>(t + ((m * 3 + i) * 16 + 8 * kh) * 2) = P.p[i];
+        const uint32_t w[4] = {P.p[i].x, P.p[i].y, P.p[i].z, P.p[i].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) colsT[i][8 * kh + e][m] = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+    }
+    __syncthreads();
+    // 3 x 16 x 32 bf16 = 3072 bytes = 192 x 16 bytes
+    const uint4* src = reinterpret_cast<const uint4*>(&colsT[0][0][0]);
+    uint4* dst = reinterpret_cast<uint4*>(t + kX3RowsBytes);
+    for (int k = lane; k < 192; k += 64) dst[k] = src[k];
+}
+
+// ---- LDS of the split pass
+constexpr int XT = 32;                    // wave tile: 32 rows x 32 floats, 16-byte slot c of row r stored at slot c ^ ((r >> 1) & 7)
+constexpr int X_TILE_F = 32 * XT;
+constexpr int X_WAVE_F = 3 * X_TILE_F + 64;   // T0 | T1 | TD | g3[32] g4[32]
+#ifndef X3_WAVES
+#define X3_WAVES 8   // waves per workgroup of the split pass (one workgroup per CU: 8 = two per SIMD; measured with 4, one per SIMD and
+#endif               // 512 registers each: 1069 us per epoch against 924)
+constexpr int kXWaves = X3_WAVES, kXThreads = 64 * kXWaves;
+struct SmemX {
+    // weight pieces, bf16, [piece][row][k-position]; 16-byte slot s of row r stored at slot s ^ ((r >> 1) & 7)
+    uint16_t W2p[3][H][H];    // rows = layer-2 units (A operand of F2), k = layer-1 units, permuted
+    uint16_t W2Tp[3][H][H];   // rows = layer-1 units (A operand of B2), k = layer-2 units, permuted
+    uint16_t W1p[3][H][16];   // rows = layer-1 units (A operand of F1), k = features
+    float b1[H], b2[H], w3[H], w4[H];
+    float wv[(kXWaves * X_WAVE_F > 4 * ((P_ACTOR + 6) & ~3)) ? kXWaves * X_WAVE_F : 4 * ((P_ACTOR + 6) & ~3)];
+};
+static_assert(sizeof(SmemX) <= 160 * 1024, "LDS");
+
+// element (row, col) of a swizzled wave tile
+__device__ __forceinline__ int xt(const int row, const int col) { return row * XT + ((((col >> 2) ^ (row >> 1)) & 7) << 2) + (col & 3); }
+// k-position of column k in a weight row: the middle two quads of every 16 columns are swapped (see the header)
+__device__ __forceinline__ int kpos(const int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
+// address (in uint16 units) of k-position p of row r
+__device__ __forceinline__ int wslot(const int r, const int p) { return r * H + ((((p >> 3) ^ (r >> 1)) & 7) << 3) + (p & 7); }
+
+template <bool ACTOR>
+__device__ __forceinline__ void pass_body_x3(SmemX& sm, const float* __restrict__ params, const unsigned char* __restrict__ prep,
+                                             const float* __restrict__ act, const float* __restrict__ logp_old,
+                                             const float* __restrict__ rtg, const float* __restrict__ adv, long long M, float var,
+                                             float clip, float inv_n, float* __restrict__ partial, float* __restrict__ stats_partial) {
+    constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
+    constexpr int NT = kXThreads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15, kk = lane >> 4;
+
+    // ---- weights -> bf16 pieces in LDS (once per launch: 5120 values, 10 per thread)
+    for (int k = tid; k < H * H / 2; k += NT) {   // pairs of adjacent columns
+        const int r = (2 * k) / H, c = (2 * k) % H;
+        uint32_t p0, p1, p2;
+        split_pair(params[OFF_W2 + r * H + c], params[OFF_W2 + r * H + c + 1], p0, p1, p2);
+        const uint32_t pc[3] = {p0, p1, p2};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            // W2p[i][r][kpos(c)], [kpos(c + 1)] (c even: the pair stays adjacent under kpos) ; W2Tp[i][c][kpos(r)], W2Tp[i][c + 1][kpos(r)]
+            *reinterpret_cast<uint32_t*>(&sm.W2p[i][0][0] + wslot(r, kpos(c))) = pc[i];
+            (&sm.W2Tp[i][0][0])[wslot(c, kpos(r))] = (uint16_t)(pc[i] & 0xffffu);
+            (&sm.W2Tp[i][0][0])[wslot(c + 1, kpos(r))] = (uint16_t)(pc[i] >> 16);
+        }
+    }
+    for (int k = tid; k < H * 16 / 2; k += NT) {
+        const int r = (2 * k) / 16, c = (2 * k) % 16;
+        uint32_t p0, p1, p2;
+        split_pair(params[OFF_W1 + r * 16 + c], params[OFF_W1 + r * 16 + c + 1], p0, p1, p2);
+        *reinterpret_cast<uint32_t*>(&sm.W1p[0][r][c]) = p0;
+        *reinterpret_cast<uint32_t*>(&sm.W1p[1][r][c]) = p1;
+        *reinterpret_cast<uint32_t*>(&sm.W1p[2][r][c]) = p2;
+    }
+    if (tid < H) {
+        sm.b1[tid] = params[OFF_B1 + tid];
+        sm.b2[tid] = params[OFF_B2 + tid];
+        sm.w3[tid] = params[OFF_W3 + tid];
+        sm.w4[tid] = ACTOR ? params[OFF_W4 + tid] : 0.f;
+    }
+    const float b3 = params[OFF_B3];
+    const float b4 = ACTOR ? params[OFF_B4] : 0.f;
+    __syncthreads();
+
+    float* const T0 = sm.wv + wave * X_WAVE_F;   // H1^T rows 0..31
+    float* const T1 = T0 + X_TILE_F;             // H1^T rows 32..63
+    float* const TD = T0 + 2 * X_TILE_F;         // H2^T / dH2^T / dH1^T, one 32-row tile at a time
+    float* const gs = T0 + 3 * X_TILE_F;         // g3[m] | g4[m]
+    const int vec_off = 4 * lhi;                 // b1 / b2 / w3 / w4 [32 t + 8 g + 4 lhi + j]
+    // accumulator register r = 4 g + j of lane (m = l31, lhi) is row j + 8 g + 4 lhi of its 32 x 32 tile: tile[row][m]
+    auto wr = [&](const int r) { return xt(8 * (r >> 2) + 4 * lhi + (r & 3), l31); };
+    // the A operand of weight step (row tile tt, k-step s of 4, piece i): 16 bytes
+    auto ldw = [&](const uint16_t* base, const int tt, const int s, const int i) {
+        const int r = 32 * tt + l31;
+        return *reinterpret_cast<const uint4*>(base + i * H * H + wslot(r, 16 * s + 8 * lhi));
+    };
+
+    // accumulators that persist over this wave's tiles
+    f32x16 aW2[2][2];   // dW2 quadrant [n2 tile][n tile]
+    f32x4 aW1[4];       // dW1 rows 16 u .. + 15
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) aW2[a][b] = zero16();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) aW1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float adb2[2] = {0.f, 0.f}, adw3[2] = {0.f, 0.f}, adw4[2] = {0.f, 0.f}, adb1[4] = {0.f, 0.f, 0.f, 0.f};
+    float adb3 = 0.f, adb4 = 0.f, st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
+
+    const long long n_tiles = (M + 31) / 32;
+    const long long gw = (long long)blockIdx.x * kXWaves + wave, stride = (long long)gridDim.x * kXWaves;
+    Pieces xp;   // the tile's observation rows as F1's B operand (prefetched)
+    xp.p[0] = xp.p[1] = xp.p[2] = make_uint4(0u, 0u, 0u, 0u);
+    float pre_a0 = 0.f, pre_a1 = 0.f, pre_lp = 0.f, pre_t = 0.f;
+    auto prefetch_tile = [&](long long tile) {
+        const long long m = tile * 32 + l31;
+        const unsigned char* t = prep + (size_t)tile * kX3TileBytes + ((l31 * 3) * 16 + 8 * lhi) * 2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xp.p[i] = *reinterpret_cast<const uint4*>(t + i * 32);   // rows past the batch are zero in `prep`
+        if (m < M) {
+            if (ACTOR) {
+                const float2 a = reinterpret_cast<const float2*>(act)[m];
+                pre_a0 = a.x;
+                pre_a1 = a.y;
+                pre_lp = logp_old[m];
+                pre_t = adv[m];
+            } else {
+                pre_t = rtg[m];
+            }
+        }
+    };
+    if (gw < n_tiles) prefetch_tile(gw);
+    for (long long tile = gw; tile < n_tiles; tile += stride) {
+        const bool valid = tile * 32 + l31 < M;
+        const Pieces xr = xp;
+        const float cur_a0 = pre_a0, cur_a1 = pre_a1, cur_lp = pre_lp, cur_t = pre_t;
+        if (tile + stride < n_tiles) prefetch_tile(tile + stride);
+
+        // ---- F1: H1^T = relu(b1 + W1 X^T), K = 16: one k-step
+        f32x16 c1[2] = {zero16(), zero16()};
+        {
+            Pieces wa[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) wa[t].p[i] = *reinterpret_cast<const uint4*>(&sm.W1p[i][32 * t + l31][8 * lhi]);
+            mma5_small2(c1[0], c1[1], wa[0], wa[1], xr);
+            mma1_big(c1[0], wa[0].p[0], xr.p[0]);
+            mma1_big(c1[1], wa[1].p[0], xr.p[0]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b = lds4(sm.b1 + 32 * t + 8 * g + vec_off);
+                    c1[t][4 * g] = relu_bits(c1[t][4 * g] + b.x); c1[t][4 * g + 1] = relu_bits(c1[t][4 * g + 1] + b.y);
+                    c1[t][4 * g + 2] = relu_bits(c1[t][4 * g + 2] + b.z); c1[t][4 * g + 3] = relu_bits(c1[t][4 * g + 3] + b.w);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                T0[wr(r)] = c1[0][r];
+                T1[wr(r)] = c1[1][r];
+            }
+        }
+
+        // ---- F2: H2^T = relu(b2 + W2 H1^T); B operands: the H1^T accumulators split in-lane, eight registers per k-step
+        f32x16 c2[2] = {zero16(), zero16()};
+        {
+            uint4 hb0[4];   // the leading pieces of the four k-steps, for the big terms at the end
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {   // k-step (t1, j) = (s >> 1, s & 1): registers 8 j .. 8 j + 7 of c1[t1]
+                float hv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = c1[s >> 1][8 * (s & 1) + e];
+                const Pieces hb = split8(hv);
+                hb0[s] = hb.p[0];
+                Pieces w0, w1;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    w0.p[i] = ldw(&sm.W2p[0][0][0], 0, s, i);
+                    w1.p[i] = ldw(&sm.W2p[0][0][0], 1, s, i);
+                }
+                mma5_small2(c2[0], c2[1], w0, w1, hb);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                mma1_big(c2[0], ldw(&sm.W2p[0][0][0], 0, s, 0), hb0[s]);
+                mma1_big(c2[1], ldw(&sm.W2p[0][0][0], 1, s, 0), hb0[s]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b = lds4(sm.b2 + 32 * t + 8 * g + vec_off);
+                    c2[t][4 * g] = relu_bits(c2[t][4 * g] + b.x); c2[t][4 * g + 1] = relu_bits(c2[t][4 * g + 1] + b.y);
+                    c2[t][4 * g + 2] = relu_bits(c2[t][4 * g + 2] + b.z); c2[t][4 * g + 3] = relu_bits(c2[t][4 * g + 3] + b.w);
+                }
+        }
+
+        // ---- output units + loss (every lane: the two halves of a sample hold 32 hidden units each) -- as in the f32 pass
+        float g3 = 0.f, g4 = 0.f;
+        {
+            float z3 = 0.f, z4 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 w = lds4(sm.w3 + 32 * t + 8 * g + vec_off);
+                    z3 = fmaf(c2[t][4 * g], w.x, z3); z3 = fmaf(c2[t][4 * g + 1], w.y, z3);
+                    z3 = fmaf(c2[t][4 * g + 2], w.z, z3); z3 = fmaf(c2[t][4 * g + 3], w.w, z3);
+                    if (ACTOR) {
+                        const float4 v = lds4(sm.w4 + 32 * t + 8 * g + vec_off);
+                        z4 = fmaf(c2[t][4 * g], v.x, z4); z4 = fmaf(c2[t][4 * g + 1], v.y, z4);
+                        z4 = fmaf(c2[t][4 * g + 2], v.z, z4); z4 = fmaf(c2[t][4 * g + 3], v.w, z4);
+                    }
+                }
+            z3 += __shfl_xor(z3, 32, 64);
+            if (ACTOR) z4 += __shfl_xor(z4, 32, 64);
+            const float own = (lhi == 0) ? 1.f : 0.f;   // statistics are counted once per sample
+            if (valid) {
+                z3 += b3;
+                z4 += b4;
+                if (ACTOR) {
+                    const float mu0 = 1.0f / (1.0f + expf(-z3));   // torch.sigmoid, net_actor.py:185
+                    const float mu1 = tanhf(z4);                    // net_actor.py:186
+                    const float d0 = cur_a0 - mu0, d1 = cur_a1 - mu1;
+                    const float lp = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);   // ppo.py:734-735
+                    const float lr = lp - cur_lp;
+                    const float ratio = expf(lr);                  // ppo.py:316
+                    const float A = cur_t;
+                    const float s1 = ratio * A;                     // ppo.py:319
+                    const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+                    const float s2 = rc * A;                        // ppo.py:320
+                    st0 += own * -fminf(s1, s2);                    // ppo.py:342
+                    st2 += own * ((ratio - 1.0f) - lr);             // approx KL, ppo.py:326
+                    st3 += (fabsf(ratio - 1.0f) > clip) ? own : 0.f;  // clip fraction, ppo.py:335
+                    const bool inside = (ratio >= 1.0f - clip) && (ratio <= 1.0f + clip);
+                    const float dL_dratio = (inside || s1 < s2) ? -A : 0.f;
+                    const float dL_dlp = dL_dratio * ratio * inv_n;
+                    g3 = dL_dlp * (d0 / var) * (mu0 * (1.0f - mu0));
+                    g4 = dL_dlp * (d1 / var) * (1.0f - mu1 * mu1);
+                } else {
+                    const float e = z3 - cur_t;                     // critic(obs).squeeze(), ppo.py:724
+                    st1 += own * (e * e);                           // MSELoss, ppo.py:343
+                    g3 = 2.0f * e * inv_n;
+                }
+            }
+            adb3 += own * g3;
+            adb4 += own * g4;
+            if (lhi == 0) {
+                gs[l31] = g3;
+                if (ACTOR) gs[32 + l31] = g4;
+            }
+        }
+
+        // ---- H1 as the B operand of the dW2 products: lane (n = l31, half lhi) of tile t1, samples 16 s + 8 lhi .. + 7
+        Pieces h1b[2][2];
+#pragma unroll
+        for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float* src = (t1 ? T1 : T0);
+                const float4 q0 = lds4(src + xt(l31, 16 * s + 8 * lhi)), q1 = lds4(src + xt(l31, 16 * s + 8 * lhi + 4));
+                const float hv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                h1b[t1][s] = split8(hv);
+            }
+
+        // ---- per 32-row tile of the second layer: dW3/dW4 from H2^T, dH2^T in place, then its two dW2 quadrants
+        Pieces d2b[4];   // dH2^T as the B operand of B2: k-step s = 2 t2 + j
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) TD[wr(r)] = c2[t2][r];
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // lane (n2 = 32 t2 + l31, half lhi): sum over its 16 samples
+                const float4 h = lds4(TD + xt(l31, 16 * lhi + 4 * q));
+                const float4 a = lds4(gs + 16 * lhi + 4 * q);
+                adw3[t2] = fmaf(h.x, a.x, adw3[t2]); adw3[t2] = fmaf(h.y, a.y, adw3[t2]);
+                adw3[t2] = fmaf(h.z, a.z, adw3[t2]); adw3[t2] = fmaf(h.w, a.w, adw3[t2]);
+                if (ACTOR) {
+                    const float4 b = lds4(gs + 32 + 16 * lhi + 4 * q);
+                    adw4[t2] = fmaf(h.x, b.x, adw4[t2]); adw4[t2] = fmaf(h.y, b.y, adw4[t2]);
+                    adw4[t2] = fmaf(h.z, b.z, adw4[t2]); adw4[t2] = fmaf(h.w, b.w, adw4[t2]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 w = lds4(sm.w3 + 32 * t2 + 8 * g + vec_off);
+                const float wv3[4] = {w.x, w.y, w.z, w.w};
+                float wv4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (ACTOR) {
+                    const float4 v = lds4(sm.w4 + 32 * t2 + 8 * g + vec_off);
+                    wv4[0] = v.x; wv4[1] = v.y; wv4[2] = v.z; wv4[3] = v.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = ACTOR ? fmaf(g3, wv3[j], g4 * wv4[j]) : g3 * wv3[j];
+                    c2[t2][4 * g + j] = (c2[t2][4 * g + j] > 0.f) ? d : 0.f;
+                }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) TD[wr(r)] = c2[t2][r];
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {   // B2's B operand, in-lane
+                float dv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dv[e] = c2[t2][8 * j + e];
+                d2b[2 * t2 + j] = split8(dv);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {   // dW2[32 t2 ..][.] += dH2^T H1 over samples 16 s .. 16 s + 15
+                const float4 q0 = lds4(TD + xt(l31, 16 * s + 8 * lhi)), q1 = lds4(TD + xt(l31, 16 * s + 8 * lhi + 4));
+                const float av[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                adb2[t2] += ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
+                const Pieces da = split8(av);
+                mma6_acc2(aW2[t2][0], aW2[t2][1], da, h1b[0][s], h1b[1][s]);
+            }
+            wave_lds_fence();
+        }
+
+        // ---- B2: dH1^T = (W2^T dH2^T) . [H1 > 0]
+        f32x16 c3[2] = {zero16(), zero16()};
+        {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Pieces w0, w1;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    w0.p[i] = ldw(&sm.W2Tp[0][0][0], 0, s, i);
+                    w1.p[i] = ldw(&sm.W2Tp[0][0][0], 1, s, i);
+                }
+                mma5_small2(c3[0], c3[1], w0, w1, d2b[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                mma1_big(c3[0], ldw(&sm.W2Tp[0][0][0], 0, s, 0), d2b[s].p[0]);
+                mma1_big(c3[1], ldw(&sm.W2Tp[0][0][0], 1, s, 0), d2b[s].p[0]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {   // relu mask of layer 1: H1^T is still in T0 / T1 (same lane, same slot it was written from)
+                c3[0][r] = (T0[wr(r)] > 0.f) ? c3[0][r] : 0.f;
+                c3[1][r] = (T1[wr(r)] > 0.f) ? c3[1][r] : 0.f;
+            }
+        }
+        wave_lds_fence();
+
+        // ---- G1: dW1 += dH1^T X over the tile's 32 samples (16 x 16 x 32: one k-step); X^T pieces from the pre-split buffer
+        Pieces xb;   // lane (f = l15, kb = kk): samples 8 kk .. 8 kk + 7 of feature f
+        {
+            const unsigned char* t = prep + (size_t)tile * kX3TileBytes + kX3RowsBytes + (l15 * 32 + 8 * kk) * 2;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xb.p[i] = *reinterpret_cast<const uint4*>(t + i * 16 * 32 * 2);
+        }
+#pragma unroll
+        for (int t1 = 0; t1 < 2; ++t1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) TD[wr(r)] = c3[t1][r];
+            wave_lds_fence();
+            Pieces da[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {   // rows 32 t1 + 16 u + l15, samples 8 kk .. 8 kk + 7
+                const float4 q0 = lds4(TD + xt(16 * u + l15, 8 * kk)), q1 = lds4(TD + xt(16 * u + l15, 8 * kk + 4));
+                const float dv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                adb1[2 * t1 + u] += ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
+                da[u] = split8(dv);
+            }
+            mma6_acc16_2(aW1[2 * t1], aW1[2 * t1 + 1], da[0], da[1], xb);
+            wave_lds_fence();
+        }
+    }
+
+    // ---- workgroup reduction of the 8 waves' partial gradients in LDS, then one coalesced row of `partial` (as the f32 pass)
+    __syncthreads();
+    constexpr int RP = (P + 3 + 3) & ~3;
+    float s3 = adb3, s4 = adb4, sA = ACTOR ? st0 : st1, sB = st2, sC = st3;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s3 += __shfl_xor(s3, o, 64); s4 += __shfl_xor(s4, o, 64);
+        sA += __shfl_xor(sA, o, 64); sB += __shfl_xor(sB, o, 64); sC += __shfl_xor(sC, o, 64);
+    }
+    float hb2[2], hw3[2], hw4[2], qb1[4];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+        hb2[t2] = adb2[t2] + __shfl_xor(adb2[t2], 32, 64);
+        hw3[t2] = adw3[t2] + __shfl_xor(adw3[t2], 32, 64);
+        hw4[t2] = adw4[t2] + __shfl_xor(adw4[t2], 32, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float v = adb1[u];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        qb1[u] = v;
+    }
+    float* const row = sm.wv + (wave & 3) * RP;
+#pragma unroll
+    for (int pass = 0; pass < kXWaves / 4; ++pass) {
+        if ((wave >> 2) == pass) {
+            const bool add = pass >= 1;
+            auto put = [&](int idx, float v) { row[idx] = add ? row[idx] + v : v; };
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+                for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) put(OFF_W2 + (32 * t2 + c_row(r, lane)) * H + 32 * t1 + l31, aW2[t2][t1][r]);
+                if (lhi == 0) {
+                    put(OFF_B2 + 32 * t2 + l31, hb2[t2]);
+                    put(OFF_W3 + 32 * t2 + l31, hw3[t2]);
+                    if (ACTOR) put(OFF_W4 + 32 * t2 + l31, hw4[t2]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) put(OFF_W1 + (16 * u + 4 * kk + r) * IN + l15, aW1[u][r]);
+                if (kk == 0) put(OFF_B1 + 16 * u + l15, qb1[u]);
+            }
+            if (lane == 0) {
+                put(OFF_B3, s3);
+                if (ACTOR) put(OFF_B4, s4);
+                put(P + 0, sA);
+                put(P + 1, sB);
+                put(P + 2, sC);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = partial + (size_t)blockIdx.x * P;
+    const float* red = sm.wv;
+    for (int k = tid; k < P; k += NT) out[k] = (red[k] + red[RP + k]) + (red[2 * RP + k] + red[3 * RP + k]);
+    if (tid < 3) stats_partial[blockIdx.x * 4 + tid] = (red[P + tid] + red[RP + P + tid]) + (red[2 * RP + P + tid] + red[3 * RP + P + tid]);
+}
+
+// both nets of one epoch in one launch; net_mask: bit 0 = actor, bit 1 = critic (the one-net launches of the multi-GPU pipeline)
+__global__ __launch_bounds__(kXThreads) void mlp64_pass_both_x3(const float* __restrict__ params, const unsigned char* __restrict__ prep,
+                                                                const float* __restrict__ act, const float* __restrict__ logp_old,
+                                                                const float* __restrict__ rtg, const float* __restrict__ adv,
+                                                                long long M, float var, float clip, float inv_n, int net_mask,
+                                                                float* __restrict__ partial_a, float* __restrict__ stats_partial_a,
+                                                                float* __restrict__ partial_c, float* __restrict__ stats_partial_c) {
+    __shared__ __attribute__((aligned(16))) SmemX sm;
+    if (net_mask & 1) pass_body_x3<true>(sm, params, prep, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_a, stats_partial_a);
+    if (net_mask == 3) __syncthreads();
+    if (net_mask & 2) pass_body_x3<false>(sm, params + P_ACTOR, prep, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_c, stats_partial_c);
+}
+
 // grad[p] = sum over the workgroups' partial rows, for BOTH nets; ADAM (single-GPU epoch): then torch.optim.Adam's update (ppo.py:116-117,381,392; defaults betas
 // (0.9, 0.999), eps 1e-8, no weight decay) applied in place -- one launch instead of two reductions + an optimiser launch.
 // One block owns 64 parameters and ALL rows (no atomics): grad[p] is stored, not accumulated.  pa / pc: parameters of the actor /
@@ -1045,6 +1623,96 @@ int navppo_mlp64_update_epoch(float* params_dev, const void* obs_dev, int32_t ob
         return -2;
     }
     return 0;
+}
+
+size_t navppo_mlp64_bf16x3_prep_bytes(int64_t n_samples) {
+    if (n_samples < 1) return 0;
+    return (size_t)((n_samples + 31) / 32) * kX3TileBytes;
+}
+
+int navppo_mlp64_bf16x3_prepare(const void* obs_dev, int32_t obs_dim, int32_t obs_f16, int64_t n_samples, void* prep_dev, void* stream) {
+    if (!obs_dev || !prep_dev || n_samples < 1 || obs_dim != 16 || !obs_aligned(obs_dev, obs_dim, obs_f16) || ((uintptr_t)prep_dev & 15)) {
+        g_err = "navppo_mlp64_bf16x3_prepare: bad argument (16-column rows; obs and prep 16-byte aligned)";
+        return -1;
+    }
+    const unsigned tiles = (unsigned)((n_samples + 31) / 32);
+    if (obs_f16)
+        hipLaunchKernelGGL(mlp64_split_obs<true>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, obs_dev, (long long)n_samples,
+                           reinterpret_cast<unsigned char*>(prep_dev));
+    else
+        hipLaunchKernelGGL(mlp64_split_obs<false>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, obs_dev, (long long)n_samples,
+                           reinterpret_cast<unsigned char*>(prep_dev));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_err = std::string("navppo_mlp64_bf16x3_prepare: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+// net_mask 3: both nets; 1 / 2: the actor's / the critic's pass and its slice of the reduction; step >= 1: Adam in the reduction
+static int x3_epoch(const char* who, float* params_dev, const void* prep_dev, const float* act_dev, const float* logp_old_dev,
+                    const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, int net_mask, int32_t step,
+                    float lr, float beta1, float beta2, float eps, float* adam_m_dev, float* adam_v_dev, float* grad_dev,
+                    float* stats_dev, void* workspace_dev, void* stream) {
+    if (!params_dev || !prep_dev || !act_dev || !logp_old_dev || !rtg_dev || !adv_dev || !grad_dev || !stats_dev || !workspace_dev ||
+        n_samples < 1 || !(var > 0.f) || ((uintptr_t)prep_dev & 15) || ((uintptr_t)act_dev & 7)) {
+        g_err = std::string(who) + ": bad argument (prep 16-byte, act 8-byte aligned)";
+        return -1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const PassPlan pl = plan_pass(workspace_dev, n_samples, 16);
+    hipLaunchKernelGGL(mlp64_pass_both_x3, dim3(pl.blocks), dim3(kXThreads), 0, st, params_dev, reinterpret_cast<const unsigned char*>(prep_dev),
+                       act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, pl.inv_n, net_mask, pl.partial, pl.stats_partial,
+                       pl.partial_c, pl.stats_partial_c);
+    const int q0 = (net_mask & 1) ? 0 : pl.pa, q1 = (net_mask & 2) ? pl.pa + pl.pc : pl.pa;
+    if (step >= 1) {
+        const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
+        const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
+        hipLaunchKernelGGL(reduce_adam<true>, dim3((q1 - q0 + 63) / 64), dim3(64 * kRedGroups), 0, st, pl.partial, pl.stats_partial, pl.partial_c,
+                           pl.stats_partial_c, pl.blocks, pl.inv_n, grad_dev, stats_dev, params_dev, adam_m_dev, adam_v_dev, lr, beta1, beta2,
+                           eps, bc1, bc2_sqrt, pl.pa, pl.pc, q0, q1);
+    } else {
+        hipLaunchKernelGGL(reduce_adam<false>, dim3((q1 - q0 + 63) / 64), dim3(64 * kRedGroups), 0, st, pl.partial, pl.stats_partial, pl.partial_c,
+                           pl.stats_partial_c, pl.blocks, pl.inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f,
+                           1.f, pl.pa, pl.pc, q0, q1);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_err = std::string(who) + ": " + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
+}
+
+int navppo_mlp64_bf16x3_loss_grad(const float* params_dev, const void* prep_dev, const float* act_dev, const float* logp_old_dev,
+                                  const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float* grad_dev,
+                                  float* stats_dev, void* workspace_dev, void* stream) {
+    return x3_epoch("navppo_mlp64_bf16x3_loss_grad", const_cast<float*>(params_dev), prep_dev, act_dev, logp_old_dev, rtg_dev, adv_dev,
+                    n_samples, var, clip, 3, 0, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, grad_dev, stats_dev, workspace_dev, stream);
+}
+
+int navppo_mlp64_bf16x3_loss_grad_net(int32_t net, const float* params_dev, const void* prep_dev, const float* act_dev,
+                                      const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var,
+                                      float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
+    if (net != 0 && net != 1) {
+        g_err = "navppo_mlp64_bf16x3_loss_grad_net: net is 0 (actor) or 1 (critic)";
+        return -1;
+    }
+    return x3_epoch("navppo_mlp64_bf16x3_loss_grad_net", const_cast<float*>(params_dev), prep_dev, act_dev, logp_old_dev, rtg_dev, adv_dev,
+                    n_samples, var, clip, net == 0 ? 1 : 2, 0, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, grad_dev, stats_dev, workspace_dev, stream);
+}
+
+int navppo_mlp64_bf16x3_update_epoch(float* params_dev, const void* prep_dev, const float* act_dev, const float* logp_old_dev,
+                                     const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
+                                     float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
+                                     float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
+    if (step < 1 || !adam_m_dev || !adam_v_dev) {
+        g_err = "navppo_mlp64_bf16x3_update_epoch: bad argument";
+        return -1;
+    }
+    return x3_epoch("navppo_mlp64_bf16x3_update_epoch", params_dev, prep_dev, act_dev, logp_old_dev, rtg_dev, adv_dev, n_samples, var, clip,
+                    3, step, lr, beta1, beta2, eps, adam_m_dev, adam_v_dev, grad_dev, stats_dev, workspace_dev, stream);
 }
 
 int navppo_episode_sums(const uint8_t* ended_dev, const uint8_t* arrive_dev, const uint8_t* done_dev, const int32_t* ep_length_dev,

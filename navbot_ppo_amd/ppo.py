@@ -50,6 +50,10 @@ class PPOConfig:
     use_graph: bool = True                 # capture the T-step rollout in one hipGraph
     persistent_rollout: bool = True        # mlp64x2 on GPU: all T steps in ONE launch (navsim_rollout_mlp64)
     fused_update: bool = True              # on GPU: fused HIP loss+gradient kernels (csrc/ppo_mlp64.hip, csrc/ppo_resmlp512.hip)
+    # arithmetic of the fused 16-64-64 update's matrix products: "bf16x3" = float32 products out of operands split into three bf16
+    # pieces on the bf16 MFMA (six piece products, float32 accumulate: float32-equivalent by measurement), "f32" =
+    # the f32-input MFMA (native float32 fma chains).  Inputs, outputs and everything around the products are float32 either way.
+    update_arith: str = "bf16x3"
     # multi-GPU, mlp64x2: False = fused passes of both nets -> ONE all-reduce of the flat gradient -> Adam (the default: at one
     # RCCL rank this path costs 9-24 us per epoch over the single-GPU epoch, the per-net pipeline below 59-74 us, because two
     # pass launches pay the ramp / staging / reduction of the fused one twice -- more than a 43 KB all-reduce costs on the wire);
@@ -221,6 +225,10 @@ class PPOUpdater:
         self.fused_resmlp512 = (on_gpu and cfg.policy == "resmlp512" and isinstance(actor, nets.ResMLPActor)
                                 and actor.rb1.f_in == 16 and actor.rb1.fc1.out_features == 512)
         self.fused = "navppo_mlp64" if self.fused_mlp64 else "navppo_resmlp512" if self.fused_resmlp512 else None
+        if cfg.update_arith not in ("f32", "bf16x3"):
+            raise ValueError(f"update_arith {cfg.update_arith!r}: 'f32' or 'bf16x3'")
+        self.bf16x3 = self.fused_mlp64 and self.obs_dim == 16 and cfg.update_arith == "bf16x3"   # (the split pass exists for 16-column rows)
+        self._prep = self._prep_key = None
         if self.fused:
             from ._native import lib
             self._n_actor = self.fp.module_numel[0]
@@ -257,6 +265,29 @@ class PPOUpdater:
         p = C.c_void_p(obs.data_ptr())
         return (p, self.obs_dim, int(obs.dtype == torch.float16)) if self.fused_mlp64 else (p,)
 
+    def prepare(self, obs):
+        """bf16x3: split the batch's observations into bf16 pieces (navppo_mlp64_bf16x3_prepare) -- once per update, the rows do not
+        change over the epochs.  The epoch entry points use the prepared buffer while `obs` is the tensor it was made from."""
+        import ctypes as C
+        from ._native import lib
+        L = lib()
+        p, d, f16 = self._obs_args(obs)
+        need = L.navppo_mlp64_bf16x3_prep_bytes(int(obs.shape[0]))
+        if self._prep is None or self._prep.numel() < need:
+            self._prep = None
+            self._prep = torch.empty(need, dtype=torch.uint8, device=self.device)
+        rc = L.navppo_mlp64_bf16x3_prepare(p, d, f16, int(obs.shape[0]), C.c_void_p(self._prep.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"navppo_mlp64_bf16x3_prepare failed: {L.navppo_last_error().decode()}")
+        self._prep_key = (obs.data_ptr(), tuple(obs.shape), obs.dtype, obs._version)
+
+    def _prepared(self, obs):
+        import ctypes as C
+        if self._prep_key != (obs.data_ptr(), tuple(obs.shape), obs.dtype, obs._version):
+            self.prepare(obs)
+        return C.c_void_p(self._prep.data_ptr())
+
     def _fused_loss_grad(self, obs, acts, logp_old, rtg, adv, var, stats=None):
         """evaluate + losses + backward of ppo.py:307-386 in the HIP kernels of csrc/ppo_mlp64.hip; gradients land
         in the flat gradient buffer, (actor_loss, approx_kl, clip_frac, -, critic_loss) in self._fstats."""
@@ -266,7 +297,8 @@ class PPOUpdater:
         ptr = lambda t: C.c_void_p(t.data_ptr())
         for t in (acts, logp_old, rtg, adv):
             assert t.is_contiguous() and t.dtype == torch.float32
-        rc = getattr(L, self.fused + "_loss_grad")(ptr(self.fp.flat), *self._obs_args(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+        name, oargs = (("navppo_mlp64_bf16x3", (self._prepared(obs),)) if self.bf16x3 else (self.fused, self._obs_args(obs)))
+        rc = getattr(L, name + "_loss_grad")(ptr(self.fp.flat), *oargs, ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
                                                    int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad),
                                                    ptr(self._fstats if stats is None else stats), ptr(self._workspace(obs.shape[0])),
                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -279,7 +311,9 @@ class PPOUpdater:
         from ._native import lib
         L = lib()
         ptr = lambda t: C.c_void_p(t.data_ptr())
-        rc = L.navppo_mlp64_loss_grad_net(int(net), ptr(self.fp.flat), *self._obs_args(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+        fn, oargs = ((L.navppo_mlp64_bf16x3_loss_grad_net, (self._prepared(obs),)) if self.bf16x3
+                     else (L.navppo_mlp64_loss_grad_net, self._obs_args(obs)))
+        rc = fn(int(net), ptr(self.fp.flat), *oargs, ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
                                           int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad), ptr(stats),
                                           ptr(self._workspace(obs.shape[0])), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
@@ -352,7 +386,8 @@ class PPOUpdater:
         L = lib()
         ptr = lambda t: C.c_void_p(t.data_ptr())
         self._adam_t += 1
-        rc = getattr(L, self.fused + "_update_epoch")(ptr(self.fp.flat), *self._obs_args(obs), ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
+        name, oargs = (("navppo_mlp64_bf16x3", (self._prepared(obs),)) if self.bf16x3 else (self.fused, self._obs_args(obs)))
+        rc = getattr(L, name + "_update_epoch")(ptr(self.fp.flat), *oargs, ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
                                                       int(obs.shape[0]), float(var), float(self.cfg.clip), float(self.cfg.lr), 0.9,
                                                       0.999, 1e-8, int(self._adam_t), ptr(self._adam_m), ptr(self._adam_v),
                                                       ptr(self.fp.grad), ptr(stats), ptr(self._workspace(obs.shape[0])),
@@ -387,6 +422,8 @@ class PPOUpdater:
             obs = obs.float()   # half rows (obs_f16 envs) are consumed as they are by the D-64-64 kernels only
         if self.fused:
             obs, acts, logp_old, rtg, adv = (t.contiguous() for t in (obs, acts, logp_old, rtg, adv))
+            if self.bf16x3 and n_ep > 0:
+                self.prepare(obs)   # ALWAYS here: the rollout kernels fill the buffer behind torch's back (no version bump)
             if self._fhist.shape[0] < n_ep:
                 self._fhist = torch.zeros((n_ep, 8), dtype=torch.float32, device=self.device)
         pipelined = self.fused and multi and self.fused_mlp64 and cfg.overlap_allreduce

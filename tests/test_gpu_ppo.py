@@ -257,9 +257,7 @@ def test_persistent_rollout_equals_per_step_rollout(N, T, map_name, per_env, epb
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
     if epb:
-        monkeypatch.setenv("NAVSIM_EPB", epb)   # read by navsim_create: both paths then run their 64-env shapes
-    if sens and N > 4096:
-        pytest.skip("the sensor-option instantiations are covered at the small shard of every shape")
+        monkeypatch.setenv("NAVSIM_EPB", epb)   # read by NavSim.__init__ (navsim_set_shape, per handle): both paths then run their 64-env shapes
     kw = dict(lidar_noise_sigma=0.01, lidar_below_min="gazebo") if sens else {}   # SENS = true instantiations of both kernels
     outs = []
     for persistent in (True, False):
