@@ -88,6 +88,13 @@ struct Pad {
     static constexpr int KH = INP / 2;                 // features per lane half in F1 (32x32x2: k = lane >> 5)
     static constexpr int NC = INP / 16;                // 16-column tiles of dW1
     static constexpr int LW1 = INP + 4;                // row stride of W1 in LDS (floats): 16-byte aligned rows, conflict-free ds_read_b128
+#ifndef MLP64_WIDE_WAVES
+#define MLP64_WIDE_WAVES 4
+#endif
+    // waves per workgroup (one workgroup per CU).  16 columns: 8 = two per SIMD, 256 registers each.  42 columns: 48 more registers of
+    // dW1 accumulators and 24 + 24 of rows do not fit 256 (the 8-wave build spilled ~450 registers and re-read X from L2 for G1:
+    // 2242 us per epoch = 0.43 of the f32 MFMA peak) -- 4 = one per SIMD, 512 registers each, the 16-column structure unchanged
+    static constexpr int NW = (IN == 16) ? 8 : MLP64_WIDE_WAVES;
     static_assert(IN == 16 || IN == 42, "observation widths of the reference's sensor configurations: 10 or 36 beams + 6");
 };
 constexpr int LW2 = 68;
@@ -95,7 +102,7 @@ constexpr int LT = 36;
 constexpr int TILE_F = 32 * LT;
 constexpr int WAVE_F = 3 * TILE_F + 64;   // T0 | T1 | TD | g3[32] g4[32]
 constexpr int kWWaves = 8;
-constexpr int kWThreads = 64 * kWWaves;
+
 constexpr int kWMaxBlocks = 256;          // one persistent workgroup per CU
 
 template <int IN>
@@ -104,7 +111,9 @@ struct SmemW {
     float W2s[H * LW2];
     float W2Ts[H * LW2];
     float b1[H], b2[H], w3[H], w4[H];
-    float wv[kWWaves * WAVE_F];
+    // the wave tiles; at the end of a pass also the four rows of the workgroup's gradient reduction (42 columns: from W2s on)
+    static constexpr int kRedF = 4 * ((Layout<IN>::P_ACTOR + 6) & ~3) - ((IN == 16) ? 0 : 2 * H * LW2 + 4 * H);
+    float wv[(Pad<IN>::NW * WAVE_F > kRedF) ? Pad<IN>::NW * WAVE_F : kRedF];
 };
 static_assert(sizeof(SmemW<16>) <= 160 * 1024 && sizeof(SmemW<42>) <= 160 * 1024, "LDS");
 static_assert(2 * kWMaxBlocks <= NAVPPO_MLP64_MAX_BLOCKS, "workspace rows for both nets");
@@ -187,8 +196,9 @@ __device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict
                   OFF_B3 = L::OFF_B3, OFF_W4 = L::OFF_W4, OFF_B4 = L::OFF_B4;
     constexpr int P = ACTOR ? L::P_ACTOR : L::P_CRITIC;
     constexpr int INP = Pad<IN>::INP, KH = Pad<IN>::KH, NC = Pad<IN>::NC, LW1 = Pad<IN>::LW1;
-    constexpr bool kKeepX = (IN == 16);   // X stays in registers from F1 to G1, the next tile's rows are prefetched (see Pad)
-    constexpr int NT = kWThreads;
+    constexpr int NW = Pad<IN>::NW;
+    constexpr bool kKeepX = (IN == 16) || NW == 4;   // X stays in registers from F1 to G1, the next tile's rows are prefetched (see Pad)
+    constexpr int NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15, kk = lane >> 4;
 
@@ -240,7 +250,7 @@ __device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict
     float adb3 = 0.f, adb4 = 0.f, st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
 
     const long long n_tiles = (M + 31) / 32;
-    const long long gw = (long long)blockIdx.x * kWWaves + wave, stride = (long long)gridDim.x * kWWaves;
+    const long long gw = (long long)blockIdx.x * NW + wave, stride = (long long)gridDim.x * NW;
     XRow<IN, F16> xpre;
     xpre.zero();
     float pre_a0 = 0.f, pre_a1 = 0.f, pre_lp = 0.f, pre_t = 0.f;
@@ -494,9 +504,9 @@ __device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict
         // ---- G1: dH1^T through TD 32 rows at a time; X as [k = sample][column]: IN = 16 from the registers through T0 (the H1^T
         // tiles are no longer needed), IN = 42 read again from L2 straight in the operand layout (lane (l15, kk): samples 8 kk + s),
         // one 16-column tile at a time, the next tile's eight values requested ahead of the current tile's MFMAs
-        if constexpr (kKeepX) {
+        if constexpr (kKeepX) {   // (42 columns: 48 rows, T0 and the first half of T1 -- the tiles are contiguous)
 #pragma unroll
-            for (int s = 0; s < 8; ++s) T0[(8 * lhi + s) * LT + l31] = xr[s];
+            for (int s = 0; s < KH; ++s) T0[(KH * lhi + s) * LT + l31] = xr[s];
         }
         int xrow[8];   // (IN = 42) row offsets of the lane's eight samples; rows past the batch re-read the last one (dH1 is zero there)
         if constexpr (!kKeepX) {
@@ -517,7 +527,7 @@ __device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) TD[wr_base + (8 * (r >> 2) + (r & 3)) * LT] = c3[t1][r];
             wave_lds_fence();
-            if constexpr (kKeepX) {
+            if constexpr (kKeepX && NC == 1) {
                 const float4 x0 = lds4(T0 + rd16), x1 = lds4(T0 + rd16 + 4);
                 xb[0][0] = x0.x; xb[0][1] = x0.y; xb[0][2] = x0.z; xb[0][3] = x0.w;
                 xb[0][4] = x1.x; xb[0][5] = x1.y; xb[0][6] = x1.z; xb[0][7] = x1.w;   // X[m = 8 kk + s][k = l15]
@@ -532,6 +542,11 @@ __device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     const int cur = kKeepX ? 0 : ((t1 * NC + c) & 1);
+                    if constexpr (kKeepX && NC > 1) {   // X[m = 8 kk + s][16 c + l15] out of the staged rows
+                        const float4 x0 = lds4(T0 + 16 * c * LT + rd16), x1 = lds4(T0 + 16 * c * LT + rd16 + 4);
+                        xb[0][0] = x0.x; xb[0][1] = x0.y; xb[0][2] = x0.z; xb[0][3] = x0.w;
+                        xb[0][4] = x1.x; xb[0][5] = x1.y; xb[0][6] = x1.z; xb[0][7] = x1.w;
+                    }
                     if constexpr (!kKeepX) {
                         if (t1 * NC + c + 1 < 2 * NC) load_xb((c + 1) % NC, xb[cur ^ 1]);
                         __builtin_amdgcn_sched_barrier(0);   // keep the requests above the MFMAs they overlap with
@@ -560,7 +575,7 @@ __device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict
     constexpr int RP = (P + 3 + 3) & ~3;   // row pitch (floats): P parameters + 3 statistics, a multiple of 4
     // the four rows lie over the wave tiles; the 42-wide nets' rows (4 x 7048 floats) start at W2s, which nothing reads any more
     float* const red_base = (IN == 16) ? sm.wv : sm.W2s;
-    static_assert(4 * RP <= kWWaves * WAVE_F + ((IN == 16) ? 0 : 2 * H * LW2 + 4 * H), "reduction rows fit");
+    static_assert(4 * RP <= (int)(sizeof(sm.wv) / sizeof(float)) + ((IN == 16) ? 0 : 2 * H * LW2 + 4 * H), "reduction rows fit");
     float s3 = adb3, s4 = adb4, sA = ACTOR ? st0 : st1, sB = st2, sC = st3;   // held per lane (lhi == 0 lanes non-zero)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -583,9 +598,9 @@ __device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict
     }
     float* const row = red_base + (wave & 3) * RP;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < NW / 4; ++pass) {
         if ((wave >> 2) == pass) {
-            const bool add = pass == 1;
+            const bool add = pass >= 1;
             auto put = [&](int idx, float v) { row[idx] = add ? row[idx] + v : v; };
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
@@ -625,7 +640,7 @@ __device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict
 }
 
 template <bool ACTOR, bool FWD, int IN, bool F16>
-__global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restrict__ params, const void* __restrict__ obs,
+__global__ __launch_bounds__(64 * Pad<IN>::NW) void mlp64_pass_w(const float* __restrict__ params, const void* __restrict__ obs,
                                                           const float* __restrict__ act, const float* __restrict__ logp_old,
                                                           const float* __restrict__ rtg, const float* __restrict__ adv,
                                                           long long M, float var, float clip, float inv_n,
@@ -639,7 +654,7 @@ __global__ __launch_bounds__(kWThreads) void mlp64_pass_w(const float* __restric
 
 // both nets of one epoch in one launch (single-GPU path): the actor's tiles, then the critic's, by the same workgroups
 template <int IN, bool F16>
-__global__ __launch_bounds__(kWThreads) void mlp64_pass_both(const float* __restrict__ params, const void* __restrict__ obs,
+__global__ __launch_bounds__(64 * Pad<IN>::NW) void mlp64_pass_both(const float* __restrict__ params, const void* __restrict__ obs,
                                                              const float* __restrict__ act, const float* __restrict__ logp_old,
                                                              const float* __restrict__ rtg, const float* __restrict__ adv,
                                                              long long M, float var, float clip, float inv_n,
@@ -1497,7 +1512,7 @@ int navppo_mlp64_loss_grad(const float* params_dev, const void* obs_dev, int32_t
     hipStream_t st = (hipStream_t)stream;
     const PassPlan pl = plan_pass(workspace_dev, n_samples, obs_dim);
     for_obs(obs_dim, obs_f16, [&](auto in, auto f16) {
-        hipLaunchKernelGGL((mlp64_pass_both<decltype(in)::value, decltype(f16)::value>), dim3(pl.blocks), dim3(kWThreads), 0, st, params_dev,
+        hipLaunchKernelGGL((mlp64_pass_both<decltype(in)::value, decltype(f16)::value>), dim3(pl.blocks), dim3(64 * Pad<decltype(in)::value>::NW), 0, st, params_dev,
                            obs_dev, act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, pl.inv_n, pl.partial,
                            pl.stats_partial, pl.partial_c, pl.stats_partial_c, grad_dev, stats_dev);
     });
@@ -1531,11 +1546,11 @@ int navppo_mlp64_loss_grad_net(int32_t net, const float* params_dev, const void*
         constexpr int IN = decltype(in)::value;
         constexpr bool F16 = decltype(f16)::value;
         if (net == 0)
-            hipLaunchKernelGGL((mlp64_pass_w<true, false, IN, F16>), dim3(pl.blocks), dim3(kWThreads), 0, st, params_dev, obs_dev, act_dev,
+            hipLaunchKernelGGL((mlp64_pass_w<true, false, IN, F16>), dim3(pl.blocks), dim3(64 * Pad<IN>::NW), 0, st, params_dev, obs_dev, act_dev,
                                logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, pl.inv_n, pl.partial, pl.stats_partial,
                                grad_dev, stats_dev, (float*)nullptr);
         else
-            hipLaunchKernelGGL((mlp64_pass_w<false, false, IN, F16>), dim3(pl.blocks), dim3(kWThreads), 0, st, params_dev + pl.pa, obs_dev,
+            hipLaunchKernelGGL((mlp64_pass_w<false, false, IN, F16>), dim3(pl.blocks), dim3(64 * Pad<IN>::NW), 0, st, params_dev + pl.pa, obs_dev,
                                act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, pl.inv_n, pl.partial_c,
                                pl.stats_partial_c, grad_dev + pl.pa, stats_dev + 4, (float*)nullptr);
     });
@@ -1580,7 +1595,7 @@ int navppo_mlp64_value(const float* critic_params_dev, const void* obs_dev, int3
     const long long want = (wtiles + kWWaves - 1) / kWWaves;
     const int blocks = (int)(want < kWMaxBlocks ? want : kWMaxBlocks);
     for_obs(obs_dim, obs_f16, [&](auto in, auto f16) {
-        hipLaunchKernelGGL((mlp64_pass_w<false, true, decltype(in)::value, decltype(f16)::value>), dim3(blocks), dim3(kWThreads), 0,
+        hipLaunchKernelGGL((mlp64_pass_w<false, true, decltype(in)::value, decltype(f16)::value>), dim3(blocks), dim3(64 * Pad<decltype(in)::value>::NW), 0,
                            (hipStream_t)stream, critic_params_dev, obs_dev, nullptr, nullptr, nullptr, nullptr, (long long)n_samples, 1.f,
                            0.f, 0.f, nullptr, nullptr, nullptr, nullptr, value_dev);
     });
@@ -1610,7 +1625,7 @@ int navppo_mlp64_update_epoch(float* params_dev, const void* obs_dev, int32_t ob
     const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
     const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
     for_obs(obs_dim, obs_f16, [&](auto in, auto f16) {
-        hipLaunchKernelGGL((mlp64_pass_both<decltype(in)::value, decltype(f16)::value>), dim3(pl.blocks), dim3(kWThreads), 0, st, params_dev,
+        hipLaunchKernelGGL((mlp64_pass_both<decltype(in)::value, decltype(f16)::value>), dim3(pl.blocks), dim3(64 * Pad<decltype(in)::value>::NW), 0, st, params_dev,
                            obs_dev, act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, pl.inv_n, pl.partial,
                            pl.stats_partial, pl.partial_c, pl.stats_partial_c, grad_dev, stats_dev);
     });
