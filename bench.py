@@ -282,6 +282,7 @@ def time_to_reward(n_envs, target=100.0, max_iters=40, seeds=(0, 1, 2)):
                 target=target, seeds=list(seeds), runs=runs)
 
 
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline is 2:1 sparse)
 MFMA_F32_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 
 
@@ -368,9 +369,10 @@ def ppo_shard_leg(n_envs, world, n_beams, obs_f16, sampler, rollout, epochs, det
     return out
 
 
-def mlp64_update_roofline(tr, reps=40):
+def mlp64_update_roofline(tr, reps=40, arith=None):
     """The update kernels of the TIMED workload alone (94 % of the timed region): HIP events around whole epochs of
-    navppo_mlp64_update_epoch (mlp64_pass_both + reduce_adam) on the trainer's own rollout buffers."""
+    navppo_mlp64[_bf16x3]_update_epoch (pass kernel + reduce_adam) on the trainer's own rollout buffers.  arith: None = the arithmetic
+    the trainer runs (PPOConfig.update_arith), "f32" / "bf16x3" = that one (same buffers, same weights: the two legs are like for like)."""
     up = tr.updater
     if not up.fused_mlp64:
         return None
@@ -379,24 +381,58 @@ def mlp64_update_roofline(tr, reps=40):
     logp, rtg = tr.logp_buf.reshape(T * N), tr.rtg_buf.reshape(T * N)
     adv = torch.randn(T * N, device=obs.device)
     st = torch.zeros(8, device=obs.device)
-    for _ in range(10):   # the clock settles on the MFMA loop's level within a few epochs
-        up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    was = up.bf16x3
+    if arith is not None:
+        if arith == "bf16x3" and D != 16:
+            return None
+        up.bf16x3 = arith == "bf16x3"
+    split_ms = None
+    try:
+        if up.bf16x3:   # the one-off split of the observations (once per update, not per epoch)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            up.prepare(obs)
+            e0.record()
+            up.prepare(obs)
+            e1.record()
+            torch.cuda.synchronize()
+            split_ms = e0.elapsed_time(e1)
+        for _ in range(10):   # the clock settles on the MFMA loop's level within a few epochs
+            up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        x3 = up.bf16x3
+    finally:
+        up.bf16x3 = was
     # MACs per sample and net: F1 64 D + F2 4096 + B2 4096 + G2 4096 + G1 64 D on MFMA (D = 16: 14,336), output units / their
     # gradients on the vector units (actor 384, critic 192): D = 16: 2 x (2 x 14,336 + 576) = 58,496 FLOP per sample
     flop = (2 * 2 * (12288 + 128 * D) + 2 * 576) * T * N
-    return dict(bound="mfma", kernel="navppo_mlp64_update_epoch (mlp64_pass_both + reduce_adam)", achieved=round(flop / ms / 1e9, 2),
-                peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4), epoch_us=round(ms * 1e3, 1),
-                flop_per_epoch=flop, samples=T * N, traffic=None,
-                detail="f32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): 14,336 MFMA cycles + ~575 vector instructions per 32-sample "
-                       "tile and net; f32 MFMA and VALU share the SIMD's FMA lanes, the loop sustains ~2.2 GHz")
+    out = dict(bound="mfma", arith="bf16x3" if x3 else "f32",
+               kernel=("navppo_mlp64_bf16x3_update_epoch (mlp64_pass_both_x3 + reduce_adam)" if x3 else
+                       "navppo_mlp64_update_epoch (mlp64_pass_both + reduce_adam)"),
+               achieved=round(flop / ms / 1e9, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4),
+               epoch_us=round(ms * 1e3, 1), flop_per_epoch=flop, samples=T * N, traffic=None)
+    if x3:
+        # what the matrix pipe executes: six bf16 piece products per float32 product (v_mfma_f32_32x32x16_bf16 / 16x16x32), priced
+        # against the dense bf16 MFMA peak; `achieved` / `frac` above stay the ALGORITHMIC float32 FLOP against the f32-MFMA peak,
+        # like for like with the native path and with earlier rounds (a frac above 1 there would mean: beyond what f32 MFMA can do)
+        mfma_flop = 6 * 2 * 2 * (12288 + 128 * D) * T * N
+        out["bf16_mfma"] = dict(executed_tflops=round(mfma_flop / ms / 1e9, 1), peak=MFMA_BF16_PEAK_TF, frac=round(mfma_flop / ms / 1e9 / MFMA_BF16_PEAK_TF, 4))
+        out["split_obs_us_per_update"] = round(split_ms * 1e3, 1)
+        out["detail"] = ("float32 products from operands split into three bf16 pieces, six piece products each on the bf16 MFMA, float32 "
+                         "accumulate (float32-equivalent: tests/test_gpu_bf16x3.py).  Bound by the vector unit, not the matrix pipe: per "
+                         "32-sample tile and net 180 MFMAs (5,376 cycles: SQ_VALU_MFMA_BUSY = 33 % of the launch) beside ~1,465 vector "
+                         "instructions (880 of them the five 32-value splits, SQ_ACTIVE_INST_VALU = 41 %); bf16 MFMA and vector work of the "
+                         "two waves of a SIMD do not overlap (tools/ubench/bf16_mfma_valu_overlap.hip) -- profiles/r05_bf16x3_pmc.txt")
+    else:
+        out["detail"] = ("f32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): 14,336 MFMA cycles + ~575 vector instructions per 32-sample "
+                         "tile and net at D = 16; f32 MFMA and VALU share the SIMD's FMA lanes, the loop sustains ~2.2 GHz")
+    return out
 
 
 def env_n1_step_us(budget_s=1.5):
@@ -554,6 +590,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline legs")
     ap.add_argument("--with-pmc-file", default=None,
                     help="pmc_traffic.json recorded by tools/pmc_traffic.py in the same gpurun call (roofline.traffic comes from it)")
+    ap.add_argument("--update-arith", choices=["bf16x3", "f32"], default="bf16x3",
+                    help="arithmetic of the fused 16-64-64 update's matrix products (PPOConfig.update_arith)")
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="N > 1, mlp64x2: the two-stage per-net pipeline instead of one all-reduce of the flat gradient per epoch")
     args = ap.parse_args()
@@ -588,7 +626,7 @@ def main():
                  device=ctx.device)
     cfg = ppo.PPOConfig(rollout_len=args.rollout, max_episode_steps=500, n_updates_per_iteration=args.epochs,
                         policy=args.policy, use_graph=not args.no_graph, seed=0,
-                        overlap_allreduce=args.overlap_allreduce)
+                        overlap_allreduce=args.overlap_allreduce, update_arith=args.update_arith)
     trainer = ppo.PPOTrainer(env, cfg, ctx)
 
     for _ in range(args.warmup):
@@ -615,12 +653,17 @@ def main():
             "metric": "env_steps_per_sec", "value": round(K * args.rollout * n_total / dt, 1), "unit": "env-steps/s",
             "n_gpus": ctx.world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32", "dtype_detail": "pose/goal angles/reward f64, ray-cast f32, PPO nets f32",
+            "dtype": "f32",
+            "dtype_detail": "pose/goal angles/reward f64, ray-cast f32, PPO nets f32" + (
+                "; the update's matrix products are float32 products evaluated from three-piece bf16 splits on the bf16 MFMA (six piece "
+                "products, float32 accumulate: 'bf16x3', float32-equivalent against float64 -- tests/test_gpu_bf16x3.py; "
+                "--update-arith f32 selects the f32-input MFMA)" if trainer.updater.bf16x3 else "; update on the f32-input MFMA"),
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {n_local} envs/GPU, stage_1 (32 segments), 10 beams, "
                                    f"PPO {args.policy}, rollout={args.rollout}, {args.epochs} full-batch epochs, episode cap 500",
                        "n_envs_total": n_total, "n_envs_per_gpu": n_local, "rollout_len": args.rollout,
                        "epochs": args.epochs, "policy": args.policy, "parallelism": f"env-shard dp{ctx.world}",
+                       "update_arith": "bf16x3" if trainer.updater.bf16x3 else "f32",
                        "rollout": "persistent kernel (navsim_rollout_mlp64)" if trainer.updater.fused_mlp64 and cfg.persistent_rollout
                        else ("hipGraph of per-step launches" if not args.no_graph else "per-step launches")},
             "dist_backend": ctx.backend, "rccl_version": ctx.rccl_version,
@@ -632,7 +675,10 @@ def main():
     if not args.no_extras and ctx.rank == 0:   # rank 0 only (the other ranks wait at the barrier below)
         # GPU legs first and long enough (several seconds in total) for an outside utilisation sampler to see them
         out["roofline_timed_region"] = rollout_kernel_leg(trainer) if trainer.updater.fused_mlp64 else None
-        out["update_roofline"] = mlp64_update_roofline(trainer)
+        out["update_roofline"] = mlp64_update_roofline(trainer)                       # the arithmetic the timed region ran
+        out["update_roofline_f32"] = mlp64_update_roofline(trainer, arith="f32")       # the native f32-MFMA pass on the same buffers
+        if out["update_roofline"] and out["update_roofline"]["arith"] != "bf16x3":
+            out["update_roofline_bf16x3"] = mlp64_update_roofline(trainer, arith="bf16x3")
         del trainer
         torch.cuda.empty_cache()
         # The ray-cast run of BASELINE configs[2].  `roofline` is the entry point the north star names -- navsim_step, ONE launch per
