@@ -452,7 +452,7 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NAVBOT_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29631", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--master-port", str(__import__("_ranks").free_port()), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--envs-per-gpu", "512", "--rollout", "64", "--epochs", "3"]
     out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -482,12 +482,18 @@ def test_bench_refuses_a_multi_rank_run_that_is_not_over_rccl():
     if torch.cuda.device_count() != 1:
         pytest.skip("needs exactly one visible GPU")
     env = {k: v for k, v in os.environ.items() if k != "NAVBOT_DIST_BACKEND"}
+    from _ranks import free_port
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29641", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--master-port", str(free_port()), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--envs-per-gpu", "256", "--rollout", "16", "--epochs", "1", "--no-extras"]
     out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=600)
     assert out.returncode != 0
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    # ... and for THIS reason: bench.py's own refusal, or RCCL rejecting two ranks on one device before bench.py gets that far --
+    # not a busy port or any other start-up failure that would make the test pass for the wrong reason
+    err = out.stderr + out.stdout
+    assert ("refusing to report a scaling number" in err or "one rank per GPU" in err or "NCCL" in err or "nccl" in err), err[-2000:]
+    assert "EADDRINUSE" not in err and "address already in use" not in err.lower(), err[-2000:]
 
 
 def test_degenerate_small_segments_take_the_ieee_divide_path():
@@ -1068,7 +1074,7 @@ def test_step_seq_against_the_oracle(case):
     8192-env shard on the shared 2048-segment house map with the start / goal tables (tile boxes); `cfg4_36beams` a 4096-env shard
     of configs[3] (stage_4, 36 beams: stage B on (segment, beam-group) entries); `hbm_stream` per-env maps large enough that one
     step's segment stream exceeds 1.25 x the Infinity Cache (navsim_set_map switches the persistent kernels' segment loads to
-    non-temporal; the one-launch-per-step kernel always streams per-env maps that way)."""
+    non-temporal; the one-launch-per-step kernel streams per-env maps that way from 32 MiB on its 32 / 64-env 10-beam shapes -- navsim_get_info: step_cast == 2)."""
     if case == "small":
         seg = maps.replicate_per_env(maps.stage_2(), 512, seed=2)
         _seq_vs_oracle(512, seg, True, 48, [(0, 512)], max_episode_steps=20, auto_reset=True, respawn_on_arrive=True, seed=9)

@@ -7,7 +7,10 @@ RND = os.environ.get("ROUND", "r04")
 O, P = os.path.join(R, "gpurun_out", RND), os.path.join(R, "profiles")
 for f in sorted(glob.glob(os.path.join(O, "*_kernel_stats.csv")) + glob.glob(os.path.join(O, "*_pmc.txt"))):
     shutil.copy(f, os.path.join(P, f"{RND}_" + os.path.basename(f)))
-for a in ("run_id.txt", "hbm_legs_hip_events.txt", "rollout_shard_sizes.txt", "update_scale.txt", "time_rtg.txt"):
+for a in ("run_id.txt", "hbm_legs_hip_events.txt", "rollout_shard_sizes.txt", "update_scale.txt", "time_rtg.txt",
+          # round 5: the update passes of both arithmetics / of the 42-column rows, the split pass's error table and microbenchmarks, the PPO shards
+          "update_arith_hip_events.txt", "update_wide_hip_events.txt", "bf16x3_error.txt", "bf16_mfma_valu_overlap.txt",
+          "bf16_mfma_fillers.txt", "bf16_split_ops.txt", "ppo_cfg4.json", "ppo_cfg5.json"):
     if os.path.exists(os.path.join(O, a)):
         shutil.copy(os.path.join(O, a), os.path.join(P, f"{RND}_{a}"))
 shutil.copy(os.path.join(O, "pmc_traffic.json"), os.path.join(P, "pmc_traffic.json"))

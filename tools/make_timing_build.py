@@ -48,8 +48,8 @@ rep("        // the observation tile of step t + 1 is in sm.obs (its store only 
 rep("        const bool more = t + 1 < T;\n        auto hook = [&](const int wv, const int ln) __attribute__((always_inline)) {\n            if (more) {\n                if (wv >= kTileWave0 && wv < kTileWave0 + TW) tile_policy(wv - kTileWave0, tn + N, (t + 1) & 1, std::true_type{});",
     "        const bool more = true; const bool more_real = t + 1 < T;\n        auto hook = [&](const int wv, const int ln) __attribute__((always_inline)) {\n            if (more) {\n                if (wv >= kTileWave0 && wv < kTileWave0 + TW) tile_policy(wv - kTileWave0, more_real ? tn + N : tn, (t + 1) & 1, std::true_type{});")
 rep("int navsim_blk_read(long long* out)", "int navsim_pol_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pol), sizeof(long long) * 256); }\nint navsim_blk_read(long long* out)")
-if "--lb4" in extra_flags:
-    rep("__global__ __launch_bounds__(kThreads) void step_kernel", "__global__ __launch_bounds__(kThreads, 4) void step_kernel")
+# (--lb4, a forced launch bound of four waves per SIMD on step_kernel, is gone: the kernels carry their own bound since round 4 --
+# min_waves_per_simd in csrc/navsim.hip)
 os.makedirs(os.path.join(R, "build"), exist_ok=True)
 open("/tmp/navsim_timing.hip", "w").write(t)
 sys.path.insert(0, R)
