@@ -361,8 +361,8 @@ def ppo_shard_leg(n_envs, world, n_beams, obs_f16, sampler, rollout, epochs, det
                ms_per_step=round(dt / steps * 1e3, 3), rollout_ms=round(r / steps * 1e3, 3), update_ms=round(u / steps * 1e3, 3),
                rollout_us_per_step=round(r / steps / rollout * 1e6, 2),
                rollout=("persistent kernel (navsim_rollout_mlp64: " + ("rollout_big_kernel, 64 envs on 16 waves" if inf["rollout_kind"] == 2
-                        else f"rollout_kernel, {inf['rollout_epb']} envs on 8 waves") + ")") if tr.updater.fused_mlp64 and not
-               (inf["tile_boxes"] and inf["rollout_kind"] == 1) else "hipGraph of navppo_mlp64_act + navsim_step launches",
+                        else f"rollout_kernel, {inf['rollout_epb']} envs on 8 waves") + (", tile boxes" if inf["rollout_cast"] == 3 else "") + ")")
+               if tr.updater.fused_mlp64 else "hipGraph of policy + navsim_step launches",
                update="navppo_mlp64_update_epoch" if tr.updater.fused_mlp64 else "PyTorch-ROCm", update_roofline=roof,
                last_iter={k: lg[k] for k in ("avg_ep_rews", "success_rate", "episodes")}, bound_detail=detail)
     env.close()

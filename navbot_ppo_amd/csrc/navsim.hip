@@ -526,7 +526,9 @@ __device__ __forceinline__ void step_body(PRef P, StepSmem<NB, EPB, NW>& sm, int
     //   one launch per step   S=128 13.11 / 12.64   S=256 18.58 / 17.62   S=512-1024 equal   S=1280 66.2 / 60.8   S=1536 82.4 / 71.8
     //   persistent (tape)     S=128  9.74 / 10.93   S=256 14.69 / 16.91   S=1024 41.6 / 48.2  S=1280 equal         S=1536 73.8 / 71.5
     // A launch reads every segment once and the next launch finds nothing of a >= 35 MB stream in the 8 x 4 MB of L2 (LRU), so
-    // allocating the lines there is pure overhead: step_kernel always streams.  A persistent workgroup re-reads ITS envs' segments every
+    // allocating the lines there is pure overhead: step_kernel streams (PAIR == 2) whenever the per-env stream is >= 32 MiB AND the shape is a
+    // big 10-beam one (32 / 64 envs per workgroup: pick_shape; the ablation above was taken there -- the 8 / 16-env shapes of shards up to
+    // 8192 envs and the 36-beam shapes keep the default policy).  A persistent workgroup re-reads ITS envs' segments every
     // step from its own XCD's L2 / the Infinity Cache (traffic 0.77 x algorithmic at configs[2]) and keeps the default policy until
     // one step's stream exceeds 1.25 x the Infinity Cache (bit 1 of per_env, navsim_set_map), where nothing can be re-used either.
     // (Below 32 MiB the stream fits the L2s and is left there: bit 2.)  The host picks the PAIR == 2 instantiation accordingly.
@@ -1418,7 +1420,7 @@ struct RolloutArgs {
     int T;
 };
 
-template <int NB, int EPB, bool SENS, int NW>
+template <int NB, int EPB, bool SENS, int NW, bool BOXES = false>
 __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs R) {
     constexpr int D = NB + 6, DP = D + 1, kThreads = 64 * NW;
     using PL = mlp64::Layout<D>;   // the (B + 6)-64-64 policy: 16-wide rows with 10 beams, 42-wide with 36
@@ -1538,8 +1540,8 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
                 }
             }
         };
-        step_body<NB, EPB, SENS, true, NW, false, false, const Params&, const StepIO&, decltype(hook)>(P, sm, next_env, io,
-                                                                                                     t == R.T - 1, 0, hook);
+        step_body<NB, EPB, SENS, true, NW, BOXES, 0, const Params&, const StepIO&, decltype(hook)>(P, sm, next_env, io,
+                                                                                                 t == R.T - 1, 0, hook);
         // the observation tile of step t + 1 is in sm.obs (its store only reads it), its action in sm.act_l
     }
 }
@@ -2157,13 +2159,18 @@ static RolloutPick pick_rollout(const navsim* h) {
     if (h->P.B != 10 && h->P.B != 36) return rp;
     const bool boxes = h->P.tile_box != nullptr;
     const bool pair = h->pair_cast && !boxes && h->P.S > 64 && h->P.seg_pack_log2 == 6;
-    if (h->P.B == 10 && (h->force_epb == 64 || (h->force_epb == 0 && h->P.N > 16 * 256))) {
+    if (h->P.B == 10 && (h->force_epb == 64 || h->force_epb == 32 || (h->force_epb == 0 && h->P.N > 16 * 256))) {
         rp.kind = 2; rp.epb = 64; rp.waves = 16;
+        // tile-box maps (the 2048-segment house map: a vector-issue-bound cast) on 4097..8192 envs: 64-env workgroups would leave half
+        // the CUs empty (8192 envs: 35.4 us per step) -- 32 envs on 8 waves, one workgroup on every CU
+        if (h->force_epb == 32 || (h->force_epb == 0 && boxes && h->P.N <= 32 * 256)) rp.epb = 32, rp.waves = 8;
         rp.cast = boxes ? 3 : (pair ? ((h->P.per_env & 2) ? 2 : 1) : 0);   // 2: one step's per-env stream exceeds 1.25 x the Infinity Cache
+        if (rp.epb == 32 && rp.cast != 3) rp.cast = 0;   // (the forced 32-env shape exists with 64-segment passes and with tile boxes)
         return rp;
     }
-    rp.kind = 1; rp.waves = 8; rp.cast = 0;
-    rp.epb = (h->P.B == 10 && (h->force_epb == 4 || h->force_epb == 8)) ? h->force_epb : 16;
+    rp.kind = 1; rp.waves = 8;
+    rp.epb = (h->P.B == 10 && !boxes && (h->force_epb == 4 || h->force_epb == 8)) ? h->force_epb : 16;
+    rp.cast = boxes ? 3 : 0;   // (round 5: the 16-env shape has the tile-box cast too -- the house map on shards up to 4096 envs)
     return rp;
 }
 
@@ -2545,14 +2552,22 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, void* obs_b
                                   : (void*)(reinterpret_cast<float*>(obs_buf_dev) + (size_t)h->P.N * D);
         io.reward = reward_dev; io.done = done_dev; io.arrive = arrive_dev; io.ended = ended_dev;
         io.ep_return = ep_return_dev; io.ep_length = ep_length_dev; io.ep_path_out = ep_path_dev;
-        const dim3 grid((h->P.N + 63) / 64), block(64 * 16);
+        const dim3 grid((h->P.N + rp.epb - 1) / rp.epb), block(64 * rp.waves);
         const BigKArgs ka = {h->P, R, io};
 #define NAVSIM_BIG(BOXES_, PAIR_)                                                                                         \
     do {                                                                                                                  \
         if (sens) hipLaunchKernelGGL((rollout_big_kernel<64, true, 16, BOXES_, PAIR_>), grid, block, 0, st, ka);   \
         else hipLaunchKernelGGL((rollout_big_kernel<64, false, 16, BOXES_, PAIR_>), grid, block, 0, st, ka);       \
     } while (0)
-        if (rp.cast == 3) NAVSIM_BIG(true, 0);
+        if (rp.epb == 32) {   // (tile boxes; forced: any map without the 128-segment passes)
+            if (rp.cast == 3) {
+                if (sens) hipLaunchKernelGGL((rollout_big_kernel<32, true, 8, true, 0>), grid, block, 0, st, ka);
+                else hipLaunchKernelGGL((rollout_big_kernel<32, false, 8, true, 0>), grid, block, 0, st, ka);
+            } else {
+                if (sens) hipLaunchKernelGGL((rollout_big_kernel<32, true, 8, false, 0>), grid, block, 0, st, ka);
+                else hipLaunchKernelGGL((rollout_big_kernel<32, false, 8, false, 0>), grid, block, 0, st, ka);
+            }
+        } else if (rp.cast == 3) NAVSIM_BIG(true, 0);
         else if (rp.cast == 2) NAVSIM_BIG(false, 2);
         else if (rp.cast == 1) NAVSIM_BIG(false, 1);
         else NAVSIM_BIG(false, 0);
@@ -2564,8 +2579,16 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, void* obs_b
     constexpr int kRollWaves = 8;
     const dim3 grid((h->P.N + rp.epb - 1) / rp.epb), block(64 * kRollWaves);
     if (h->P.B == 36) {
-        if (sens) hipLaunchKernelGGL((rollout_kernel<36, 16, true, kRollWaves>), grid, block, 0, st, h->P, R);
-        else hipLaunchKernelGGL((rollout_kernel<36, 16, false, kRollWaves>), grid, block, 0, st, h->P, R);
+        if (rp.cast == 3) {
+            if (sens) hipLaunchKernelGGL((rollout_kernel<36, 16, true, kRollWaves, true>), grid, block, 0, st, h->P, R);
+            else hipLaunchKernelGGL((rollout_kernel<36, 16, false, kRollWaves, true>), grid, block, 0, st, h->P, R);
+        } else {
+            if (sens) hipLaunchKernelGGL((rollout_kernel<36, 16, true, kRollWaves>), grid, block, 0, st, h->P, R);
+            else hipLaunchKernelGGL((rollout_kernel<36, 16, false, kRollWaves>), grid, block, 0, st, h->P, R);
+        }
+    } else if (rp.cast == 3) {
+        if (sens) hipLaunchKernelGGL((rollout_kernel<10, 16, true, kRollWaves, true>), grid, block, 0, st, h->P, R);
+        else hipLaunchKernelGGL((rollout_kernel<10, 16, false, kRollWaves, true>), grid, block, 0, st, h->P, R);
     } else if (rp.epb == 4) {
         if (sens) hipLaunchKernelGGL((rollout_kernel<10, 4, true, kRollWaves>), grid, block, 0, st, h->P, R);
         else hipLaunchKernelGGL((rollout_kernel<10, 4, false, kRollWaves>), grid, block, 0, st, h->P, R);

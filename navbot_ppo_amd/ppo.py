@@ -586,15 +586,9 @@ class PPOTrainer:
         self.eplen_buf.zero_()
         self.env.sim.reset(self.obs_buf[0])  # ppo.py:486: every batch starts from a reset
         sim = self.env.sim
-        # shared maps of 65..4096 segments carry tile bounding boxes (navsim_set_map); up to 4096 envs per GPU only the per-step
-        # kernel's BOXES instantiation uses them to skip whole tiles, so there the hipGraph of per-step launches is the faster
-        # rollout (beyond 4096 envs navsim_rollout_mlp64 runs rollout_big_kernel, which has the cast variants of the step kernel)
-        tile_boxes = False
-        # (navsim_get_info names the kernel navsim_rollout_mlp64 would launch: kind 1 = the 16-env shape, cast without tile boxes)
-        if cfg.persistent_rollout and self.updater.fused_mlp64:
-            inf = sim.info()
-            tile_boxes = bool(inf["tile_boxes"]) and inf["rollout_kind"] == 1
-        if cfg.persistent_rollout and self.updater.fused_mlp64 and self.env.B in (10, 36) and not tile_boxes:
+        # (round 5: both rollout kernels have the tile-box cast of shared 65..4096-segment maps; until then shards up to 4096 envs on
+        # such a map took the hipGraph of per-step launches)
+        if cfg.persistent_rollout and self.updater.fused_mlp64 and self.env.B in (10, 36):
             self._persistent_rollout()
         elif cfg.use_graph and self.device.type == "cuda":
             if self._graph is not None and self._graph_gen != self.env.sim.generation:

@@ -80,3 +80,45 @@ def test_library_reads_no_shape_knobs_from_the_environment():
     # argument checks run without a device
     assert L.navsim_set_shape(None, 16, -1) != 0
     assert L.navsim_get_info(None, None) != 0
+
+
+def test_ctypes_structs_match_the_c_headers(tmp_path):
+    """navsim_cfg / navsim_info as the C compiler lays them out (gcc on include/navsim.h) against the ctypes mirrors of
+    navbot_ppo_amd/_native.py: size and every field offset."""
+    import subprocess
+    from navbot_ppo_amd import _native
+    fields = {"navsim_cfg": [n for n, _ in _native.NavsimCfg._fields_], "navsim_info": [n for n, _ in _native.NavsimInfo._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "navsim.h"', '#include "navppo.h"', 'int main(void) {']
+    for st, fs in fields.items():
+        src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for f in fs:
+            src.append(f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    src += ['  printf("actor16 %d critic16 %d actor42 %d critic42 %d\\n", NAVPPO_MLP64_ACTOR_PARAMS, NAVPPO_MLP64_CRITIC_PARAMS,',
+            '         NAVPPO_MLP64_ACTOR_PARAMS_D(42), NAVPPO_MLP64_CRITIC_PARAMS_D(42));', '  return 0; }']
+    c = tmp_path / "abi.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(c), "-o", str(exe)])
+    got = dict(line.rsplit(" ", 1) for line in subprocess.check_output([str(exe)], text=True).splitlines() if not line.startswith("actor16"))
+    for st, cls in (("navsim_cfg", _native.NavsimCfg), ("navsim_info", _native.NavsimInfo)):
+        assert int(got[st]) == ctypes.sizeof(cls), st
+        for f in fields[st]:
+            assert int(got[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
+    tail = subprocess.check_output([str(exe)], text=True).splitlines()[-1]
+    assert tail == "actor16 5378 critic16 5313 actor42 7042 critic42 6977"
+    # the flat parameter counts the Python side derives from the net shapes are the header's
+    import torch
+    from navbot_ppo_amd import nets
+    for d, (pa, pc) in ((16, (5378, 5313)), (42, (7042, 6977))):
+        a, c_ = nets.make_policy("mlp64x2", d)
+        assert (sum(p.numel() for p in a.parameters()), sum(p.numel() for p in c_.parameters())) == (pa, pc)
+
+
+def test_update_arith_is_validated_on_the_cpu_too():
+    import torch
+    from navbot_ppo_amd import nets, ppo
+    a, c = nets.make_policy("mlp64x2")
+    with pytest.raises(ValueError):
+        ppo.PPOUpdater(a, c, ppo.PPOConfig(policy="mlp64x2", update_arith="bf16"), None, torch.device("cpu"))
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(policy="mlp64x2"), None, torch.device("cpu"))
+    assert up.fused is None and up.bf16x3 is False and up.obs_dim == 16   # no HIP device: PyTorch formulation, no split pass

@@ -178,6 +178,8 @@ ROLLOUT_CASES = [
     (16384, 30, "stage_2", True, 10, True, None, None),       # f16 on the 128-segment passes
     (200, 50, "stage_1", False, 10, True, None, 64),          # the 64-env shape forced onto a small ragged shard
     (120, 40, "stage_4", False, 36, True, None, None),        # both at once
+    (1000, 36, "house", False, 36, False, "small_house", None),   # 36 beams on the house map: the 16-env rollout kernel's tile-box cast
+    (2048, 34, "house", False, 10, True, "small_house", None),    # float16 rows + tile boxes on the 16-env shape
 ]
 
 

@@ -249,7 +249,12 @@ def test_cli_train_resume_eval(tmp_path):
     # onto small ragged shards (200 = 3 workgroups + 8 envs; 40 envs: one partial policy tile)
     (16384, 40, "stage_1", False, None), (16384, 36, "stage_2", True, None), (16384, 34, "house", False, None),
     (4160, 40, "stage_1", False, None), (6144, 36, "stage_2", True, None),   # the first shard sizes of the 64-env shape
-    (200, 60, "stage_1", False, "64"), (40, 50, "stage_2", True, "64"), (1000, 36, "house", False, "64")])
+    (200, 60, "stage_1", False, "64"), (40, 50, "stage_2", True, "64"), (1000, 36, "house", False, "64"),
+    # round 5: the 16-env rollout kernel with the tile-box cast (shared 65..4096-segment maps on shards up to 4096 envs; until then such
+    # shards took the hipGraph of per-step launches)
+    (1000, 36, "house", False, None), (4096, 34, "house", False, None),
+    # ... and the 32-env closed-loop shape (tile-box maps on 4097..8192 envs: one workgroup on every CU), natural and forced
+    (8192, 34, "house", False, None), (200, 50, "stage_1", False, "32"), (1000, 36, "house", False, "32"), (96, 40, "stage_2", True, "32")])
 def test_persistent_rollout_equals_per_step_rollout(N, T, map_name, per_env, epb, sens, monkeypatch):
     """navsim_rollout_mlp64 (all T steps in one launch) against T pairs of navppo_mlp64_act / navsim_step: same device
     functions and Philox keys, so every rollout buffer and the simulator state must come out bit-identical -- over two
@@ -266,6 +271,10 @@ def test_persistent_rollout_equals_per_step_rollout(N, T, map_name, per_env, epb
         cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=30, n_updates_per_iteration=1, policy="mlp64x2", seed=5,
                             persistent_rollout=persistent, use_graph=False)
         tr = ppo.PPOTrainer(env, cfg)
+        if persistent and map_name == "house":   # the tile-box cast in whichever rollout kernel the shard selects
+            inf = env.sim.info()
+            assert inf["tile_boxes"] == 1 and inf["rollout_cast"] == 3 and inf["rollout_kind"] == (2 if (N > 4096 or epb in ("64", "32")) else 1), inf
+            assert inf["rollout_epb"] == (32 if (epb == "32" or (epb is None and 4096 < N <= 8192)) else 64 if (N > 4096 or epb == "64") else 16), inf
         bufs = []
         for _ in range(2):
             tr.rollout()

@@ -37,37 +37,46 @@ if "--rollout" not in sys.argv:   # (--rollout: only the closed-loop part below)
     soak(8192, seg, False, 60, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi))
     soak(2048, maps.stage_4(), False, 300, B=36)
     soak(2048, maps.replicate_per_env(maps.stage_2(sides=56), 2048, seed=3), True, 300, amax=3.0)
+    # round 5 (ADVICE: the 36-beam stage B tests only the beams of a segment's float32 extent +- 0.02 beams): 36 beams on per-env maps, on
+    # the house map (near-sensor and grazing segments, tile boxes) and with fast spins
+    soak(2048, maps.replicate_per_env(maps.stage_2(), 2048, seed=4), True, 300, B=36)
+    soak(2048, seg, False, 250, B=36, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi))
+    soak(1024, maps.replicate_per_env(maps.stage_2(sides=56), 1024, seed=5), True, 300, B=36, amax=3.0)
 
 
-def soak_rollout(N, seg, per_env, T, iters=2, cap=60, seed=_S0, sampler=None):
+def soak_rollout(N, seg, per_env, T, iters=2, cap=60, seed=_S0, sampler=None, B=10, half=False):
     """The persistent rollout CLOSED-LOOP (navsim_rollout_mlp64: rollout_big_kernel beyond 4096 envs): the actions the in-kernel policy
     chose are replayed on the oracle for EVERY env; every observation row, flag and reward of every step is compared."""
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
-    env = VecEnv(N, map=seg, max_episode_steps=cap, seed=seed, per_env_map=False, sampler=sampler)
+    env = VecEnv(N, map=seg, n_beams=B, max_episode_steps=cap, seed=seed, per_env_map=False, sampler=sampler, obs_f16=half)
     tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=T, max_episode_steps=cap, policy="mlp64x2", seed=seed + 1))
     with torch.no_grad():
         tr.actor.layer3.bias.add_(2.0)   # drive forward: collisions and arrivals, not only timeouts
-    cpu = O.OracleSim(N, max_episode_steps=cap, auto_reset=True, seed=seed)
+    cpu = O.OracleSim(N, n_beams=B, max_episode_steps=cap, auto_reset=True, seed=seed)
     cpu.set_map(seg, per_env=per_env)
     if sampler: cpu.set_spawn_sampler(*sampler)
+    # float16 buffers: a row must be the oracle's row rounded to half (compared in half: 1e-6 before the rounding = at most one half ulp)
+    rnd = (lambda x: x.astype(np.float16).astype(np.float32)) if half else (lambda x: x)
+    tol = 1e-3 if half else 1e-6
     bad = 0; exact = 0; tot = 0; ends = 0; mx = 0.0; mr = 0.0
     for it in range(iters):
         tr.rollout(); torch.cuda.synchronize()
-        obs, acts = tr.obs_buf.cpu().numpy(), tr.act_buf.cpu().numpy()
+        obs, acts = tr.obs_buf.float().cpu().numpy(), tr.act_buf.cpu().numpy()
         fl = {k: getattr(tr, k + "_buf").cpu().numpy() for k in ("done", "arrive", "ended", "rew")}
         o0 = cpu.reset()   # ppo.py:486: every batch starts from a reset
-        bad += int(np.abs(obs[0] - o0).max() > 1e-6)
+        bad += int(np.abs(obs[0] - rnd(o0)).max() > tol)
         for t in range(T):
             out = cpu.step(acts[t])
+            out["obs"] = rnd(out["obs"])
             d = np.abs(obs[t + 1] - out["obs"]).max(); mx = max(mx, d)
             mr = max(mr, float(np.abs(fl["rew"][t] - out["reward"]).max()))
             f = sum(int((fl[k][t] != out[k]).sum()) for k in ("done", "arrive", "ended"))
-            bad += f + int(d > 1e-6)
+            bad += f + int(d > tol)
             exact += int((obs[t + 1] == out["obs"]).all(1).sum()); tot += N; ends += int(out["ended"].sum())
-            if f or d > 1e-6:
+            if f or d > tol:
                 print("MISMATCH iteration", it, "step", t, "maxdiff", d, "flags", f); break
-    print(f"closed-loop rollout N={N} S={seg.shape[-2]} per_env={per_env} T={T} x {iters}: bad={bad} max|dobs|={mx:.2e} max|dreward|={mr:.2e} "
+    print(f"closed-loop rollout N={N} S={seg.shape[-2]} per_env={per_env} B={B} {'f16' if half else 'f32'} rows T={T} x {iters}: bad={bad} max|dobs|={mx:.2e} max|dreward|={mr:.2e} "
           f"exact rows {exact/tot:.5f} episode ends {ends}")
     env.close()
 
@@ -77,3 +86,8 @@ if True:
     soak_rollout(16384, maps.stage_1(), False, 200)
     soak_rollout(16384, seg, False, 60, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi))
     soak_rollout(4096, maps.stage_1(), False, 512, cap=500)
+    # round 5: the 36-beam and float16 instantiations of the rollout kernels (configs[3]'s / configs[4]'s shards and around them)
+    soak_rollout(4096, maps.stage_4(), False, 400, cap=200, B=36)
+    soak_rollout(8192, seg, False, 80, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi), half=True)
+    soak_rollout(4096, maps.stage_1(), False, 300, cap=150, half=True)
+    soak_rollout(4608, maps.stage_4(), False, 120, B=36, half=True)
