@@ -101,7 +101,11 @@ typedef struct navsim_info {
     int32_t step_epb, step_waves, step_cast;       /* navsim_step */
     int32_t seq_epb, seq_waves, seq_cast;          /* navsim_step_seq */
     int32_t rollout_kind, rollout_epb, rollout_waves, rollout_cast;   /* navsim_rollout_mlp64 */
-    int32_t reserved[12];
+    /* resources of the selected step / tape instantiations as the loaded code object reports them (hipFuncGetAttributes):
+       vector registers per lane, scratch bytes per lane (= spilled registers x 4; 0 = none), static LDS bytes per workgroup */
+    int32_t step_vgprs, step_scratch_bytes, step_lds_bytes;
+    int32_t seq_vgprs, seq_scratch_bytes, seq_lds_bytes;
+    int32_t reserved[6];
 } navsim_info;
 int navsim_get_info(navsim_t* h, navsim_info* out);
 

@@ -40,7 +40,8 @@ class NavsimInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "n_envs", "n_beams", "obs_f16", "n_segments", "per_env_map", "tile_boxes", "has_map",
         "forced_epb", "forced_pair_cast", "step_epb", "step_waves", "step_cast", "seq_epb", "seq_waves", "seq_cast",
-        "rollout_kind", "rollout_epb", "rollout_waves", "rollout_cast")] + [("reserved", C.c_int32 * 12)]
+        "rollout_kind", "rollout_epb", "rollout_waves", "rollout_cast", "step_vgprs", "step_scratch_bytes", "step_lds_bytes",
+        "seq_vgprs", "seq_scratch_bytes", "seq_lds_bytes")] + [("reserved", C.c_int32 * 6)]
 
 
 # every symbol include/navsim.h declares: (name, restype, argtypes)

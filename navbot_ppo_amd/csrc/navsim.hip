@@ -2115,14 +2115,18 @@ static ShapePick pick_shape(const navsim* h, bool tape) {
         } else NAVSIM_DISPATCH_CAST(KERNEL, 16, 8);                                \
     } while (0)
 
+// `query` non-null: the selected instantiation is not launched, its resources (registers, scratch = spilled registers, LDS) are read
+// into *query (navsim_get_info: the run-time check that what the rule picks fits the way the rule assumes)
 template <int NB>
 static void launch_step(const navsim* h, const float* action, const float* past, void* obs, float* reward, uint8_t* done,
-                        uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len, float* ep_path, hipStream_t st) {
+                        uint8_t* arrive, uint8_t* ended, float* ep_ret, int32_t* ep_len, float* ep_path, hipStream_t st,
+                        hipFuncAttributes* query = nullptr) {
     const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
     const StepKArgs ka = {h->P, StepIO{(const float2*)action, (const float2*)past, obs, reward, done, arrive, ended, ep_ret, ep_len,
                                        ep_path}};
     auto go = [&](auto kernel, int epb, int nw) {
-        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
+        if (query) (void)hipFuncGetAttributes(query, reinterpret_cast<const void*>(kernel));
+        else hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
     };
     const ShapePick sp = pick_shape(h, false);
     NAVSIM_DISPATCH_SHAPE(step_kernel);
@@ -2130,11 +2134,12 @@ static void launch_step(const navsim* h, const float* action, const float* past,
 
 // navsim_step_seq: the same shapes and cast variants, all steps of the tape in one launch
 template <int NB>
-static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st) {
+static void launch_steps(const navsim* h, const SeqArgs& R, hipStream_t st, hipFuncAttributes* query = nullptr) {
     const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
     const SeqKArgs ka = {h->P, R};
     auto go = [&](auto kernel, int epb, int nw) {
-        hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
+        if (query) (void)hipFuncGetAttributes(query, reinterpret_cast<const void*>(kernel));
+        else hipLaunchKernelGGL(kernel, dim3((h->P.N + epb - 1) / epb), dim3(64 * nw), 0, st, ka);
     };
     const ShapePick sp = pick_shape(h, true);
     NAVSIM_DISPATCH_SHAPE(steps_kernel);
@@ -2348,6 +2353,17 @@ int navsim_get_info(navsim_t* h, navsim_info* out) {
         out->seq_epb = b.epb; out->seq_waves = b.waves; out->seq_cast = b.cast;
         const RolloutPick r = pick_rollout(h);
         out->rollout_kind = r.kind; out->rollout_epb = r.epb; out->rollout_waves = r.waves; out->rollout_cast = r.cast;
+        hipFuncAttributes fa;
+        std::memset(&fa, 0, sizeof(fa));
+        if (h->P.B == 10) launch_step<10>(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &fa);
+        else launch_step<36>(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &fa);
+        out->step_vgprs = fa.numRegs; out->step_scratch_bytes = (int32_t)fa.localSizeBytes; out->step_lds_bytes = (int32_t)fa.sharedSizeBytes;
+        std::memset(&fa, 0, sizeof(fa));
+        SeqArgs sr;
+        std::memset(&sr, 0, sizeof(sr));
+        if (h->P.B == 10) launch_steps<10>(h, sr, nullptr, &fa);
+        else launch_steps<36>(h, sr, nullptr, &fa);
+        out->seq_vgprs = fa.numRegs; out->seq_scratch_bytes = (int32_t)fa.localSizeBytes; out->seq_lds_bytes = (int32_t)fa.sharedSizeBytes;
     }
     return NAVSIM_OK;
 }

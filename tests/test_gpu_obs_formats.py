@@ -357,6 +357,9 @@ def test_two_handles_with_different_forced_shapes_in_one_process():
     infos = [e.sim.info() for e in envs]
     assert [(i["step_epb"], i["step_waves"], i["step_cast"]) for i in infos[:2]] == [(8, 8, 1), (64, 16, 0)]
     assert infos[2]["forced_epb"] == 0 and infos[2]["step_epb"] == 16 and infos[0]["n_segments"] == 128 and infos[0]["per_env_map"] == 1
+    for i in infos:   # the resources of the selected instantiations, as the loaded code object reports them
+        for k in ("step", "seq"):
+            assert 32 <= i[k + "_vgprs"] <= 512 and 0 < i[k + "_lds_bytes"] <= 160 * 1024 and 0 <= i[k + "_scratch_bytes"] <= 512, i
     cpu = O.OracleSim(N, max_episode_steps=20, auto_reset=True, seed=5)
     cpu.set_map(envs[0].sim._seg.cpu().numpy(), per_env=True)
     rr, rs = maps.goal_rects("stage_2")
