@@ -360,7 +360,7 @@ def ppo_shard_leg(n_envs, world, n_beams, obs_f16, sampler, rollout, epochs, det
                value=round(steps * rollout * n_envs / dt, 1), unit="env-steps/s per GPU", steps=steps,
                ms_per_step=round(dt / steps * 1e3, 3), rollout_ms=round(r / steps * 1e3, 3), update_ms=round(u / steps * 1e3, 3),
                rollout_us_per_step=round(r / steps / rollout * 1e6, 2),
-               rollout=("persistent kernel (navsim_rollout_mlp64: " + ("rollout_big_kernel, 64 envs on 16 waves" if inf["rollout_kind"] == 2
+               rollout=("persistent kernel (navsim_rollout_mlp64: " + (f"rollout_big_kernel, {inf['rollout_epb']} envs on {inf['rollout_waves']} waves" if inf["rollout_kind"] == 2
                         else f"rollout_kernel, {inf['rollout_epb']} envs on 8 waves") + (", tile boxes" if inf["rollout_cast"] == 3 else "") + ")")
                if tr.updater.fused_mlp64 else "hipGraph of policy + navsim_step launches",
                update="navppo_mlp64_update_epoch" if tr.updater.fused_mlp64 else "PyTorch-ROCm", update_roofline=roof,

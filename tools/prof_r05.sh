@@ -19,4 +19,6 @@ python tools/time_ppo_shard.py cfg5 2>/dev/null | tail -1 > $O/ppo_cfg5.json
 ./build/bf16_overlap > $O/bf16_mfma_valu_overlap.txt 2>&1
 ./build/bf16_fillers > $O/bf16_mfma_fillers.txt 2>&1
 ./build/bf16_split_ops > $O/bf16_split_ops.txt 2>&1
+python tools/show_info.py 2>&1 | grep -v amdgpu > $O/selected_instantiations.txt
+python tools/time_house_rollout.py 2>&1 | grep -v amdgpu > $O/house_rollout_shapes.txt
 tail -c 600 $O/bench_final.json; echo; cat $O/update_arith_hip_events.txt $O/update_wide_hip_events.txt
