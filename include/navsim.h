@@ -253,6 +253,21 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, void* obs_b
                          uint64_t act_seed, const uint32_t* step_base_dev, int32_t n_steps, void* stream);
 
 /*
+ * The same hot loop (ppo.py:505-594) with the reference's ACTIVE actor choosing every action in the kernel: NetActor
+ * (project_ppo/src/net_actor.py:56-144 -- two residual blocks of 512 hidden units, LeakyReLU(0.2), heads sigmoid / tanh), i.e. per
+ * step what navppo_resmlp512_act computes (include/navppo.h) followed by what navsim_step computes, all n_steps steps in ONE launch;
+ * buffers, noise keys and bit-for-bit equality with the per-step entry points as for navsim_rollout_mlp64.
+ *   actor_params_dev [NAVPPO_RESMLP512_ACTOR_PARAMS = 50290] f32, the layout of navppo.h (no BatchNorm entries)
+ *   obs_buf_dev [n_steps + 1, N, 16] f32.   Needs n_beams == 10 and float32 observations (the 512-wide kernels read float32 rows).
+ * 16 envs on 8 waves per workgroup at every shard size (each wave owns 64 hidden units; the 197 KB of weights stream from L2 every
+ * step), 64-segment passes for every map (no tile boxes: correct on every map, the house map just tests all its tiles).
+ */
+int navsim_rollout_resmlp512(navsim_t* h, const float* actor_params_dev, float* obs_buf_dev, float* act_buf_dev, float* logp_buf_dev,
+                             float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev, float* ep_return_dev,
+                             int32_t* ep_length_dev, float* ep_path_dev, const float* var_dev, uint64_t act_seed,
+                             const uint32_t* step_base_dev, int32_t n_steps, void* stream);
+
+/*
  * n_steps calls of navsim_step with the actions of a tape, in ONE launch: the step loop of PPO.rollout (ppo.py:505-594) or of the
  * evaluation loop (main.py:176-235) when the actions do not depend on the observations being produced -- a recorded tape, a
  * scripted or random policy, an open-loop controller.  A workgroup keeps its envs for the whole tape (their state stays on chip

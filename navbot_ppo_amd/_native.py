@@ -66,6 +66,7 @@ SYMBOLS = [
     ("navsim_raycast", C.c_int, [_vp, _vp, _vp, _vp]),
     ("navsim_odometry", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("navsim_rollout_mlp64", C.c_int, [_vp] * 13 + [C.c_uint64, _vp, _i32, _vp]),
+    ("navsim_rollout_resmlp512", C.c_int, [_vp] * 13 + [C.c_uint64, _vp, _i32, _vp]),
     ("navsim_step_seq", C.c_int, [_vp, _vp, _i32] + [_vp] * 9),
     # include/navppo.h
     ("navppo_last_error", C.c_char_p, []),

@@ -42,6 +42,7 @@
 
 #include "navsim.h"
 #include "mlp64_policy.h"
+#include "resmlp_policy.h"
 
 namespace {
 
@@ -1546,6 +1547,101 @@ __global__ __launch_bounds__(64 * NW) void rollout_kernel(Params P, RolloutArgs 
     }
 }
 
+// ---------------------------------------------------------------- the persistent rollout for the reference's ACTIVE actor
+// PPO.rollout (ppo.py:463-641) with NetActor (net_actor.py:56-144: two residual blocks of 512 hidden units) choosing every action
+// in the kernel: rollout_kernel's workgroup (16 envs on 8 waves, env state and observation tile in LDS for all T steps) with the
+// policy step of csrc/resmlp_policy.h -- the one navppo_resmlp512_act launches per step -- in front of every env step: all eight
+// waves (each owns 64 hidden units), two workgroup sums, wave 0 finishes (clamp, log-prob of the clamped action); the Philox /
+// Box-Muller noise of step t + 1 is drawn inside step t (wave 5, behind barrier B2, where it would only wait for the rules).
+// Same device functions and Philox keys as the per-step entry points: every row of the [T, N, .] buffers keeps its bits.
+//
+// Where the weights live decides the time.  A CU pulls L2 hits at ~37 GB/s (measured here: 197 KB in 5 us, the same with 64 and
+// with 256 workgroups -- outstanding misses x latency, not a shared limit), so the 197 KB of weights streamed per step were the
+// longest phase of the first version.  Block 1 (66 KB) and the 114 small tail parameters now stay in LDS for the whole launch
+// (145 KB per workgroup with the step body's 79 KB: one workgroup per CU); block 2 (130 KB) still streams, requested first so
+// that it is in flight while block 1 runs.  Per 512-step rollout at 4096 envs: 9.1 ms as a hipGraph of 512 x (policy launch +
+// step launch), 6.4 ms persistent with everything streamed, 5.9 ms now (bench.py resmlp512.rollout_ms).  Requesting the
+// weights a phase early, inside the env step, was measured and is not done: the 128 registers per lane do not fit beside the
+// step body (24-58 spilled VGPRs, 6.9-7.4 ms).  The phases of one step (tools/resmlp_rollout_phases.py; profiles/
+// r05_rollout_resmlp_phases.txt): block 1 2.1 us, sum 1.9 (it waits for block 2's weights), block 2 2.3 (the f32 MFMA floor of
+// both blocks on one CU is 2.6), sum + finish 1.3, env step 4.0.
+template <bool SENS>
+__global__ __launch_bounds__(64 * 8) void rollout_resmlp_kernel(Params P, RolloutArgs R) {
+    constexpr int NB = 10, EPB = 16, NW = 8, D = NB + 6, DP = D + 1, kThreads = 64 * NW;
+    static_assert(D == resmlp::rp::D && EPB == resmlp::kPolEnvs && NW == resmlp::kPolWaves, "the policy step's workgroup");
+    __shared__ StepSmem<NB, EPB, NW> sm;
+    __shared__ int next_env;
+    __shared__ __attribute__((aligned(16))) resmlp::PolicySmem ps;
+    __shared__ __attribute__((aligned(16))) resmlp::Block1Smem bs;   // block 1's weights + the small tail of the parameters
+    __shared__ float2 pol_eps[EPB];   // the action noise of the next policy step (drawn inside the env step in front of it)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int base = blockIdx.x * EPB;
+    const int nloc = min(EPB, P.N - base);
+    const size_t N = (size_t)P.N;
+    if (tid < nloc) {   // the envs' state: HBM -> LDS for the whole rollout
+        const int e = tid, i = base + e;
+        sm.st_d[0][e] = P.x[i]; sm.st_d[1][e] = P.y[i]; sm.st_d[2][e] = P.th[i]; sm.st_d[3][e] = P.gx[i]; sm.st_d[4][e] = P.gy[i];
+        sm.st_d[5][e] = P.past_dist[i]; sm.st_d[6][e] = P.ep_ret[i]; sm.st_d[7][e] = P.ep_path[i];
+        sm.st_pact[e] = P.past_action[i];
+        sm.st_step[e] = (uint32_t)P.ep_step[i];
+        sm.st_ctr[e] = P.rng_ctr[i];
+    }
+    for (int k = tid; k < nloc * D; k += kThreads) sm.obs[(k / D) * DP + (k % D)] = reinterpret_cast<const float*>(R.obs_buf)[(size_t)base * D + k];
+    for (int k = tid; k < 2 * NB; k += kThreads) sm.beam[k] = P.beam_cs[k];
+    for (int k = tid; k < (int)(sizeof(Rects) / 8); k += kThreads)
+        reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
+    const uint32_t step0 = R.step_base ? *R.step_base : 0u;
+    const float var = *R.var_ptr;
+    const int l15 = lane & 15, q = lane >> 4;
+    const bool valid = l15 < nloc;
+    auto draw_noise = [&](const uint32_t step) __attribute__((always_inline)) {   // lane = env
+        float e0, e1;
+        mlp64::policy_noise(step, R.seed, P.env_id_base + (uint64_t)(base + lane), e0, e1);
+        pol_eps[lane] = make_float2(e0, e1);
+    };
+    // The weights of a policy step (this wave's 64 hidden units: 128 registers) are REQUESTED inside the env step in front of it --
+    // behind barrier B2, where every wave but wave 0 only waits for the rules -- and arrive during the step's tail: the L2 round
+    // trip of 197 KB per workgroup and step is off the critical path.  (They cannot simply stay in registers: the step body needs them.)
+    resmlp::Weights W;
+    resmlp::stage_block1(R.params, lane, wave, bs);
+    if (wave == 5 && lane < nloc) draw_noise(step0);
+    __syncthreads();
+    for (int t = 0; t < R.T; ++t) {
+        const size_t tn = (size_t)t * N;
+        // ---- PPO.get_action (ppo.py:673-706) on the observation tile the previous step (or the reset) left in LDS
+        resmlp::f32x4 xq = resmlp::zero4();
+        if (valid) {
+            const float* row = sm.obs + l15 * DP + 4 * q;
+            xq = resmlp::f32x4{row[0], row[1], row[2], row[3]};
+        }
+        float z3, z4;
+        resmlp::load_weights_b(R.params, lane, wave, W);   // requested first: in flight while block 1 runs out of LDS
+        resmlp::load_weights_a_lds(bs, lane, wave, W);
+        resmlp::policy_preact_w(W, bs.b2a, bs.tail, xq, lane, wave, ps, z3, z4);
+        if (wave == 0 && q == 0 && valid) {
+            const float2 eps = pol_eps[l15];
+            const resmlp::Action o = resmlp::policy_finish(bs.tail, z3, z4, var, eps.x, eps.y);
+            sm.act_l[l15] = make_float2(o.a0, o.a1);
+            reinterpret_cast<float2*>(R.act_buf)[tn + base + l15] = make_float2(o.a0, o.a1);
+            R.logp_buf[tn + base + l15] = o.logp;
+        }
+        __syncthreads();
+        // ---- the env step: the same step body as every other entry point; behind its barrier B2 the next policy step's weights are
+        // requested and its noise is drawn
+        const StepIO io = {nullptr, nullptr, reinterpret_cast<float*>(R.obs_buf) + (tn + N) * D, R.reward + tn, R.done + tn, R.arrive + tn,
+                           R.ended + tn, R.ep_return ? R.ep_return + tn : nullptr, R.ep_length ? R.ep_length + tn : nullptr,
+                           R.ep_path ? R.ep_path + tn : nullptr};
+        const bool more = t + 1 < R.T;
+        auto hook = [&](const int wv, const int ln) __attribute__((always_inline)) {
+            if (more) {
+                if (wv == 5 && ln < nloc) draw_noise(step0 + (uint32_t)(t + 1));
+            }
+        };
+        step_body<NB, EPB, SENS, true, NW, false, 0, const Params&, const StepIO&, decltype(hook)>(P, sm, next_env, io, t == R.T - 1, 0, hook);
+        __syncthreads();   // the observation tile of step t + 1 is complete in sm.obs (the tile store only reads it)
+    }
+}
+
 // ---------------------------------------------------------------- n steps of an action tape in ONE launch (navsim_step_seq)
 // The step loop of PPO.rollout / the evaluation loop (ppo.py:505-594, main.py:176-235) when the actions are already known -- a
 // recorded tape, a scripted or random policy: a workgroup keeps its envs for all n steps, their state lives in LDS between the
@@ -2615,6 +2711,32 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, void* obs_b
         if (sens) hipLaunchKernelGGL((rollout_kernel<10, 16, true, kRollWaves>), grid, block, 0, st, h->P, R);
         else hipLaunchKernelGGL((rollout_kernel<10, 16, false, kRollWaves>), grid, block, 0, st, h->P, R);
     }
+    HIP_TRY(hipGetLastError());
+    return NAVSIM_OK;
+}
+
+int navsim_rollout_resmlp512(navsim_t* h, const float* actor_params_dev, float* obs_buf_dev, float* act_buf_dev, float* logp_buf_dev,
+                             float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev, float* ep_return_dev,
+                             int32_t* ep_length_dev, float* ep_path_dev, const float* var_dev, uint64_t act_seed,
+                             const uint32_t* step_base_dev, int32_t n_steps, void* stream) {
+    if (!h || !actor_params_dev || !obs_buf_dev || !act_buf_dev || !logp_buf_dev || !reward_dev || !done_dev || !arrive_dev ||
+        !ended_dev || !var_dev || n_steps < 0)
+        return fail(NAVSIM_E_ARG, "navsim_rollout_resmlp512: bad argument");
+    if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_rollout_resmlp512: call navsim_set_map first");
+    if (h->P.B != 10 || h->P.obs_f16)
+        return fail(NAVSIM_E_ARG, "navsim_rollout_resmlp512: the reference's nets read 16-wide float32 observations (10 beams, obs_f16 = 0)");
+    if (((uintptr_t)actor_params_dev & 15) || ((uintptr_t)act_buf_dev & 7) || ((uintptr_t)obs_buf_dev & 15))
+        return fail(NAVSIM_E_ARG, "navsim_rollout_resmlp512: params and obs must be 16-byte, act 8-byte aligned");
+    if (n_steps == 0) return NAVSIM_OK;
+    RolloutArgs R;
+    R.params = actor_params_dev; R.obs_buf = obs_buf_dev; R.act_buf = act_buf_dev; R.logp_buf = logp_buf_dev;
+    R.reward = reward_dev; R.done = done_dev; R.arrive = arrive_dev; R.ended = ended_dev; R.ep_return = ep_return_dev;
+    R.ep_length = ep_length_dev; R.ep_path = ep_path_dev; R.var_ptr = var_dev; R.step_base = step_base_dev;
+    R.seed = act_seed; R.T = n_steps;
+    const bool sens = h->P.sigma > 0.f || h->P.below_min_mode != 0;
+    const dim3 grid((h->P.N + 15) / 16), block(64 * 8);
+    if (sens) hipLaunchKernelGGL(rollout_resmlp_kernel<true>, grid, block, 0, (hipStream_t)stream, h->P, R);
+    else hipLaunchKernelGGL(rollout_resmlp_kernel<false>, grid, block, 0, (hipStream_t)stream, h->P, R);
     HIP_TRY(hipGetLastError());
     return NAVSIM_OK;
 }

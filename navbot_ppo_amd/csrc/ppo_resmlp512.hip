@@ -55,18 +55,18 @@
 #include "mlp64_policy.h"   // Philox / Box-Muller noise of the rollout policy step (same stream as the mlp64x2 path)
 #include "navppo.h"
 #include "navppo_internal.h"
+#include "resmlp_policy.h"   // the rollout-time policy step + the parameter layout (shared with the persistent rollout kernel)
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-namespace rp {   // flat parameter layout of one net = nn.Module.named_parameters() order without the unused BatchNorm entries
-constexpr int D = 16, HID = 512;
-constexpr int W1A = 0, B1A = W1A + HID * D, W2A = B1A + HID, B2A = W2A + D * HID, W1B = B2A + D, B1B = W1B + HID * 2 * D,
-              W2B = B1B + HID, B2B = W2B + 2 * D * HID, WO1 = B2B + 2 * D, BO1 = WO1 + 2 * D, WO2 = BO1 + 1, BO2 = WO2 + 2 * D;
-constexpr int P_ACTOR = BO2 + 1, P_CRITIC = BO1 + 1;
-static_assert(P_ACTOR == NAVPPO_RESMLP512_ACTOR_PARAMS && P_CRITIC == NAVPPO_RESMLP512_CRITIC_PARAMS, "layout");
-}  // namespace rp
+using resmlp::f32x4;
+using resmlp::ld4;
+using resmlp::leaky;
+using resmlp::mfma16;
+using resmlp::v4;
+using resmlp::zero4;
+namespace rp = resmlp::rp;
+static_assert(rp::P_ACTOR == NAVPPO_RESMLP512_ACTOR_PARAMS && rp::P_CRITIC == NAVPPO_RESMLP512_CRITIC_PARAMS, "layout");
 
 constexpr int NSL = 4;               // hidden slices
 constexpr int HS = rp::HID / NSL;    // 128 hidden units per slice
@@ -85,16 +85,7 @@ template <int IN> struct Blk;
 template <> struct Blk<16> { static constexpr int W1 = rp::W1A, B1 = rp::B1A, W2 = rp::W2A; };
 template <> struct Blk<32> { static constexpr int W1 = rp::W1B, B1 = rp::B1B, W2 = rp::W2B; };
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ f32x4 v4(const float4 a) { return f32x4{a.x, a.y, a.z, a.w}; }
-__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-// nn.LeakyReLU(0.2) (net_actor.py:38) = max(x, 0.2 x) = the median of (x, 0.2 x, FLT_MAX-ish): v_mul + v_med3_f32, two
-// instructions.  fmaxf() costs three (the compiler quiets a possible signalling NaN with v_max x, x first; it also rewrites a
-// median against +inf into that max).  A hand-written v_max_f32 in inline asm is two as well, but the hazard recogniser does
-// not see an asm statement as a VALU write and the MFMA behind it read a stale register (the rollout policy step did).
-__device__ __forceinline__ float leaky(float x) { return __builtin_amdgcn_fmed3f(x, 0.2f * x, 3.0e38f); }
 __device__ __forceinline__ float dleaky(float g, float act) { return act > 0.f ? g : 0.2f * g; }   // sign(leaky(x)) == sign(x)
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave are performed in issue order: this only stops the compiler from moving them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -733,114 +724,23 @@ __global__ __launch_bounds__(64 * kRedGroups) void resmlp_reduce(const float* __
 }
 
 // ---------------------------------------------------------------- rollout-time policy step (PPO.get_action, ppo.py:673-706)
-// One workgroup = 16 envs; its 8 waves split the hidden units 8 ways (64 each), weights come straight from global memory
-// (L2: all workgroups read the same 197 KB), the two block outputs are summed over the waves through LDS.
-constexpr int kActEnvs = 16;
+// One workgroup = 16 envs on 8 waves: csrc/resmlp_policy.h (shared with the persistent rollout kernel of navsim.hip: same bits).
+constexpr int kActEnvs = resmlp::kPolEnvs;
+static_assert(kWaves == resmlp::kPolWaves, "the policy step's workgroup");
 __global__ __launch_bounds__(kThreads) void resmlp_act(const float* __restrict__ pa, const float* __restrict__ obs,
                                                        const float* __restrict__ noise, long long n, const float* __restrict__ var_ptr,
                                                        uint64_t seed, uint64_t env_id_base, const uint32_t* __restrict__ step_base,
                                                        uint32_t step_offset, float* __restrict__ act, float* __restrict__ logp,
                                                        float* __restrict__ mean_out) {
-    __shared__ __attribute__((aligned(16))) float part1[kWaves][256];
-    __shared__ __attribute__((aligned(16))) float part2[kWaves][2][256];
+    __shared__ __attribute__((aligned(16))) resmlp::PolicySmem ps;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, q = lane >> 4;
     const long long e = (long long)blockIdx.x * kActEnvs + l15;
     const bool valid = e < n;
-    const int j0 = 64 * w;
-    // every weight this wave needs, requested up front (addresses do not depend on anything computed)
-    f32x4 w1a[4], b1a[4], w2a[4], w1b[4][2], b1b[4], w2b[2][4];
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-        w1a[jb] = v4(ld4(pa + rp::W1A + (j0 + 16 * jb + l15) * 16 + 4 * q));
-        b1a[jb] = v4(ld4(pa + rp::B1A + j0 + 16 * jb + 4 * q));
-        w2a[jb] = v4(ld4(pa + rp::W2A + l15 * rp::HID + j0 + 16 * jb + 4 * q));
-        w1b[jb][0] = v4(ld4(pa + rp::W1B + (j0 + 16 * jb + l15) * 32 + 4 * q));
-        w1b[jb][1] = v4(ld4(pa + rp::W1B + (j0 + 16 * jb + l15) * 32 + 16 + 4 * q));
-        b1b[jb] = v4(ld4(pa + rp::B1B + j0 + 16 * jb + 4 * q));
-        w2b[0][jb] = v4(ld4(pa + rp::W2B + l15 * rp::HID + j0 + 16 * jb + 4 * q));
-        w2b[1][jb] = v4(ld4(pa + rp::W2B + (16 + l15) * rp::HID + j0 + 16 * jb + 4 * q));
-    }
     const f32x4 xq = valid ? v4(ld4(obs + e * 16 + 4 * q)) : zero4();
-    // rb1, this wave's 64 hidden units
-    f32x4 y1[2] = {zero4(), zero4()};
-    {
-        f32x4 H[4];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) H[jb] = b1a[jb];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) H[jb] = mfma16(w1a[jb][r], xq[r], H[jb]);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y1[jb & 1] = mfma16(w2a[jb][r], leaky(H[jb][r]), y1[jb & 1]);
-    }
-    *reinterpret_cast<float4*>(&part1[w][4 * lane]) = make_float4(y1[0][0] + y1[1][0], y1[0][1] + y1[1][1], y1[0][2] + y1[1][2], y1[0][3] + y1[1][3]);
-    __syncthreads();
-    f32x4 h1;
-    {
-        const float4 b = ld4(pa + rp::B2A + 4 * q);
-        f32x4 s = v4(ld4(&part1[0][4 * lane]));
-#pragma unroll
-        for (int k = 1; k < kWaves; ++k) s += v4(ld4(&part1[k][4 * lane]));
-        h1 = xq + v4(b) + s;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h1[r] = leaky(h1[r]);
-    }
-    // rb2
-    f32x4 y2[2] = {zero4(), zero4()};
-    {
-        f32x4 H[4];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) H[jb] = b1b[jb];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) H[jb] = mfma16(w1b[jb][0][r], xq[r], H[jb]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) H[jb] = mfma16(w1b[jb][1][r], h1[r], H[jb]);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float hl = leaky(H[jb][r]);
-                y2[0] = mfma16(w2b[0][jb][r], hl, y2[0]);
-                y2[1] = mfma16(w2b[1][jb][r], hl, y2[1]);
-            }
-    }
-    *reinterpret_cast<float4*>(&part2[w][0][4 * lane]) = make_float4(y2[0][0], y2[0][1], y2[0][2], y2[0][3]);
-    *reinterpret_cast<float4*>(&part2[w][1][4 * lane]) = make_float4(y2[1][0], y2[1][1], y2[1][2], y2[1][3]);
-    __syncthreads();
+    float z3, z4;
+    resmlp::policy_preact(pa, xq, lane, w, ps, z3, z4);
     if (w != 0) return;
-    float z3 = 0.f, z4 = 0.f;
-#pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-        f32x4 s = v4(ld4(&part2[0][ob][4 * lane]));
-#pragma unroll
-        for (int k = 1; k < kWaves; ++k) s += v4(ld4(&part2[k][ob][4 * lane]));
-        const f32x4 x1 = ob == 0 ? xq : h1;
-        const float4 b = ld4(pa + rp::B2B + 16 * ob + 4 * q), u = ld4(pa + rp::WO1 + 16 * ob + 4 * q);
-        const float* w2p = pa + rp::WO2 + 16 * ob + 4 * q;   // out2.weight starts one float after out1.bias: not 16-byte aligned
-        const f32x4 h2 = x1 + v4(b) + s;
-        const float uv[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float hl = leaky(h2[r]);
-            z3 = fmaf(hl, uv[r], z3);
-            z4 = fmaf(hl, w2p[r], z4);
-        }
-    }
-    z3 += __shfl_xor(z3, 16, 64);
-    z4 += __shfl_xor(z4, 16, 64);
-    z3 += __shfl_xor(z3, 32, 64);
-    z4 += __shfl_xor(z4, 32, 64);
     if (q == 0 && valid) {
-        z3 += pa[rp::BO1];
-        z4 += pa[rp::BO2];
-        const float var = *var_ptr;
         float e0, e1;
         if (noise) {
             e0 = noise[2 * e];
@@ -848,17 +748,13 @@ __global__ __launch_bounds__(kThreads) void resmlp_act(const float* __restrict__
         } else {
             mlp64::policy_noise((step_base ? *step_base : 0u) + step_offset, seed, env_id_base + (uint64_t)e, e0, e1);
         }
-        const float mu0 = 1.0f / (1.0f + expf(-z3)), mu1 = tanhf(z4);
-        const float sd = sqrtf(var);
-        const float a0 = fminf(fmaxf(fmaf(sd, e0, mu0), 0.f), 1.f);    // ppo.py:698-703
-        const float a1 = fminf(fmaxf(fmaf(sd, e1, mu1), -1.f), 1.f);
-        const float d0 = a0 - mu0, d1 = a1 - mu1;
-        act[2 * e] = a0;
-        act[2 * e + 1] = a1;
-        logp[e] = -0.5f * ((d0 * d0 + d1 * d1) / var) - 1.8378770664093453f - logf(var);  // log-prob of the CLAMPED action, ppo.py:704
+        const resmlp::Action o = resmlp::policy_finish(pa + rp::B2B, z3, z4, *var_ptr, e0, e1);
+        act[2 * e] = o.a0;
+        act[2 * e + 1] = o.a1;
+        logp[e] = o.logp;
         if (mean_out) {
-            mean_out[2 * e] = mu0;
-            mean_out[2 * e + 1] = mu1;
+            mean_out[2 * e] = o.mu0;
+            mean_out[2 * e + 1] = o.mu1;
         }
     }
 }

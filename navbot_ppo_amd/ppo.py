@@ -48,7 +48,7 @@ class PPOConfig:
     save_freq: int = 2                     # ppo.py:774
     seed: int = 0
     use_graph: bool = True                 # capture the T-step rollout in one hipGraph
-    persistent_rollout: bool = True        # mlp64x2 on GPU: all T steps in ONE launch (navsim_rollout_mlp64)
+    persistent_rollout: bool = True        # on GPU: all T steps in ONE launch (navsim_rollout_mlp64 / navsim_rollout_resmlp512)
     fused_update: bool = True              # on GPU: fused HIP loss+gradient kernels (csrc/ppo_mlp64.hip, csrc/ppo_resmlp512.hip)
     # arithmetic of the fused 16-64-64 update's matrix products: "bf16x3" = float32 products out of operands split into three bf16
     # pieces on the bf16 MFMA (six piece products, float32 accumulate: float32-equivalent by measurement), "f32" =
@@ -565,12 +565,13 @@ class PPOTrainer:
         from ._native import check, lib
         ptr = lambda x: C.c_void_p(x.data_ptr())
         sim = self.env.sim
+        entry = lib().navsim_rollout_resmlp512 if self.updater.fused_resmlp512 else lib().navsim_rollout_mlp64
         with torch.cuda.device(self.device):
-            check(lib().navsim_rollout_mlp64(sim._h, ptr(self.updater.fp.flat), ptr(self.obs_buf), ptr(self.act_buf),
+            check(entry(sim._h, ptr(self.updater.fp.flat), ptr(self.obs_buf), ptr(self.act_buf),
                                              ptr(self.logp_buf), ptr(self.rew_buf), ptr(self.done_buf), ptr(self.arrive_buf),
                                              ptr(self.ended_buf), ptr(self.epret_buf), ptr(self.eplen_buf), ptr(self.eppath_buf),
                                              ptr(self.var), self._act_seed, ptr(self._step_base), self.cfg.rollout_len,
-                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "navsim_rollout_mlp64")
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "navsim_rollout_" + ("resmlp512" if self.updater.fused_resmlp512 else "mlp64"))
         self._step_base += self.cfg.rollout_len
 
     def _rollout_body(self):
@@ -588,8 +589,9 @@ class PPOTrainer:
         sim = self.env.sim
         # (round 5: both rollout kernels have the tile-box cast of shared 65..4096-segment maps; until then shards up to 4096 envs on
         # such a map took the hipGraph of per-step launches)
-        if cfg.persistent_rollout and self.updater.fused_mlp64 and self.env.B in (10, 36):
-            self._persistent_rollout()
+        if cfg.persistent_rollout and ((self.updater.fused_mlp64 and self.env.B in (10, 36)) or
+                                       (self.updater.fused_resmlp512 and self.env.B == 10 and not self._half_obs)):
+            self._persistent_rollout()   # (the 512-wide actor too since round 5: navsim_rollout_resmlp512)
         elif cfg.use_graph and self.device.type == "cuda":
             if self._graph is not None and self._graph_gen != self.env.sim.generation:
                 self._graph = None   # set_map / set_spawn_sampler / set_goal_rects re-allocated what the capture froze

@@ -296,3 +296,45 @@ def test_trainer_with_gae_lambda():
         env.close()
     assert torch.equal(flats[0], flats[1])
     assert not torch.equal(flats[0], flats[2])
+
+
+@pytest.mark.parametrize("sens", [False, True])
+@pytest.mark.parametrize("N,T,map_name,per_env", [(4096, 48, "stage_1", False), (200, 90, "stage_1", False), (96, 40, "stage_2", True),
+                                                   (4608, 36, "stage_1", False), (1000, 34, "house", False)])
+def test_persistent_resmlp512_rollout_equals_per_step_rollout(N, T, map_name, per_env, sens):
+    """navsim_rollout_resmlp512 (all T steps in one launch, the reference's ACTIVE actor -- net_actor.py:56-144 -- choosing every
+    action in the kernel: ppo.py:505-594) against the hipGraph-free per-step path (T pairs of navppo_resmlp512_act / navsim_step):
+    same device functions (csrc/resmlp_policy.h, step_body) and Philox keys, so every rollout buffer and the simulator state must
+    come out bit-identical, over two consecutive rollouts; and the stored log-probs are those of the stored actions under the
+    PyTorch NetActor on the stored observations (ppo.py:696-704)."""
+    from navbot_ppo_amd.env import VecEnv
+    kw = dict(lidar_noise_sigma=0.01, lidar_below_min="gazebo") if sens else {}
+    outs = []
+    for persistent in (True, False):
+        env = VecEnv(N, map=map_name, max_episode_steps=30, seed=3, per_env_map=per_env,
+                     sampler="small_house" if map_name == "house" else None, **kw)
+        cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=30, n_updates_per_iteration=1, policy="resmlp512", seed=5,
+                            persistent_rollout=persistent, use_graph=False)
+        tr = ppo.PPOTrainer(env, cfg)
+        assert tr.updater.fused_resmlp512
+        bufs = []
+        for _ in range(2):
+            tr.rollout()
+            torch.cuda.synchronize()
+            bufs.append([b.clone() for b in (tr.obs_buf, tr.act_buf, tr.logp_buf, tr.rew_buf, tr.done_buf, tr.arrive_buf,
+                                             tr.ended_buf, tr.rtg_buf)] +
+                        [torch.where(tr.ended_buf.bool(), b, torch.zeros_like(b)) for b in (tr.epret_buf, tr.eplen_buf, tr.eppath_buf)])
+        outs.append((bufs, env.sim.get_state()))
+        if persistent and not sens:
+            with torch.no_grad():
+                lp = ppo.gaussian_log_prob(tr.actor(tr.obs_buf[:T].reshape(T * N, 16)), tr.act_buf.reshape(T * N, 2), tr.var)
+            np.testing.assert_allclose(tr.logp_buf.reshape(-1).cpu().numpy(), lp.cpu().numpy(), rtol=1e-4, atol=3e-5)
+        env.close()
+    (a, sa), (b, sb) = outs
+    assert int(a[0][6].sum()) > N // 4          # episodes ended
+    bits = lambda x: x.view(torch.int32) if x.dtype == torch.float32 else x
+    for ra, rb in zip(a, b):
+        for x, y in zip(ra, rb):
+            assert torch.equal(bits(x), bits(y))
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k])
