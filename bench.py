@@ -288,7 +288,8 @@ MFMA_F32_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-i
 
 def resmlp512_leg(n_envs, rollout, epochs, steps=2):
     """SURVEY 8(d) cfg 2 "reported alongside": the reference's ACTIVE nets (net_actor.py:56-144, net_critic.py:50-130) on the
-    same workload: fused HIP update (csrc/ppo_resmlp512.hip), hipGraph rollout of fused policy step + env step."""
+    same workload: fused HIP update (csrc/ppo_resmlp512.hip), rollout in one persistent launch (navsim_rollout_resmlp512: the policy
+    step of csrc/resmlp_policy.h in front of every env step; round 4 ran a hipGraph of policy launch + step launch per step)."""
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
     env = VecEnv(n_envs, map="stage_1", max_episode_steps=500, seed=0)
@@ -331,6 +332,8 @@ def resmlp512_leg(n_envs, rollout, epochs, steps=2):
     env.close()
     return dict(policy="resmlp512", value=round(steps * rollout * n_envs / dt, 1), unit="env-steps/s", steps=steps,
                 ms_per_step=round(dt / steps * 1e3, 2), rollout_ms=round(r / steps * 1e3, 2), update_ms=round(u / steps * 1e3, 2),
+                rollout=("persistent kernel (navsim_rollout_resmlp512: rollout_resmlp_kernel, 16 envs on 8 waves)"
+                         if tr.uses_persistent_rollout else "hipGraph of per-step launches"),
                 update="fused f32-MFMA kernels" if up.fused_resmlp512 else "PyTorch-ROCm", update_roofline=roof)
 
 

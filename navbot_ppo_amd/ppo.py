@@ -580,6 +580,14 @@ class PPOTrainer:
         self._step_base += self.cfg.rollout_len  # inside the captured graph: every replay draws fresh noise
 
     @torch.no_grad()
+    @property
+    def uses_persistent_rollout(self):
+        """All T steps of PPO.rollout in ONE launch: navsim_rollout_mlp64 (the (B + 6)-64-64 actor, 10 or 36 beams, float32 or float16
+        rows) or navsim_rollout_resmlp512 (the reference's 512-wide actor, 10 beams, float32 rows: round 5).  Anything else runs the
+        hipGraph of per-step launches."""
+        return bool(self.cfg.persistent_rollout and ((self.updater.fused_mlp64 and self.env.B in (10, 36)) or
+                                                     (self.updater.fused_resmlp512 and self.env.B == 10 and not self._half_obs)))
+
     def rollout(self):
         cfg = self.cfg
         self._decay_exploration()
@@ -589,9 +597,8 @@ class PPOTrainer:
         sim = self.env.sim
         # (round 5: both rollout kernels have the tile-box cast of shared 65..4096-segment maps; until then shards up to 4096 envs on
         # such a map took the hipGraph of per-step launches)
-        if cfg.persistent_rollout and ((self.updater.fused_mlp64 and self.env.B in (10, 36)) or
-                                       (self.updater.fused_resmlp512 and self.env.B == 10 and not self._half_obs)):
-            self._persistent_rollout()   # (the 512-wide actor too since round 5: navsim_rollout_resmlp512)
+        if self.uses_persistent_rollout:
+            self._persistent_rollout()
         elif cfg.use_graph and self.device.type == "cuda":
             if self._graph is not None and self._graph_gen != self.env.sim.generation:
                 self._graph = None   # set_map / set_spawn_sampler / set_goal_rects re-allocated what the capture froze

@@ -21,4 +21,8 @@ python tools/time_ppo_shard.py cfg5 2>/dev/null | tail -1 > $O/ppo_cfg5.json
 ./build/bf16_split_ops > $O/bf16_split_ops.txt 2>&1
 python tools/show_info.py 2>&1 | grep -v amdgpu > $O/selected_instantiations.txt
 python tools/time_house_rollout.py 2>&1 | grep -v amdgpu > $O/house_rollout_shapes.txt
+# the closed-loop rollout of the 512-wide actor: one persistent launch against the hipGraph of per-step launches, its kernel average, its phases
+python tools/time_rollout_resmlp.py 2>&1 | grep -v amdgpu > $O/rollout_resmlp_times.txt
+tools/prof_stats.sh rollout_resmlp -- python tools/time_rollout_resmlp.py > $O/rollout_resmlp_rocprof.log 2>&1
+[ -f build/libnavsim_resmlp_phases.so ] && python tools/resmlp_rollout_phases.py 2>&1 | grep -v amdgpu > $O/rollout_resmlp_phases.txt
 tail -c 600 $O/bench_final.json; echo; cat $O/update_arith_hip_events.txt $O/update_wide_hip_events.txt

@@ -52,7 +52,7 @@ def run():
     import torch
     from navbot_ppo_amd import ppo, _native
     from navbot_ppo_amd.env import VecEnv
-    L = _native.load()
+    L = _native.lib()
     L.navsim_resmlp_phases.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     T = 512
     for N in (4096, 1024):
