@@ -579,7 +579,6 @@ class PPOTrainer:
             self._rollout_step(t)
         self._step_base += self.cfg.rollout_len  # inside the captured graph: every replay draws fresh noise
 
-    @torch.no_grad()
     @property
     def uses_persistent_rollout(self):
         """All T steps of PPO.rollout in ONE launch: navsim_rollout_mlp64 (the (B + 6)-64-64 actor, 10 or 36 beams, float32 or float16
@@ -588,6 +587,7 @@ class PPOTrainer:
         return bool(self.cfg.persistent_rollout and ((self.updater.fused_mlp64 and self.env.B in (10, 36)) or
                                                      (self.updater.fused_resmlp512 and self.env.B == 10 and not self._half_obs)))
 
+    @torch.no_grad()
     def rollout(self):
         cfg = self.cfg
         self._decay_exploration()

@@ -201,6 +201,7 @@ def test_persistent_rollout_equals_per_step_rollout_on_wide_and_half_rows(N, T, 
         cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=30, n_updates_per_iteration=1, policy="mlp64x2", seed=5,
                             persistent_rollout=persistent, use_graph=False)
         tr = ppo.PPOTrainer(env, cfg)
+        assert tr.uses_persistent_rollout is persistent   # the two sides of the comparison do take different paths
         assert tr.updater.fused_mlp64 and tr.obs_buf.dtype == (torch.float16 if half else torch.float32)
         if persistent:
             inf = env.sim.info()

@@ -271,6 +271,7 @@ def test_persistent_rollout_equals_per_step_rollout(N, T, map_name, per_env, epb
         cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=30, n_updates_per_iteration=1, policy="mlp64x2", seed=5,
                             persistent_rollout=persistent, use_graph=False)
         tr = ppo.PPOTrainer(env, cfg)
+        assert tr.uses_persistent_rollout is persistent   # the two sides of the comparison do take different paths
         if persistent and map_name == "house":   # the tile-box cast in whichever rollout kernel the shard selects
             inf = env.sim.info()
             assert inf["tile_boxes"] == 1 and inf["rollout_cast"] == 3 and inf["rollout_kind"] == (2 if (N > 4096 or epb in ("64", "32")) else 1), inf
@@ -559,6 +560,7 @@ def test_persistent_rollout_with_arrival_respawn(N, epb, monkeypatch):
         cfg = ppo.PPOConfig(rollout_len=150, max_episode_steps=70, n_updates_per_iteration=1, policy="mlp64x2", seed=6,
                             persistent_rollout=persistent, use_graph=False)
         tr = ppo.PPOTrainer(env, cfg)
+        assert tr.uses_persistent_rollout is persistent   # the two sides of the comparison do take different paths
         with torch.no_grad():
             tr.actor.layer3.bias.add_(2.0)   # drive forward: collisions as well as arrivals and time-outs
         tr.rollout()
@@ -589,6 +591,7 @@ def test_persistent_rollout_on_a_streamed_map():
         cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=4, n_updates_per_iteration=1, policy="mlp64x2", seed=2,
                             persistent_rollout=persistent, use_graph=False)
         tr = ppo.PPOTrainer(env, cfg)
+        assert tr.uses_persistent_rollout is persistent   # the two sides of the comparison do take different paths
         tr.rollout()
         torch.cuda.synchronize()
         outs.append([b.clone() for b in (tr.obs_buf, tr.act_buf, tr.logp_buf, tr.rew_buf, tr.done_buf, tr.arrive_buf, tr.ended_buf)])

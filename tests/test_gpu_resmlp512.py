@@ -316,6 +316,7 @@ def test_persistent_resmlp512_rollout_equals_per_step_rollout(N, T, map_name, pe
         cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=30, n_updates_per_iteration=1, policy="resmlp512", seed=5,
                             persistent_rollout=persistent, use_graph=False)
         tr = ppo.PPOTrainer(env, cfg)
+        assert tr.uses_persistent_rollout is persistent   # the two sides of the comparison do take different paths
         assert tr.updater.fused_resmlp512
         bufs = []
         for _ in range(2):
