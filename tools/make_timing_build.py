@@ -25,9 +25,9 @@ rep("    __syncthreads();  // barrier C:", "    STAMP(5);\n    __syncthreads(); 
 if "            pose_ok = true;\n" in t:
     rep("            pose_ok = true;\n", "            pose_ok = true;\n            STAMP(6);\n")
 # end of step_body = the closing brace after the observation tile's store (next_obs4 follows it)
-idx = t.index("// Entries 4 kk .. 4 kk + 3 of the observation env `e` (local) will hold when this step is over")
+idx = t.index("// Entries f0 .. f0 + KS - 1 of the observation env `e` (local) will hold when this step is over")
 j = t.rfind("}\n\n", 0, idx)
-assert "o[k] = sm.obs[(k / D) * DP + (k % D)];" in t[j - 200:j], "end of step_body not where the timing patch expects it"
+assert "o[k] = sm.obs[(k / D) * DP + (k % D)];" in t[j - 300:j], "end of step_body not where the timing patch expects it"
 t = t[:j] + "    STAMP(7);\n    if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk[blockIdx.x * 3 + 1] = wall_clock64();\n" + t[j:]
 rep("int navsim_version(void) { return NAVSIM_ABI_VERSION; }",
     "int navsim_version(void) { return NAVSIM_ABI_VERSION; }\n"
@@ -43,8 +43,8 @@ rep("        const bool more = t + 1 < R.T;\n        auto hook = [&](const int w
     "        const bool more_real = t + 1 < R.T; const bool more = true;\n        auto hook = [&](const int wv, const int ln) __attribute__((always_inline)) {\n            // (measured")
 rep("                else if (ln < nloc) draw_noise(step0 + (uint32_t)(t + 1));\n", "                else if (ln < nloc) draw_noise(step0 + (uint32_t)(t + 1));\n                PSTAMP(1);\n")
 rep("                    if (ln < nloc) finish(tn + N);\n", "                    if (ln < nloc) finish(more_real ? tn + N : tn);\n                    PSTAMP(2);\n")
-rep("        // the observation tile of step t + 1 is in sm.obs (its store only reads it), its action in sm.act_l\n    }\n}\n\n// ---------------------------------------------------------------- n steps of an action tape",
-    "        PSTAMP(0);\n    }\n}\n\n// ---------------------------------------------------------------- n steps of an action tape")
+rep("        // the observation tile of step t + 1 is in sm.obs (its store only reads it), its action in sm.act_l\n    }\n}\n",
+    "        PSTAMP(0);\n    }\n}\n")
 rep("        const bool more = t + 1 < T;\n        auto hook = [&](const int wv, const int ln) __attribute__((always_inline)) {\n            if (more) {\n                if (wv >= kTileWave0 && wv < kTileWave0 + TW) tile_policy(wv - kTileWave0, tn + N, (t + 1) & 1, std::true_type{});",
     "        const bool more = true; const bool more_real = t + 1 < T;\n        auto hook = [&](const int wv, const int ln) __attribute__((always_inline)) {\n            if (more) {\n                if (wv >= kTileWave0 && wv < kTileWave0 + TW) tile_policy(wv - kTileWave0, more_real ? tn + N : tn, (t + 1) & 1, std::true_type{});")
 rep("int navsim_blk_read(long long* out)", "int navsim_pol_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pol), sizeof(long long) * 256); }\nint navsim_blk_read(long long* out)")

@@ -16,6 +16,8 @@ if "--rollout" in sys.argv:   # the persistent rollout kernel: stamps of its LAS
     BIG = "--big" in sys.argv   # configs[2] closed loop: 16384 envs, per-env stage_2 maps -> rollout_big_kernel (16 waves, 64 envs)
     if BIG:
         env = VecEnv(16384, map="stage_2", max_episode_steps=500, seed=0, per_env_map=True)
+    elif "--beams36" in sys.argv:   # configs[3]'s shard: 4096 envs, stage_4, 36 beams -> rollout_kernel<36, 16, ., 8>
+        env = VecEnv(4096, map="stage_4", n_beams=36, max_episode_steps=500, seed=0)
     else:
         env = VecEnv(4096, map="stage_1", max_episode_steps=500, seed=0)
     tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=T, policy="mlp64x2", n_updates_per_iteration=1))
