@@ -384,3 +384,57 @@ def test_two_handles_with_different_forced_shapes_in_one_process():
         envs[0].sim.set_shape(5)
     for e in envs:
         e.close()
+
+
+def _format_batch(d, half, n=768, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.rand((n, d), generator=g) * 1.5 - 0.25
+    acts = torch.rand((n, 2), generator=g)
+    acts[:, 1] = acts[:, 1] * 2 - 1
+    logp = -1.0 - torch.rand(n, generator=g)
+    rtg = torch.randn(n, generator=g) * 3
+    return (obs.half() if half else obs), acts, logp, rtg
+
+
+def _dp_format_worker(rank, world, port, path, d, half, overlap):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      NAVBOT_DIST_BACKEND="gloo")   # RCCL refuses two ranks on one device: gloo carries the all-reduce here
+    from navbot_ppo_amd import nets, ppo
+    ctx = ppo.DistCtx(device="cuda:0")
+    torch.manual_seed(100 + rank)   # rank 0's parameters are broadcast
+    a, c = nets.make_policy("mlp64x2", d)
+    a.cuda(), c.cuda()
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(n_updates_per_iteration=5, policy="mlp64x2", overlap_allreduce=overlap), ctx,
+                        torch.device("cuda:0"))
+    assert up.fused_mlp64 and up.obs_dim == d
+    obs, acts, logp, rtg = _format_batch(d, half)
+    lo, hi = ctx.shard(obs.shape[0])
+    up.update(obs[lo:hi].cuda(), acts[lo:hi].cuda(), logp[lo:hi].cuda(), rtg[lo:hi].cuda(), torch.tensor(0.8, device="cuda"))
+    torch.save({"flat": up.fp.flat.cpu()}, f"{path}.{rank}")
+    ctx.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,half,overlap", [(42, False, False), (42, False, True), (16, True, True), (42, True, False)])
+def test_two_rank_update_on_row_formats_equals_single_rank(tmp_path, d, half, overlap):
+    """BASELINE configs[3] (36 beams -> 42-D rows, "RCCL grad all-reduce") and configs[4] (float16 observation buffers) are 8-GPU
+    TRAINING configurations (ppo.py:305-397 on each rank's shard + one gradient all-reduce per epoch): the N > 1 update path on these
+    row formats -- fused passes on the shard, all-reduce of the flat gradient (overlap: the per-net pipeline), scale + Adam kernel --
+    with two ranks on halves of a batch == the single-rank path on the whole batch."""
+    from _ranks import spawn_ranks
+    from navbot_ppo_amd import nets, ppo
+    path = str(tmp_path / "dpf")
+    spawn_ranks(_dp_format_worker, 2, lambda port: (2, port, path, d, half, overlap))
+    r0, r1 = torch.load(path + ".0"), torch.load(path + ".1")
+    assert torch.equal(r0["flat"], r1["flat"])
+    torch.manual_seed(100)
+    a, c = nets.make_policy("mlp64x2", d)
+    a.cuda(), c.cuda()
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(n_updates_per_iteration=5, policy="mlp64x2"), None, torch.device("cuda:0"))
+    obs, acts, logp, rtg = _format_batch(d, half)
+    before = up.fp.flat.clone()
+    up.update(obs.cuda(), acts.cuda(), logp.cuda(), rtg.cuda(), torch.tensor(0.8, device="cuda"))
+    assert (up.fp.flat - before).abs().max().item() > 1e-3   # five Adam steps moved the parameters
+    np.testing.assert_allclose(r0["flat"].numpy(), up.fp.flat.cpu().numpy(), rtol=0, atol=5e-6)
