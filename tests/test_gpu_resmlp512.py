@@ -339,3 +339,54 @@ def test_persistent_resmlp512_rollout_equals_per_step_rollout(N, T, map_name, pe
             assert torch.equal(bits(x), bits(y))
     for k in sa:
         np.testing.assert_array_equal(sa[k], sb[k])
+
+
+@pytest.mark.parametrize("N,T,cap,lo,n_s", [(4096, 512, 500, 2000, 96), (1000, 300, 120, 1000 - 72, 72)])
+def test_persistent_resmlp512_rollout_against_the_oracle(N, T, cap, lo, n_s):
+    """navsim_rollout_resmlp512 checked DIRECTLY against the oracle at the timed configuration (BASELINE configs[1] with the
+    reference's ACTIVE nets: T = 512, N = 4096, episode cap 500, stage_1) and on a ragged shard (its last workgroup holds 8 envs):
+    the actions the kernel recorded for a block of envs are replayed on an OracleSim keyed by the same global env ids
+    (environment_new.py:272-310 + the episode logic of ppo.py:543-593); flags bit-exact, observations within 1e-6, rewards within
+    1e-5, episode sums; the return scan of the same buffers == the oracle's compute_rtgs (ppo.py:643-671)."""
+    from navbot_ppo_amd import maps
+    from navbot_ppo_amd.env import VecEnv
+    from oracle import navsim_oracle as O
+    env = VecEnv(N, map="stage_1", max_episode_steps=cap, seed=7)
+    cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=cap, policy="resmlp512", seed=3)
+    tr = ppo.PPOTrainer(env, cfg)
+    assert tr.updater.fused_resmlp512 and tr.uses_persistent_rollout is True
+    with torch.no_grad():   # drive forward: collisions and arrivals inside the rollout, not only time-outs
+        tr.actor.out1.bias.add_(2.0)
+    tr.rollout()
+    torch.cuda.synchronize()
+    sl = slice(lo, lo + n_s)
+    acts = tr.act_buf[:, sl].cpu().numpy()
+    cpu = O.OracleSim(n_s, max_episode_steps=cap, auto_reset=True, seed=7, env_id_base=lo)
+    cpu.set_map(maps.stage_1())
+    rr, rs = maps.goal_rects("stage_1")
+    cpu.set_goal_rects(0, rr)
+    cpu.set_goal_rects(1, rs)
+    obs = tr.obs_buf[:, sl].cpu().numpy()
+    np.testing.assert_allclose(obs[0], cpu.reset(), rtol=0, atol=1e-6)
+    g = {k: getattr(tr, k + "_buf")[:, sl].cpu().numpy() for k in ("rew", "done", "arrive", "ended", "epret", "eplen", "eppath")}
+    n_end = 0
+    for t in range(T):
+        out = cpu.step(acts[t])
+        for k in ("done", "arrive", "ended"):
+            np.testing.assert_array_equal(g[k][t], out[k], err_msg=f"{k}, step {t}")
+        np.testing.assert_allclose(obs[t + 1], out["obs"], rtol=0, atol=1e-6, err_msg=f"obs, step {t}")
+        np.testing.assert_allclose(g["rew"][t], out["reward"], rtol=1e-5, atol=1e-5, err_msg=f"reward, step {t}")
+        e = out["ended"].astype(bool)
+        np.testing.assert_array_equal(g["eplen"][t][e], out["ep_length"][e])
+        np.testing.assert_allclose(g["epret"][t][e], out["ep_return"][e], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(g["eppath"][t][e], out["ep_path"][e], rtol=1e-6, atol=1e-7)
+        n_end += int(e.sum())
+    assert n_end >= n_s and int(g["done"].sum()) > 0
+    with torch.no_grad():   # policy side over the whole rollout: log-prob of the stored clamped action under the PyTorch NetActor
+        lp_ref = ppo.gaussian_log_prob(tr.actor(tr.obs_buf[:T].reshape(T * N, 16)), tr.act_buf.reshape(T * N, 2), tr.var)
+    np.testing.assert_allclose(tr.logp_buf.reshape(-1).cpu().numpy(), lp_ref.cpu().numpy(), rtol=1e-4, atol=3e-5)
+    a = tr.act_buf
+    assert (a[..., 0] >= 0).all() and (a[..., 0] <= 1).all() and (a[..., 1].abs() <= 1).all()
+    from test_gpu_parity import assert_rtg_close
+    assert_rtg_close(tr.rtg_buf[:, sl].cpu().numpy(), O.compute_rtgs_tn(g["rew"], g["ended"], cfg.gamma))
+    env.close()
