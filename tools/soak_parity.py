@@ -44,15 +44,16 @@ if "--rollout" not in sys.argv:   # (--rollout: only the closed-loop part below)
     soak(1024, maps.replicate_per_env(maps.stage_2(sides=56), 1024, seed=5), True, 300, B=36, amax=3.0)
 
 
-def soak_rollout(N, seg, per_env, T, iters=2, cap=60, seed=_S0, sampler=None, B=10, half=False):
+def soak_rollout(N, seg, per_env, T, iters=2, cap=60, seed=_S0, sampler=None, B=10, half=False, policy="mlp64x2"):
     """The persistent rollout CLOSED-LOOP (navsim_rollout_mlp64: rollout_big_kernel beyond 4096 envs): the actions the in-kernel policy
     chose are replayed on the oracle for EVERY env; every observation row, flag and reward of every step is compared."""
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
     env = VecEnv(N, map=seg, n_beams=B, max_episode_steps=cap, seed=seed, per_env_map=False, sampler=sampler, obs_f16=half)
-    tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=T, max_episode_steps=cap, policy="mlp64x2", seed=seed + 1))
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=T, max_episode_steps=cap, policy=policy, seed=seed + 1))
+    assert tr.uses_persistent_rollout
     with torch.no_grad():
-        tr.actor.layer3.bias.add_(2.0)   # drive forward: collisions and arrivals, not only timeouts
+        (tr.actor.layer3 if policy == "mlp64x2" else tr.actor.out1).bias.add_(2.0)   # drive forward: collisions and arrivals, not only timeouts
     cpu = O.OracleSim(N, n_beams=B, max_episode_steps=cap, auto_reset=True, seed=seed)
     cpu.set_map(seg, per_env=per_env)
     if sampler: cpu.set_spawn_sampler(*sampler)
@@ -76,7 +77,7 @@ def soak_rollout(N, seg, per_env, T, iters=2, cap=60, seed=_S0, sampler=None, B=
             exact += int((obs[t + 1] == out["obs"]).all(1).sum()); tot += N; ends += int(out["ended"].sum())
             if f or d > tol:
                 print("MISMATCH iteration", it, "step", t, "maxdiff", d, "flags", f); break
-    print(f"closed-loop rollout N={N} S={seg.shape[-2]} per_env={per_env} B={B} {'f16' if half else 'f32'} rows T={T} x {iters}: bad={bad} max|dobs|={mx:.2e} max|dreward|={mr:.2e} "
+    print(f"closed-loop rollout {policy} N={N} S={seg.shape[-2]} per_env={per_env} B={B} {'f16' if half else 'f32'} rows T={T} x {iters}: bad={bad} max|dobs|={mx:.2e} max|dreward|={mr:.2e} "
           f"exact rows {exact/tot:.5f} episode ends {ends}")
     env.close()
 
@@ -91,3 +92,7 @@ if True:
     soak_rollout(8192, seg, False, 80, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi), half=True)
     soak_rollout(4096, maps.stage_1(), False, 300, cap=150, half=True)
     soak_rollout(4608, maps.stage_4(), False, 120, B=36, half=True)
+    # round 5: the persistent rollout of the reference's 512-wide actor (navsim_rollout_resmlp512)
+    soak_rollout(4096, maps.stage_1(), False, 512, cap=500, policy="resmlp512")
+    soak_rollout(3000, seg, False, 100, cap=40, sampler=maps.open_tables(seg, st, g) + (lo, hi), policy="resmlp512")
+    soak_rollout(1024, maps.replicate_per_env(maps.stage_2(), 1024, seed=3), True, 300, cap=120, policy="resmlp512")
