@@ -358,6 +358,7 @@ def ppo_shard_leg(n_envs, world, n_beams, obs_f16, sampler, rollout, epochs, det
     inf = env.sim.info()
     D = env.D
     roof = mlp64_update_roofline(tr, reps=10)
+    roof_f32 = mlp64_update_roofline(tr, reps=10, arith="f32") if roof and roof["arith"] != "f32" else None   # same buffers, same weights
     out = dict(workload=f"{n_envs} envs, {world} ({env.sim.S} segments, shared map), {n_beams} beams, {D}-D "
                         f"{'float16' if obs_f16 else 'float32'} rows, PPO mlp64x2 ({D}-64-64), rollout={rollout}, {epochs} full-batch epochs",
                value=round(steps * rollout * n_envs / dt, 1), unit="env-steps/s per GPU", steps=steps,
@@ -366,7 +367,8 @@ def ppo_shard_leg(n_envs, world, n_beams, obs_f16, sampler, rollout, epochs, det
                rollout=("persistent kernel (navsim_rollout_mlp64: " + (f"rollout_big_kernel, {inf['rollout_epb']} envs on {inf['rollout_waves']} waves" if inf["rollout_kind"] == 2
                         else f"rollout_kernel, {inf['rollout_epb']} envs on 8 waves") + (", tile boxes" if inf["rollout_cast"] == 3 else "") + ")")
                if tr.updater.fused_mlp64 else "hipGraph of policy + navsim_step launches",
-               update="navppo_mlp64_update_epoch" if tr.updater.fused_mlp64 else "PyTorch-ROCm", update_roofline=roof,
+               update=("navppo_mlp64_bf16x3_update_epoch" if tr.updater.bf16x3 else "navppo_mlp64_update_epoch") if tr.updater.fused_mlp64
+               else "PyTorch-ROCm", update_roofline=roof, update_roofline_f32=roof_f32,
                last_iter={k: lg[k] for k in ("avg_ep_rews", "success_rate", "episodes")}, bound_detail=detail)
     env.close()
     return out
@@ -386,8 +388,6 @@ def mlp64_update_roofline(tr, reps=40, arith=None):
     st = torch.zeros(8, device=obs.device)
     was = up.bf16x3
     if arith is not None:
-        if arith == "bf16x3" and D != 16:
-            return None
         up.bf16x3 = arith == "bf16x3"
     split_ms = None
     try:
@@ -424,14 +424,16 @@ def mlp64_update_roofline(tr, reps=40, arith=None):
         # what the matrix pipe executes: six bf16 piece products per float32 product (v_mfma_f32_32x32x16_bf16 / 16x16x32), priced
         # against the dense bf16 MFMA peak; `achieved` / `frac` above stay the ALGORITHMIC float32 FLOP against the f32-MFMA peak,
         # like for like with the native path and with earlier rounds (a frac above 1 there would mean: beyond what f32 MFMA can do)
-        mfma_flop = 6 * 2 * 2 * (12288 + 128 * D) * T * N
+        mfma_flop = 6 * 2 * 2 * (12288 + 128 * (16 if D == 16 else 48)) * T * N   # (42-column rows are 48 columns on chip)
         out["bf16_mfma"] = dict(executed_tflops=round(mfma_flop / ms / 1e9, 1), peak=MFMA_BF16_PEAK_TF, frac=round(mfma_flop / ms / 1e9 / MFMA_BF16_PEAK_TF, 4))
         out["split_obs_us_per_update"] = round(split_ms * 1e3, 1)
         out["detail"] = ("float32 products from operands split into three bf16 pieces, six piece products each on the bf16 MFMA, float32 "
                          "accumulate (float32-equivalent: tests/test_gpu_bf16x3.py).  Bound by the vector unit, not the matrix pipe: per "
                          "32-sample tile and net 180 MFMAs (5,376 cycles: SQ_VALU_MFMA_BUSY = 33 % of the launch) beside ~1,465 vector "
-                         "instructions (880 of them the five 32-value splits, SQ_ACTIVE_INST_VALU = 41 %); bf16 MFMA and vector work of the "
-                         "two waves of a SIMD do not overlap (tools/ubench/bf16_mfma_valu_overlap.hip) -- profiles/r05_bf16x3_pmc.txt")
+                         "instructions (880 of them the five 32-value splits, SQ_ACTIVE_INST_VALU = 41 %) at 16 columns; bf16 MFMA and vector "
+                         "work of the two waves of a SIMD do not overlap (tools/ubench/bf16_mfma_valu_overlap.hip) -- profiles/r05_bf16x3_pmc.txt"
+                         + ("" if D == 16 else ".  42-column rows (48 on chip): 252 MFMAs per tile and net, 4 waves x 512 registers "
+                            "(the 8-wave build does not fit the LDS)"))
     else:
         out["detail"] = ("f32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): 14,336 MFMA cycles + ~575 vector instructions per 32-sample "
                          "tile and net at D = 16; f32 MFMA and VALU share the SIMD's FMA lanes, the loop sustains ~2.2 GHz")

@@ -99,7 +99,7 @@ int navppo_mlp64_update_epoch(float* params_dev, const void* obs_dev, int32_t ob
                               float* adam_v_dev, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------------
- * The same update (ppo.py:305-397, 16-column rows) with every matrix product evaluated on the bf16 MFMA from operands split into
+ * The same update (ppo.py:305-397; 16- or 42-column rows, float32 or float16) with every matrix product evaluated on the bf16 MFMA from operands split into
  * three bf16 pieces -- "bf16x3": a = a0 + a1 + a2 exactly (8 + 8 + 8 significand bits), a b ~ the six leading piece products,
  * each exact in float32, float32 accumulation, small terms first.  float32-equivalent by measurement (against float64 the
  * error is not above the f32-MFMA path's on any contraction of the kernel: tests/test_gpu_bf16x3.py), 16 x the
@@ -107,20 +107,21 @@ int navppo_mlp64_update_epoch(float* params_dev, const void* obs_dev, int32_t ob
  * which stay available (PPOConfig.update_arith = "f32").
  *
  * The observations are split ONCE per update -- they do not change over the epochs -- into prep_dev
- * (navppo_mlp64_bf16x3_prep_bytes(n) bytes, 192 per sample: row-major pieces for the forward products, tile-transposed pieces
- * for the weight gradient of layer 1); the epoch entry points then take prep_dev in place of obs_dev.
+ * (navppo_mlp64_bf16x3_prep_bytes(n, obs_dim) bytes -- 192 per sample at 16 columns, 576 at 42 (48 on chip): row-major pieces
+ * for the forward products, tile-transposed pieces for the weight gradient of layer 1); the epoch entry points then take
+ * (prep_dev, obs_dim) in place of (obs_dev, obs_dim, obs_f16).
  */
-size_t navppo_mlp64_bf16x3_prep_bytes(int64_t n_samples);
-int navppo_mlp64_bf16x3_prepare(const void* obs_dev, int32_t obs_dim /* 16 */, int32_t obs_f16, int64_t n_samples, void* prep_dev,
+size_t navppo_mlp64_bf16x3_prep_bytes(int64_t n_samples, int32_t obs_dim /* 16 | 42; anything else: 0 */);
+int navppo_mlp64_bf16x3_prepare(const void* obs_dev, int32_t obs_dim /* 16 | 42 */, int32_t obs_f16, int64_t n_samples, void* prep_dev,
                                 void* stream);
-/* as navppo_mlp64_loss_grad / _loss_grad_net / _update_epoch, same workspace (navppo_mlp64_workspace_bytes(16)) */
-int navppo_mlp64_bf16x3_loss_grad(const float* params_dev, const void* prep_dev, const float* act_dev, const float* logp_old_dev,
-                                  const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float* grad_dev,
-                                  float* stats_dev, void* workspace_dev, void* stream);
-int navppo_mlp64_bf16x3_loss_grad_net(int32_t net, const float* params_dev, const void* prep_dev, const float* act_dev,
+/* as navppo_mlp64_loss_grad / _loss_grad_net / _update_epoch, same workspace (navppo_mlp64_workspace_bytes(obs_dim)) */
+int navppo_mlp64_bf16x3_loss_grad(const float* params_dev, const void* prep_dev, int32_t obs_dim, const float* act_dev,
+                                  const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip,
+                                  float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
+int navppo_mlp64_bf16x3_loss_grad_net(int32_t net, const float* params_dev, const void* prep_dev, int32_t obs_dim, const float* act_dev,
                                       const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var,
                                       float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
-int navppo_mlp64_bf16x3_update_epoch(float* params_dev, const void* prep_dev, const float* act_dev, const float* logp_old_dev,
+int navppo_mlp64_bf16x3_update_epoch(float* params_dev, const void* prep_dev, int32_t obs_dim, const float* act_dev, const float* logp_old_dev,
                                      const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
                                      float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
                                      float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);

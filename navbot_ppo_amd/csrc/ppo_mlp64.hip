@@ -785,53 +785,75 @@ __device__ __forceinline__ void mma6_acc16_2(f32x4& acc0, f32x4& acc1, const Pie
     acc1 = X3_MFMA16(as_bf(A1.p[0]), as_bf(B.p[0]), acc1);
 }
 
-// ---- the pre-split observations (navppo_mlp64_bf16x3_prepare): per 32-sample tile
-//   rows  [32 m][3 pieces][16 f] bf16   F1's B operand: lane (m, kh) reads the eight features 8 kh .. 8 kh + 7 of piece i (16 bytes)
-//   cols  [3 pieces][16 f][32 m] bf16   G1's B operand: lane (f, kb) reads the eight samples 8 kb .. 8 kb + 7 of feature f
-constexpr int kX3TileBytes = 2 * 32 * 3 * 16 * 2;   // 6144
-constexpr int kX3RowsBytes = 32 * 3 * 16 * 2;       // offset of `cols` inside a tile
+// ---- the pre-split observations (navppo_mlp64_bf16x3_prepare): per 32-sample tile, INP = 16 | 48 columns on chip (42-column rows:
+// columns 42 .. 47 are zero), KX = INP / 16 k-steps of F1 / column tiles of dW1
+//   rows  [32 m][3 pieces][INP f] bf16   F1's B operand: lane (m, kh) reads the eight features 16 ks + 8 kh .. + 7 of piece i (16 bytes)
+//   cols  [3 pieces][INP f][32 m] bf16   G1's B operand: lane (f, kb) reads the eight samples 8 kb .. 8 kb + 7 of feature 16 c + f
+#ifndef X3_WAVES
+#define X3_WAVES 8   // waves per workgroup of the 16-column split pass (one workgroup per CU: 8 = two per SIMD; measured with 4, one per
+#endif               // SIMD and 512 registers each: 1069 us per epoch against 924)
+template <int IN>
+struct XPad {
+    static constexpr int INP = Pad<IN>::INP, KX = INP / 16;
+    static constexpr int W1P = (INP == 16) ? 16 : 56;       // pitch of a W1 piece row in LDS (bf16): 112-byte rows, conflict-free 16-byte reads
+    // 42 columns: the wave tiles of 8 waves + 21 KB of W1 pieces do not fit the LDS beside W2 / W2^T -- 4 waves (one per SIMD, 512
+    // registers each: the 48 dW1 accumulators and 36 + 36 registers of row pieces fit without spills), as the f32 pass of that width
+    static constexpr int NW = (IN == 16) ? X3_WAVES : 4;
+    static constexpr int kRowsBytes = 32 * 3 * INP * 2;     // 3072 | 9216: offset of `cols` inside a tile
+    static constexpr int kTileBytes = 2 * kRowsBytes;       // 6144 | 18432
+};
 
-template <bool F16>
+template <bool F16, int IN>
 __global__ __launch_bounds__(64) void mlp64_split_obs(const void* __restrict__ obs, long long M, unsigned char* __restrict__ prep) {
-    __shared__ __attribute__((aligned(16))) uint16_t colsT[3][16][32];
+    constexpr int INP = XPad<IN>::INP, KX = XPad<IN>::KX;
+    __shared__ __attribute__((aligned(16))) uint16_t colsT[3][INP][32];
     const int lane = threadIdx.x, m = lane & 31, kh = lane >> 5;
     const long long tile = blockIdx.x, row = tile * 32 + m;
-    float v[8];
+    unsigned char* const t = prep + (size_t)tile * XPad<IN>::kTileBytes;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (row < M) ? obs_at<F16>(obs, row * 16 + 8 * kh + e) : 0.f;
-    const Pieces P = split8(v);
-    unsigned char* const t = prep + (size_t)tile * kX3TileBytes;
+    for (int ks = 0; ks < KX; ++ks) {
+        float v[8];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        *reinterpret_cast<uint4*>(t + ((m * 3 + i) * 16 + 8 * kh) * 2) = P.p[i];
-        const uint32_t w[4] = {P.p[i].x, P.p[i].y, P.p[i].z, P.p[i].w};
+        for (int e = 0; e < 8; ++e) {
+            const int f = 16 * ks + 8 * kh + e;
+            v[e] = (row < M && f < IN) ? obs_at<F16>(obs, row * IN + min(f, IN - 1)) : 0.f;
+        }
+        const Pieces P = split8(v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) colsT[i][8 * kh + e][m] = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+        for (int i = 0; i < 3; ++i) {
+            *reinterpret_cast<uint4*>(t + ((m * 3 + i) * INP + 16 * ks + 8 * kh) * 2) = P.p[i];
+            const uint32_t w[4] = {P.p[i].x, P.p[i].y, P.p[i].z, P.p[i].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                colsT[i][16 * ks + 8 * kh + e][m] = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+        }
     }
     __syncthreads();
-    // 3 x 16 x 32 bf16 = 3072 bytes = 192 x 16 bytes
+    // 3 x INP x 32 bf16 = INP x 12 x 16 bytes
     const uint4* src = reinterpret_cast<const uint4*>(&colsT[0][0][0]);
-    uint4* dst = reinterpret_cast<uint4*>(t + kX3RowsBytes);
-    for (int k = lane; k < 192; k += 64) dst[k] = src[k];
+    uint4* dst = reinterpret_cast<uint4*>(t + XPad<IN>::kRowsBytes);
+    for (int k = lane; k < 12 * INP; k += 64) dst[k] = src[k];
 }
 
 // ---- LDS of the split pass
 constexpr int XT = 32;                    // wave tile: 32 rows x 32 floats, 16-byte slot c of row r stored at slot c ^ ((r >> 1) & 7)
 constexpr int X_TILE_F = 32 * XT;
 constexpr int X_WAVE_F = 3 * X_TILE_F + 64;   // T0 | T1 | TD | g3[32] g4[32]
-#ifndef X3_WAVES
-#define X3_WAVES 8   // waves per workgroup of the split pass (one workgroup per CU: 8 = two per SIMD; measured with 4, one per SIMD and
-#endif               // 512 registers each: 1069 us per epoch against 924)
-constexpr int kXWaves = X3_WAVES, kXThreads = 64 * kXWaves;
+template <int IN>
 struct SmemX {
     // weight pieces, bf16, [piece][row][k-position]; 16-byte slot s of row r stored at slot s ^ ((r >> 1) & 7)
     uint16_t W2p[3][H][H];    // rows = layer-2 units (A operand of F2), k = layer-1 units, permuted
     uint16_t W2Tp[3][H][H];   // rows = layer-1 units (A operand of B2), k = layer-2 units, permuted
-    uint16_t W1p[3][H][16];   // rows = layer-1 units (A operand of F1), k = features
+    uint16_t W1p[3][H][XPad<IN>::W1P];   // rows = layer-1 units (A operand of F1), k = features
     float b1[H], b2[H], w3[H], w4[H];
-    float wv[(kXWaves * X_WAVE_F > 4 * ((P_ACTOR + 6) & ~3)) ? kXWaves * X_WAVE_F : 4 * ((P_ACTOR + 6) & ~3)];
+    // the wave tiles; at the end of a pass also the four rows of the workgroup's gradient reduction -- 16 columns: in wv; 42 columns
+    // (4 x 7048 floats): from the start of the struct on, nothing reads the weights any more at that point
+    static constexpr int kRedRow = (Layout<IN>::P_ACTOR + 6) & ~3;
+    static constexpr int kWvF = (IN == 16 && 4 * kRedRow > XPad<IN>::NW * X_WAVE_F) ? 4 * kRedRow : XPad<IN>::NW * X_WAVE_F;
+    float wv[kWvF];
 };
-static_assert(sizeof(SmemX) <= 160 * 1024, "LDS");
+static_assert(sizeof(SmemX<16>) <= 160 * 1024 && sizeof(SmemX<42>) <= 160 * 1024, "LDS");
+static_assert(sizeof(SmemX<42>) >= 4 * SmemX<42>::kRedRow * sizeof(float), "the reduction rows of the 42-column nets fit the struct");
 
 // element (row, col) of a swizzled wave tile
 __device__ __forceinline__ int xt(const int row, const int col) { return row * XT + ((((col >> 2) ^ (row >> 1)) & 7) << 2) + (col & 3); }
@@ -840,13 +862,18 @@ __device__ __forceinline__ int kpos(const int k) { return (k & ~12) | ((k & 4) <
 // address (in uint16 units) of k-position p of row r
 __device__ __forceinline__ int wslot(const int r, const int p) { return r * H + ((((p >> 3) ^ (r >> 1)) & 7) << 3) + (p & 7); }
 
-template <bool ACTOR>
-__device__ __forceinline__ void pass_body_x3(SmemX& sm, const float* __restrict__ params, const unsigned char* __restrict__ prep,
+template <bool ACTOR, int IN>
+__device__ __forceinline__ void pass_body_x3(SmemX<IN>& sm, const float* __restrict__ params, const unsigned char* __restrict__ prep,
                                              const float* __restrict__ act, const float* __restrict__ logp_old,
                                              const float* __restrict__ rtg, const float* __restrict__ adv, long long M, float var,
                                              float clip, float inv_n, float* __restrict__ partial, float* __restrict__ stats_partial) {
-    constexpr int P = ACTOR ? P_ACTOR : P_CRITIC;
-    constexpr int NT = kXThreads;
+    using L = Layout<IN>;   // (the names below shadow the 16-column constants of the namespace)
+    constexpr int OFF_W1 = L::OFF_W1, OFF_B1 = L::OFF_B1, OFF_W2 = L::OFF_W2, OFF_B2 = L::OFF_B2, OFF_W3 = L::OFF_W3, OFF_B3 = L::OFF_B3,
+                  OFF_W4 = L::OFF_W4, OFF_B4 = L::OFF_B4;
+    constexpr int P = ACTOR ? L::P_ACTOR : L::P_CRITIC;
+    constexpr int INP = XPad<IN>::INP, KX = XPad<IN>::KX, kXWaves = XPad<IN>::NW, kX3TileBytes = XPad<IN>::kTileBytes,
+                  kX3RowsBytes = XPad<IN>::kRowsBytes;
+    constexpr int NT = 64 * kXWaves;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15, kk = lane >> 4;
 
@@ -864,10 +891,12 @@ __device__ __forceinline__ void pass_body_x3(SmemX& sm, const float* __restrict_
             (&sm.W2Tp[i][0][0])[wslot(c + 1, kpos(r))] = (uint16_t)(pc[i] >> 16);
         }
     }
-    for (int k = tid; k < H * 16 / 2; k += NT) {
-        const int r = (2 * k) / 16, c = (2 * k) % 16;
+    for (int k = tid; k < H * INP / 2; k += NT) {   // (42 columns: the pair (c, c + 1) is inside the row or past it as a whole)
+        const int r = (2 * k) / INP, c = (2 * k) % INP;
         uint32_t p0, p1, p2;
-        split_pair(params[OFF_W1 + r * 16 + c], params[OFF_W1 + r * 16 + c + 1], p0, p1, p2);
+        const int cc = min(c, IN - 2);
+        const float wa_ = params[OFF_W1 + r * IN + cc], wb_ = params[OFF_W1 + r * IN + cc + 1];
+        split_pair(c < IN ? wa_ : 0.f, c < IN ? wb_ : 0.f, p0, p1, p2);
         *reinterpret_cast<uint32_t*>(&sm.W1p[0][r][c]) = p0;
         *reinterpret_cast<uint32_t*>(&sm.W1p[1][r][c]) = p1;
         *reinterpret_cast<uint32_t*>(&sm.W1p[2][r][c]) = p2;
@@ -897,26 +926,32 @@ __device__ __forceinline__ void pass_body_x3(SmemX& sm, const float* __restrict_
 
     // accumulators that persist over this wave's tiles
     f32x16 aW2[2][2];   // dW2 quadrant [n2 tile][n tile]
-    f32x4 aW1[4];       // dW1 rows 16 u .. + 15
+    f32x4 aW1[KX][4];   // dW1 rows 16 u .. + 15 of column tile c
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) aW2[a][b] = zero16();
 #pragma unroll
-    for (int u = 0; u < 4; ++u) aW1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < KX; ++c)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) aW1[c][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     float adb2[2] = {0.f, 0.f}, adw3[2] = {0.f, 0.f}, adw4[2] = {0.f, 0.f}, adb1[4] = {0.f, 0.f, 0.f, 0.f};
     float adb3 = 0.f, adb4 = 0.f, st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
 
     const long long n_tiles = (M + 31) / 32;
     const long long gw = (long long)blockIdx.x * kXWaves + wave, stride = (long long)gridDim.x * kXWaves;
-    Pieces xp;   // the tile's observation rows as F1's B operand (prefetched)
-    xp.p[0] = xp.p[1] = xp.p[2] = make_uint4(0u, 0u, 0u, 0u);
+    Pieces xp[KX];   // the tile's observation rows as F1's B operand (prefetched), one set of pieces per k-step
+#pragma unroll
+    for (int ks = 0; ks < KX; ++ks) xp[ks].p[0] = xp[ks].p[1] = xp[ks].p[2] = make_uint4(0u, 0u, 0u, 0u);
     float pre_a0 = 0.f, pre_a1 = 0.f, pre_lp = 0.f, pre_t = 0.f;
     auto prefetch_tile = [&](long long tile) {
         const long long m = tile * 32 + l31;
-        const unsigned char* t = prep + (size_t)tile * kX3TileBytes + ((l31 * 3) * 16 + 8 * lhi) * 2;
+        const unsigned char* t = prep + (size_t)tile * kX3TileBytes + ((l31 * 3) * INP + 8 * lhi) * 2;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) xp.p[i] = *reinterpret_cast<const uint4*>(t + i * 32);   // rows past the batch are zero in `prep`
+        for (int ks = 0; ks < KX; ++ks)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)   // rows past the batch are zero in `prep`
+                xp[ks].p[i] = *reinterpret_cast<const uint4*>(t + (i * INP + 16 * ks) * 2);
         if (m < M) {
             if (ACTOR) {
                 const float2 a = reinterpret_cast<const float2*>(act)[m];
@@ -932,21 +967,29 @@ __device__ __forceinline__ void pass_body_x3(SmemX& sm, const float* __restrict_
     if (gw < n_tiles) prefetch_tile(gw);
     for (long long tile = gw; tile < n_tiles; tile += stride) {
         const bool valid = tile * 32 + l31 < M;
-        const Pieces xr = xp;
+        Pieces xr[KX];
+#pragma unroll
+        for (int ks = 0; ks < KX; ++ks) xr[ks] = xp[ks];
         const float cur_a0 = pre_a0, cur_a1 = pre_a1, cur_lp = pre_lp, cur_t = pre_t;
         if (tile + stride < n_tiles) prefetch_tile(tile + stride);
 
-        // ---- F1: H1^T = relu(b1 + W1 X^T), K = 16: one k-step
+        // ---- F1: H1^T = relu(b1 + W1 X^T), K = 16 per k-step (one for 16 columns, three for 42)
         f32x16 c1[2] = {zero16(), zero16()};
         {
-            Pieces wa[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int ks = 0; ks < KX; ++ks) {
+                Pieces wa[2];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) wa[t].p[i] = *reinterpret_cast<const uint4*>(&sm.W1p[i][32 * t + l31][8 * lhi]);
-            mma5_small2(c1[0], c1[1], wa[0], wa[1], xr);
-            mma1_big(c1[0], wa[0].p[0], xr.p[0]);
-            mma1_big(c1[1], wa[1].p[0], xr.p[0]);
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) wa[t].p[i] = *reinterpret_cast<const uint4*>(&sm.W1p[i][32 * t + l31][16 * ks + 8 * lhi]);
+                mma5_small2(c1[0], c1[1], wa[0], wa[1], xr[ks]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KX; ++ks) {
+                mma1_big(c1[0], *reinterpret_cast<const uint4*>(&sm.W1p[0][l31][16 * ks + 8 * lhi]), xr[ks].p[0]);
+                mma1_big(c1[1], *reinterpret_cast<const uint4*>(&sm.W1p[0][32 + l31][16 * ks + 8 * lhi]), xr[ks].p[0]);
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1147,11 +1190,13 @@ __device__ __forceinline__ void pass_body_x3(SmemX& sm, const float* __restrict_
         wave_lds_fence();
 
         // ---- G1: dW1 += dH1^T X over the tile's 32 samples (16 x 16 x 32: one k-step); X^T pieces from the pre-split buffer
-        Pieces xb;   // lane (f = l15, kb = kk): samples 8 kk .. 8 kk + 7 of feature f
+        Pieces xb[KX];   // lane (f = l15, kb = kk): samples 8 kk .. 8 kk + 7 of feature 16 c + f
         {
             const unsigned char* t = prep + (size_t)tile * kX3TileBytes + kX3RowsBytes + (l15 * 32 + 8 * kk) * 2;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) xb.p[i] = *reinterpret_cast<const uint4*>(t + i * 16 * 32 * 2);
+            for (int c = 0; c < KX; ++c)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xb[c].p[i] = *reinterpret_cast<const uint4*>(t + (i * INP + 16 * c) * 32 * 2);
         }
 #pragma unroll
         for (int t1 = 0; t1 < 2; ++t1) {
@@ -1166,7 +1211,8 @@ __device__ __forceinline__ void pass_body_x3(SmemX& sm, const float* __restrict_
                 adb1[2 * t1 + u] += ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
                 da[u] = split8(dv);
             }
-            mma6_acc16_2(aW1[2 * t1], aW1[2 * t1 + 1], da[0], da[1], xb);
+#pragma unroll
+            for (int c = 0; c < KX; ++c) mma6_acc16_2(aW1[c][2 * t1], aW1[c][2 * t1 + 1], da[0], da[1], xb[c]);
             wave_lds_fence();
         }
     }
@@ -1194,7 +1240,8 @@ __device__ __forceinline__ void pass_body_x3(SmemX& sm, const float* __restrict_
         v += __shfl_xor(v, 32, 64);
         qb1[u] = v;
     }
-    float* const row = sm.wv + (wave & 3) * RP;
+    float* const red0 = (IN == 16) ? sm.wv : reinterpret_cast<float*>(&sm);   // (42 columns: the rows start at the dead weight pieces)
+    float* const row = red0 + (wave & 3) * RP;
 #pragma unroll
     for (int pass = 0; pass < kXWaves / 4; ++pass) {
         if ((wave >> 2) == pass) {
@@ -1215,7 +1262,10 @@ __device__ __forceinline__ void pass_body_x3(SmemX& sm, const float* __restrict_
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) put(OFF_W1 + (16 * u + 4 * kk + r) * IN + l15, aW1[u][r]);
+                for (int c = 0; c < KX; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * c + l15 < IN) put(OFF_W1 + (16 * u + 4 * kk + r) * IN + 16 * c + l15, aW1[c][u][r]);
                 if (kk == 0) put(OFF_B1 + 16 * u + l15, qb1[u]);
             }
             if (lane == 0) {
@@ -1229,22 +1279,23 @@ __device__ __forceinline__ void pass_body_x3(SmemX& sm, const float* __restrict_
         __syncthreads();
     }
     float* out = partial + (size_t)blockIdx.x * P;
-    const float* red = sm.wv;
+    const float* red = red0;
     for (int k = tid; k < P; k += NT) out[k] = (red[k] + red[RP + k]) + (red[2 * RP + k] + red[3 * RP + k]);
     if (tid < 3) stats_partial[blockIdx.x * 4 + tid] = (red[P + tid] + red[RP + P + tid]) + (red[2 * RP + P + tid] + red[3 * RP + P + tid]);
 }
 
 // both nets of one epoch in one launch; net_mask: bit 0 = actor, bit 1 = critic (the one-net launches of the multi-GPU pipeline)
-__global__ __launch_bounds__(kXThreads) void mlp64_pass_both_x3(const float* __restrict__ params, const unsigned char* __restrict__ prep,
+template <int IN>
+__global__ __launch_bounds__(64 * XPad<IN>::NW) void mlp64_pass_both_x3(const float* __restrict__ params, const unsigned char* __restrict__ prep,
                                                                 const float* __restrict__ act, const float* __restrict__ logp_old,
                                                                 const float* __restrict__ rtg, const float* __restrict__ adv,
                                                                 long long M, float var, float clip, float inv_n, int net_mask,
                                                                 float* __restrict__ partial_a, float* __restrict__ stats_partial_a,
                                                                 float* __restrict__ partial_c, float* __restrict__ stats_partial_c) {
-    __shared__ __attribute__((aligned(16))) SmemX sm;
-    if (net_mask & 1) pass_body_x3<true>(sm, params, prep, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_a, stats_partial_a);
+    __shared__ __attribute__((aligned(16))) SmemX<IN> sm;
+    if (net_mask & 1) pass_body_x3<true, IN>(sm, params, prep, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_a, stats_partial_a);
     if (net_mask == 3) __syncthreads();
-    if (net_mask & 2) pass_body_x3<false>(sm, params + P_ACTOR, prep, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_c, stats_partial_c);
+    if (net_mask & 2) pass_body_x3<false, IN>(sm, params + Layout<IN>::P_ACTOR, prep, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_c, stats_partial_c);
 }
 
 // grad[p] = sum over the workgroups' partial rows, for BOTH nets; ADAM (single-GPU epoch): then torch.optim.Adam's update (ppo.py:116-117,381,392; defaults betas
@@ -1640,23 +1691,22 @@ int navppo_mlp64_update_epoch(float* params_dev, const void* obs_dev, int32_t ob
     return 0;
 }
 
-size_t navppo_mlp64_bf16x3_prep_bytes(int64_t n_samples) {
-    if (n_samples < 1) return 0;
-    return (size_t)((n_samples + 31) / 32) * kX3TileBytes;
+size_t navppo_mlp64_bf16x3_prep_bytes(int64_t n_samples, int32_t obs_dim) {
+    if (n_samples < 1 || (obs_dim != 16 && obs_dim != 42)) return 0;
+    return (size_t)((n_samples + 31) / 32) * (obs_dim == 16 ? XPad<16>::kTileBytes : XPad<42>::kTileBytes);
 }
 
 int navppo_mlp64_bf16x3_prepare(const void* obs_dev, int32_t obs_dim, int32_t obs_f16, int64_t n_samples, void* prep_dev, void* stream) {
-    if (!obs_dev || !prep_dev || n_samples < 1 || obs_dim != 16 || !obs_aligned(obs_dev, obs_dim, obs_f16) || ((uintptr_t)prep_dev & 15)) {
-        g_err = "navppo_mlp64_bf16x3_prepare: bad argument (16-column rows; obs and prep 16-byte aligned)";
+    if (!obs_dev || !prep_dev || n_samples < 1 || (obs_dim != 16 && obs_dim != 42) || !obs_aligned(obs_dev, obs_dim, obs_f16) ||
+        ((uintptr_t)prep_dev & 15)) {
+        g_err = "navppo_mlp64_bf16x3_prepare: bad argument (obs_dim is 16 or 42; obs aligned as for navppo_mlp64_loss_grad, prep 16-byte aligned)";
         return -1;
     }
     const unsigned tiles = (unsigned)((n_samples + 31) / 32);
-    if (obs_f16)
-        hipLaunchKernelGGL(mlp64_split_obs<true>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, obs_dev, (long long)n_samples,
-                           reinterpret_cast<unsigned char*>(prep_dev));
-    else
-        hipLaunchKernelGGL(mlp64_split_obs<false>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, obs_dev, (long long)n_samples,
-                           reinterpret_cast<unsigned char*>(prep_dev));
+    for_obs(obs_dim, obs_f16, [&](auto in, auto f16) {
+        hipLaunchKernelGGL((mlp64_split_obs<decltype(f16)::value, decltype(in)::value>), dim3(tiles), dim3(64), 0, (hipStream_t)stream, obs_dev,
+                           (long long)n_samples, reinterpret_cast<unsigned char*>(prep_dev));
+    });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_bf16x3_prepare: ") + hipGetErrorString(e);
@@ -1666,20 +1716,25 @@ int navppo_mlp64_bf16x3_prepare(const void* obs_dev, int32_t obs_dim, int32_t ob
 }
 
 // net_mask 3: both nets; 1 / 2: the actor's / the critic's pass and its slice of the reduction; step >= 1: Adam in the reduction
-static int x3_epoch(const char* who, float* params_dev, const void* prep_dev, const float* act_dev, const float* logp_old_dev,
+static int x3_epoch(const char* who, float* params_dev, const void* prep_dev, int32_t obs_dim, const float* act_dev, const float* logp_old_dev,
                     const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, int net_mask, int32_t step,
                     float lr, float beta1, float beta2, float eps, float* adam_m_dev, float* adam_v_dev, float* grad_dev,
                     float* stats_dev, void* workspace_dev, void* stream) {
     if (!params_dev || !prep_dev || !act_dev || !logp_old_dev || !rtg_dev || !adv_dev || !grad_dev || !stats_dev || !workspace_dev ||
-        n_samples < 1 || !(var > 0.f) || ((uintptr_t)prep_dev & 15) || ((uintptr_t)act_dev & 7)) {
-        g_err = std::string(who) + ": bad argument (prep 16-byte, act 8-byte aligned)";
+        n_samples < 1 || !(var > 0.f) || (obs_dim != 16 && obs_dim != 42) || ((uintptr_t)prep_dev & 15) || ((uintptr_t)act_dev & 7)) {
+        g_err = std::string(who) + ": bad argument (obs_dim is 16 or 42; prep 16-byte, act 8-byte aligned)";
         return -1;
     }
     hipStream_t st = (hipStream_t)stream;
-    const PassPlan pl = plan_pass(workspace_dev, n_samples, 16);
-    hipLaunchKernelGGL(mlp64_pass_both_x3, dim3(pl.blocks), dim3(kXThreads), 0, st, params_dev, reinterpret_cast<const unsigned char*>(prep_dev),
-                       act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip, pl.inv_n, net_mask, pl.partial, pl.stats_partial,
-                       pl.partial_c, pl.stats_partial_c);
+    const PassPlan pl = plan_pass(workspace_dev, n_samples, obs_dim);
+    if (obs_dim == 16)
+        hipLaunchKernelGGL(mlp64_pass_both_x3<16>, dim3(pl.blocks), dim3(64 * XPad<16>::NW), 0, st, params_dev,
+                           reinterpret_cast<const unsigned char*>(prep_dev), act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip,
+                           pl.inv_n, net_mask, pl.partial, pl.stats_partial, pl.partial_c, pl.stats_partial_c);
+    else
+        hipLaunchKernelGGL(mlp64_pass_both_x3<42>, dim3(pl.blocks), dim3(64 * XPad<42>::NW), 0, st, params_dev,
+                           reinterpret_cast<const unsigned char*>(prep_dev), act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip,
+                           pl.inv_n, net_mask, pl.partial, pl.stats_partial, pl.partial_c, pl.stats_partial_c);
     const int q0 = (net_mask & 1) ? 0 : pl.pa, q1 = (net_mask & 2) ? pl.pa + pl.pc : pl.pa;
     if (step >= 1) {
         const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
@@ -1700,25 +1755,25 @@ static int x3_epoch(const char* who, float* params_dev, const void* prep_dev, co
     return 0;
 }
 
-int navppo_mlp64_bf16x3_loss_grad(const float* params_dev, const void* prep_dev, const float* act_dev, const float* logp_old_dev,
-                                  const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float* grad_dev,
-                                  float* stats_dev, void* workspace_dev, void* stream) {
-    return x3_epoch("navppo_mlp64_bf16x3_loss_grad", const_cast<float*>(params_dev), prep_dev, act_dev, logp_old_dev, rtg_dev, adv_dev,
+int navppo_mlp64_bf16x3_loss_grad(const float* params_dev, const void* prep_dev, int32_t obs_dim, const float* act_dev,
+                                  const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip,
+                                  float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
+    return x3_epoch("navppo_mlp64_bf16x3_loss_grad", const_cast<float*>(params_dev), prep_dev, obs_dim, act_dev, logp_old_dev, rtg_dev, adv_dev,
                     n_samples, var, clip, 3, 0, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, grad_dev, stats_dev, workspace_dev, stream);
 }
 
-int navppo_mlp64_bf16x3_loss_grad_net(int32_t net, const float* params_dev, const void* prep_dev, const float* act_dev,
+int navppo_mlp64_bf16x3_loss_grad_net(int32_t net, const float* params_dev, const void* prep_dev, int32_t obs_dim, const float* act_dev,
                                       const float* logp_old_dev, const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var,
                                       float clip, float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
     if (net != 0 && net != 1) {
         g_err = "navppo_mlp64_bf16x3_loss_grad_net: net is 0 (actor) or 1 (critic)";
         return -1;
     }
-    return x3_epoch("navppo_mlp64_bf16x3_loss_grad_net", const_cast<float*>(params_dev), prep_dev, act_dev, logp_old_dev, rtg_dev, adv_dev,
+    return x3_epoch("navppo_mlp64_bf16x3_loss_grad_net", const_cast<float*>(params_dev), prep_dev, obs_dim, act_dev, logp_old_dev, rtg_dev, adv_dev,
                     n_samples, var, clip, net == 0 ? 1 : 2, 0, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, grad_dev, stats_dev, workspace_dev, stream);
 }
 
-int navppo_mlp64_bf16x3_update_epoch(float* params_dev, const void* prep_dev, const float* act_dev, const float* logp_old_dev,
+int navppo_mlp64_bf16x3_update_epoch(float* params_dev, const void* prep_dev, int32_t obs_dim, const float* act_dev, const float* logp_old_dev,
                                      const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
                                      float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
                                      float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
@@ -1726,7 +1781,7 @@ int navppo_mlp64_bf16x3_update_epoch(float* params_dev, const void* prep_dev, co
         g_err = "navppo_mlp64_bf16x3_update_epoch: bad argument";
         return -1;
     }
-    return x3_epoch("navppo_mlp64_bf16x3_update_epoch", params_dev, prep_dev, act_dev, logp_old_dev, rtg_dev, adv_dev, n_samples, var, clip,
+    return x3_epoch("navppo_mlp64_bf16x3_update_epoch", params_dev, prep_dev, obs_dim, act_dev, logp_old_dev, rtg_dev, adv_dev, n_samples, var, clip,
                     3, step, lr, beta1, beta2, eps, adam_m_dev, adam_v_dev, grad_dev, stats_dev, workspace_dev, stream);
 }
 

@@ -227,7 +227,7 @@ class PPOUpdater:
         self.fused = "navppo_mlp64" if self.fused_mlp64 else "navppo_resmlp512" if self.fused_resmlp512 else None
         if cfg.update_arith not in ("f32", "bf16x3"):
             raise ValueError(f"update_arith {cfg.update_arith!r}: 'f32' or 'bf16x3'")
-        self.bf16x3 = self.fused_mlp64 and self.obs_dim == 16 and cfg.update_arith == "bf16x3"   # (the split pass exists for 16-column rows)
+        self.bf16x3 = self.fused_mlp64 and cfg.update_arith == "bf16x3"   # (16- and 42-column rows, float32 or float16)
         self._prep = self._prep_key = None
         if self.fused:
             from ._native import lib
@@ -272,7 +272,7 @@ class PPOUpdater:
         from ._native import lib
         L = lib()
         p, d, f16 = self._obs_args(obs)
-        need = L.navppo_mlp64_bf16x3_prep_bytes(int(obs.shape[0]))
+        need = L.navppo_mlp64_bf16x3_prep_bytes(int(obs.shape[0]), self.obs_dim)
         if self._prep is None or self._prep.numel() < need:
             self._prep = None
             self._prep = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -297,7 +297,7 @@ class PPOUpdater:
         ptr = lambda t: C.c_void_p(t.data_ptr())
         for t in (acts, logp_old, rtg, adv):
             assert t.is_contiguous() and t.dtype == torch.float32
-        name, oargs = (("navppo_mlp64_bf16x3", (self._prepared(obs),)) if self.bf16x3 else (self.fused, self._obs_args(obs)))
+        name, oargs = (("navppo_mlp64_bf16x3", (self._prepared(obs), self.obs_dim)) if self.bf16x3 else (self.fused, self._obs_args(obs)))
         rc = getattr(L, name + "_loss_grad")(ptr(self.fp.flat), *oargs, ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
                                                    int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad),
                                                    ptr(self._fstats if stats is None else stats), ptr(self._workspace(obs.shape[0])),
@@ -311,7 +311,7 @@ class PPOUpdater:
         from ._native import lib
         L = lib()
         ptr = lambda t: C.c_void_p(t.data_ptr())
-        fn, oargs = ((L.navppo_mlp64_bf16x3_loss_grad_net, (self._prepared(obs),)) if self.bf16x3
+        fn, oargs = ((L.navppo_mlp64_bf16x3_loss_grad_net, (self._prepared(obs), self.obs_dim)) if self.bf16x3
                      else (L.navppo_mlp64_loss_grad_net, self._obs_args(obs)))
         rc = fn(int(net), ptr(self.fp.flat), *oargs, ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
                                           int(obs.shape[0]), float(var), float(self.cfg.clip), ptr(self.fp.grad), ptr(stats),
@@ -386,7 +386,7 @@ class PPOUpdater:
         L = lib()
         ptr = lambda t: C.c_void_p(t.data_ptr())
         self._adam_t += 1
-        name, oargs = (("navppo_mlp64_bf16x3", (self._prepared(obs),)) if self.bf16x3 else (self.fused, self._obs_args(obs)))
+        name, oargs = (("navppo_mlp64_bf16x3", (self._prepared(obs), self.obs_dim)) if self.bf16x3 else (self.fused, self._obs_args(obs)))
         rc = getattr(L, name + "_update_epoch")(ptr(self.fp.flat), *oargs, ptr(acts), ptr(logp_old), ptr(rtg), ptr(adv),
                                                       int(obs.shape[0]), float(var), float(self.cfg.clip), float(self.cfg.lr), 0.9,
                                                       0.999, 1e-8, int(self._adam_t), ptr(self._adam_m), ptr(self._adam_v),

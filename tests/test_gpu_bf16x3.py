@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _batch(n, seed, dev, half=False):
+def _batch(n, seed, dev, half=False, d=16):
     g = torch.Generator().manual_seed(seed)
-    obs = torch.rand((n, 16), generator=g)
+    obs = torch.rand((n, d), generator=g)
     acts = torch.stack([torch.rand(n, generator=g), torch.rand(n, generator=g) * 2 - 1], 1)
     acts[torch.rand(n, generator=g) < 0.2, 0] = 0.0
     acts[torch.rand(n, generator=g) < 0.1, 1] = 1.0
@@ -33,9 +33,9 @@ def _batch(n, seed, dev, half=False):
     return [t.to(dev).contiguous() for t in (obs, acts, logp, rtg, adv)]
 
 
-def _nets(dev, scale=3.0, seed=3):
+def _nets(dev, scale=3.0, seed=3, d=16):
     torch.manual_seed(seed)
-    a, c = nets.make_policy("mlp64x2")
+    a, c = nets.make_policy("mlp64x2", d)
     a.to(dev), c.to(dev)
     with torch.no_grad():
         for p in list(a.parameters()) + list(c.parameters()):
@@ -52,10 +52,10 @@ def _grad(a, c, arith, batch, dev):
     return up, up.fp.grad.clone(), up._fstats.clone()
 
 
-def _errors_vs_float64(n, half, seed, dev):
+def _errors_vs_float64(n, half, seed, dev, d=16):
     """Per parameter tensor: rms and max error of both arithmetics against float64 autograd, / the tensor's max |gradient|."""
-    a, c = _nets(dev, seed=3 + seed)
-    batch = _batch(n, 100 + n + seed, dev, half)
+    a, c = _nets(dev, seed=3 + seed, d=d)
+    batch = _batch(n, 100 + n + seed, dev, half, d)
     obs, acts, logp, rtg, adv = batch
     a64, c64 = copy.deepcopy(a).double(), copy.deepcopy(c).double()
     al, cl, _, _, _ = ppo.ppo_losses(a64, c64, obs.double(), acts.double(), logp.double(), rtg.double(), adv.double(),
@@ -73,8 +73,9 @@ def _errors_vs_float64(n, half, seed, dev):
     return out
 
 
-@pytest.mark.parametrize("n", [128 * 300 + 7, 1 << 17, 512 * 4096])   # the last one is the bench's own batch
-def test_bf16x3_error_is_not_above_the_f32_paths_error_against_float64(n):
+@pytest.mark.parametrize("n,d", [(128 * 300 + 7, 16), (1 << 17, 16), (512 * 4096, 16),   # the last one is the bench's own batch
+                                 (128 * 300 + 7, 42), (512 * 4096, 42)])              # 42-column rows: configs[3]'s shard
+def test_bf16x3_error_is_not_above_the_f32_paths_error_against_float64(n, d):
     """Gradients of both arithmetics against float64 autograd of the same losses (ppo.py:307-349,386) on the same rows -- float32
     and float16 rows, three seeds -- per parameter tensor, as a fraction of the tensor's gradient scale.
 
@@ -94,7 +95,7 @@ def test_bf16x3_error_is_not_above_the_f32_paths_error_against_float64(n):
     r32, rx3 = [], []
     for half in (False, True):
         for seed in range(3):
-            out = _errors_vs_float64(n, half, seed, dev)
+            out = _errors_vs_float64(n, half, seed, dev, d)
             r32.append(out["f32"][1])
             rx3.append(out["bf16x3"][1])
             assert out["bf16x3"][0].max() <= 2e-4 or out["bf16x3"][0].max() <= 1.5 * out["f32"][0].max(), (out["bf16x3"][0], out["f32"][0])
@@ -102,19 +103,21 @@ def test_bf16x3_error_is_not_above_the_f32_paths_error_against_float64(n):
     r32, rx3 = np.stack(r32), np.stack(rx3)   # [6 cases, 14 tensors]; tensors 8 .. 13 are the critic's
     m32, mx3 = float(np.median(r32)), float(np.median(rx3))
     c32, cx3 = float(np.median(r32[:, 8:])), float(np.median(rx3[:, 8:]))
-    print(f"n = {n}: median rms error / tensor scale, f32-MFMA path vs bf16x3: critic tensors {c32:.2e} vs {cx3:.2e}, all tensors {m32:.2e} vs {mx3:.2e}")
+    print(f"n = {n}, {d} columns: median rms error / tensor scale, f32-MFMA path vs bf16x3: critic tensors {c32:.2e} vs {cx3:.2e}, all tensors {m32:.2e} vs {mx3:.2e}")
     assert cx3 <= 1.2 * c32 + 1e-9, (cx3, c32)
     assert mx3 <= 1.75 * m32 + 1e-9 and mx3 <= 1.5e-7, (mx3, m32)
 
 
 @pytest.mark.parametrize("arith", ["f32", "bf16x3"])
-@pytest.mark.parametrize("n", [128, 1000, 128 * 300 + 7, 1 << 17])
-def test_gradients_match_autograd_on_both_arithmetics(n, arith):
+@pytest.mark.parametrize("n,d", [(128, 16), (1000, 16), (128 * 300 + 7, 16), (1 << 17, 16), (1, 42), (31, 42), (1000, 42), (128 * 300 + 7, 42)])
+def test_gradients_match_autograd_on_both_arithmetics(n, d, arith):
     """test_fused_mlp64_gradients_match_autograd (float32 autograd, 2e-4 of each tensor's scale) with the arithmetic pinned."""
     dev = torch.device("cuda")
-    a, c = _nets(dev)
-    batch = _batch(n, n, dev)
+    a, c = _nets(dev, d=d)
+    batch = _batch(n, n, dev, d=d)
     obs, acts, logp, rtg, adv = batch
+    from _kinks import replace_kink_samples
+    replace_kink_samples(a, c, obs, acts, logp, rtg, adv, 0.5)   # (tests/_kinks.py: the bound below is about arithmetic)
     up, g, st = _grad(a, c, arith, batch, dev)
     a2, c2 = copy.deepcopy(a), copy.deepcopy(c)
     al, cl, ratios, lp, _ = ppo.ppo_losses(a2, c2, obs, acts, logp, rtg, adv, torch.tensor(0.5, device=dev), 0.2)
@@ -134,16 +137,17 @@ def test_gradients_match_autograd_on_both_arithmetics(n, arith):
     assert torch.equal(up.fp.grad, g)
 
 
+@pytest.mark.parametrize("d", [16, 42])
 @pytest.mark.parametrize("arith", ["f32", "bf16x3"])
-def test_update_tracks_pytorch_on_both_arithmetics(arith):
+def test_update_tracks_pytorch_on_both_arithmetics(arith, d):
     """test_fused_update_tracks_pytorch_update_over_epochs (10 Adam epochs against PyTorch autograd + torch.optim.Adam) with the
     arithmetic pinned.  (G7, the reference's own learn() golden, is a 512-wide-net fixture: test_gpu_resmlp512.py.)"""
     dev = torch.device("cuda")
-    obs, acts, logp, rtg, adv = _batch(1 << 15, 5, dev)
+    obs, acts, logp, rtg, adv = _batch(1 << 15, 5, dev, d=d)
     res = []
     for fused in (True, False):
         torch.manual_seed(11)
-        a, c = nets.make_policy("mlp64x2")
+        a, c = nets.make_policy("mlp64x2", d)
         a.to(dev), c.to(dev)
         up = ppo.PPOUpdater(a, c, ppo.PPOConfig(policy="mlp64x2", n_updates_per_iteration=10, fused_update=fused, update_arith=arith), None, dev)
         st = up.update(obs, acts, logp, rtg, torch.tensor(0.8, device=dev))

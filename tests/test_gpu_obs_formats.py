@@ -51,6 +51,9 @@ def test_fused_gradients_match_autograd_on_wide_and_half_rows(n, d, half):
     a, c, up = _updater(d, dev, scale=3.0 if d == 16 else 2.0)
     obs, acts, logp, rtg, adv = _batch(n, n + d, dev, d, half)
     var = torch.tensor(0.5, device=dev)
+    from _kinks import replace_kink_samples
+    n_kink = replace_kink_samples(a, c, obs, acts, logp, rtg, adv, 0.5)   # (tests/_kinks.py: the bounds below are about arithmetic)
+    assert n_kink <= 2 + n // 100
     up.fp.grad.zero_()
     al, cl, ratios, lp, _ = ppo.ppo_losses(a, c, obs.float(), acts, logp, rtg, adv, var, 0.2)
     (al + cl).backward()
