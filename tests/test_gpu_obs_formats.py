@@ -441,3 +441,30 @@ def test_two_rank_update_on_row_formats_equals_single_rank(tmp_path, d, half, ov
     up.update(obs.cuda(), acts.cuda(), logp.cuda(), rtg.cuda(), torch.tensor(0.8, device="cuda"))
     assert (up.fp.flat - before).abs().max().item() > 1e-3   # five Adam steps moved the parameters
     np.testing.assert_allclose(r0["flat"].numpy(), up.fp.flat.cpu().numpy(), rtol=0, atol=5e-6)
+
+
+def test_split_pass_entry_points_refuse_other_widths():
+    """navppo_mlp64_bf16x3_* exist for the reference's two observation widths (16, 42): any other width, a missing buffer or a
+    misaligned one is an error code with a message, never a launch (include/navppo.h)."""
+    from navbot_ppo_amd._native import lib
+    L = lib()
+    dev = torch.device("cuda")
+    assert L.navppo_mlp64_bf16x3_prep_bytes(64, 16) == 2 * 6144 and L.navppo_mlp64_bf16x3_prep_bytes(65, 42) == 3 * 18432
+    assert L.navppo_mlp64_bf16x3_prep_bytes(64, 20) == 0 and L.navppo_mlp64_bf16x3_prep_bytes(0, 16) == 0
+    obs = torch.zeros((64, 42), device=dev)
+    prep = torch.zeros(L.navppo_mlp64_bf16x3_prep_bytes(64, 42) + 16, dtype=torch.uint8, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.navppo_mlp64_bf16x3_prepare(p(obs), 42, 0, 64, p(prep), st) == 0
+    assert L.navppo_mlp64_bf16x3_prepare(p(obs), 20, 0, 64, p(prep), st) == -1 and b"obs_dim" in L.navppo_last_error()
+    assert L.navppo_mlp64_bf16x3_prepare(p(obs), 42, 0, 64, C.c_void_p(prep.data_ptr() + 8), st) == -1   # prep not 16-byte aligned
+    assert L.navppo_mlp64_bf16x3_prepare(p(obs), 42, 0, 0, p(prep), st) == -1
+    a, c, up = _updater(42, dev)
+    acts, lp, rtg, adv = torch.zeros((64, 2), device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    ws = up._workspace(64)
+    stats = torch.zeros(8, device=dev)
+    args = lambda d: (p(up.fp.flat), p(prep), d, p(acts), p(lp), p(rtg), p(adv), 64, 0.5, 0.2, p(up.fp.grad), p(stats), p(ws), st)
+    assert L.navppo_mlp64_bf16x3_loss_grad(*args(42)) == 0
+    assert L.navppo_mlp64_bf16x3_loss_grad(*args(17)) == -1 and b"obs_dim" in L.navppo_last_error()
+    assert L.navppo_mlp64_bf16x3_loss_grad_net(2, *args(42)) == -1
+    torch.cuda.synchronize()
