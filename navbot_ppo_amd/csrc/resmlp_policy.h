@@ -42,8 +42,8 @@ struct Weights {
     f32x4 w1a[4], b1a[4], w2a[4], w1b[4][2], b1b[4], w2b[2][4];
 };
 // requested in the order the step consumes them (block 1 first: its MFMAs start while block 2's weights are still in flight).  The
-// persistent rollout kernel calls this AHEAD of the policy step, inside the env step in front of it, so that the L2 round trip
-// (197 KB per workgroup and step) is hidden behind the step's tail; addresses do not depend on anything computed.
+// per-step kernel (resmlp_act) streams both blocks from L2; the persistent rollout kernel keeps block 1 in LDS (Block1Smem below)
+// and streams block 2 only (navsim.hip: rollout_resmlp_kernel has the measurements).
 __device__ __forceinline__ void load_weights_a(const float* __restrict__ pa, const int lane, const int w, Weights& W) {   // block 1
     const int l15 = lane & 15, q = lane >> 4;
     const int j0 = 64 * w;
