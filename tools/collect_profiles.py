@@ -11,7 +11,7 @@ for a in ("run_id.txt", "hbm_legs_hip_events.txt", "rollout_shard_sizes.txt", "u
           # round 5: the update passes of both arithmetics / of the 42-column rows, the split pass's error table and microbenchmarks, the PPO shards
           "update_arith_hip_events.txt", "update_wide_hip_events.txt", "bf16x3_error.txt", "bf16_mfma_valu_overlap.txt",
           "bf16_mfma_fillers.txt", "bf16_split_ops.txt", "ppo_cfg4.json", "ppo_cfg5.json", "selected_instantiations.txt",
-          "house_rollout_shapes.txt", "soak_parity.txt", "rollout_resmlp_times.txt", "rollout_resmlp_phases.txt"):
+          "house_rollout_shapes.txt", "soak_parity.txt", "soak_parity_seed1.txt", "soak_parity_seed2.txt", "rollout_resmlp_times.txt", "rollout_resmlp_phases.txt"):
     if os.path.exists(os.path.join(O, a)):
         shutil.copy(os.path.join(O, a), os.path.join(P, f"{RND}_{a}"))
 shutil.copy(os.path.join(O, "pmc_traffic.json"), os.path.join(P, "pmc_traffic.json"))
