@@ -33,8 +33,12 @@
 // (4 KB per sample and net).  MFMA work per sample and net: 2 x 155,648 MAC = 311 kFLOP -> 1.31 TFLOP per epoch at
 // BASELINE configs[1] = 8.3 ms at the 157.3 TF f32-MFMA peak.
 //
-// All GEMMs are v_mfma_f32_16x16x4_f32 (exact k-ordered f32 fma chains; same rate as 32x32x2, and the 16-row output blocks
-// of rb1 waste nothing).  Layout ("16-layout"): a [rows, 32 samples] activation lives as f32x4 v[rows / 16][2]: lane
+// The GEMMs are v_mfma_f32_16x16x4_f32 (exact k-ordered f32 fma chains; same rate as 32x32x2, and the 16-row output blocks
+// of rb1 waste nothing) -- except, since round 5, the H products of the two FORWARD kernels, which run as float32 products from
+// three-piece bf16 splits on v_mfma_f32_16x16x32_bf16 (hidden_chunk_x3: both operands of that product are narrow -- weights and
+// the 16 / 32 inputs of a sample -- so nothing has to be split per hidden value; resmlp_fwd<32> 1781 -> 1340 us, resmlp_fwd<16>
+// 870 -> 820 us per epoch).  The same move on dH^T = dY^T W2 in resmlp_bwd<32> was measured and is not in: that kernel has no
+// registers for the pieces (66 -> 125 spilled, 4999 vs 4988-5132 us).  Layout ("16-layout"): a [rows, 32 samples] activation lives as f32x4 v[rows / 16][2]: lane
 // (n = lane & 15, q = lane >> 4) holds rows 16 b + 4 q + r (r = 0..3) of sample 16 st + n -- which is both the C/D layout of
 // the MFMA and, register r taken as the B operand of step r, a legal k-pairing when the A operand (weights) is read
 // k-permuted: lane (m, q) fetches columns 16 b + 4 q .. + 3 of its row with ONE ds_read_b128.  Products that contract over
@@ -55,6 +59,7 @@
 #include "mlp64_policy.h"   // Philox / Box-Muller noise of the rollout policy step (same stream as the mlp64x2 path)
 #include "navppo.h"
 #include "navppo_internal.h"
+#include "bf16x3.h"          // float32 values as three bf16 pieces (the H product of rb2 below)
 #include "resmlp_policy.h"   // the rollout-time policy step + the parameter layout (shared with the persistent rollout kernel)
 
 namespace {
@@ -122,45 +127,54 @@ __device__ __forceinline__ void load_x(f32x4 (&X)[IN / 16][2], const float* __re
     }
 }
 
-// H = W1[chunk] X + b1[chunk] (LEAKY: leaky of it): 32 hidden units x 32 samples, as [2 j-blocks][2 sample tiles]
-template <int IN, bool LEAKY = true>
-__device__ __forceinline__ void hidden_chunk(const float* W1s, const float* b1s, int c, const f32x4 (&X)[IN / 16][2],
-                                             f32x4 (&H)[2][2], int l15, int q) {
-    constexpr int S1 = IN + 4;
+// H = leaky(W1[chunk] X + b1[chunk]): 32 hidden units x 32 samples, as [2 j-blocks][2 sample tiles].  (Rounds 3-4 ran it as
+// v_mfma_f32_16x16x4_f32 chains -- four independent accumulators back to back, the element-wise block in one piece behind them because
+// f32 MFMA and vector work share the SIMD's FMA lanes; the backward kernels still form their H^T that way.)
+// Since round 5: on the bf16 MFMA from three-piece splits ("bf16x3": csrc/bf16x3.h): K = 32 (rb2) is one k-step of
+// v_mfma_f32_16x16x32_bf16, K = 16 (rb1) half of one.  BOTH operands are narrow here -- weights, split once per launch, and the 32 input values of a
+// sample, split once per tile -- so the product runs at the bf16 rate with no per-hidden-value split: 6 MFMAs of 16 cycles per
+// 16 x 16 tile against 8 f32 MFMAs of 32.  Lane (n, q) of the B operand holds ITS OWN eight registers X[0][st][0..3], X[1][st][0..3]
+// (features 4 q + r and 16 + 4 q + r) as the eight k-slots of k-group q; the weight pieces are stored in that order.  Small terms
+// first, the a0 b0 term last, the bias on the vector unit behind it (the order of the update kernels of the 64-wide heads).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma16bf(const uint4 a, const uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf16x3::as_bf(a), bf16x3::as_bf(b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void hidden_chunk_x3(const uint4* W1p /* [3][HS][4] */, const float* b1s, int c, const bf16x3::Pieces (&XP)[2],
+                                                f32x4 (&H)[2][2], int l15, int q) {
+    bf16x3::Pieces A[2];
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) H[jb][0] = H[jb][1] = v4(ld4(b1s + c * 32 + 16 * jb + 4 * q));
+    for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-    for (int b = 0; b < IN / 16; ++b) {
-        const f32x4 a0 = v4(ld4(W1s + (c * 32 + l15) * S1 + 16 * b + 4 * q));
-        const f32x4 a1 = v4(ld4(W1s + (c * 32 + 16 + l15) * S1 + 16 * b + 4 * q));
+        for (int i = 0; i < 3; ++i) A[jb].p[i] = W1p[(i * HS + c * 32 + 16 * jb + l15) * 4 + q];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {   // four independent accumulators back to back (dependent latency 40 > issue 32 cycles)
-            H[0][0] = mfma16(a0[r], X[b][0][r], H[0][0]);
-            H[0][1] = mfma16(a0[r], X[b][1][r], H[0][1]);
-            H[1][0] = mfma16(a1[r], X[b][0][r], H[1][0]);
-            H[1][1] = mfma16(a1[r], X[b][1][r], H[1][1]);
-        }
+    for (int jb = 0; jb < 2; ++jb) H[jb][0] = H[jb][1] = zero4();
+    // four independent accumulators take turns
+#define RESMLP_X3_TERM(ia, ib)                                        \
+    H[0][0] = mfma16bf(A[0].p[ia], XP[0].p[ib], H[0][0]);             \
+    H[0][1] = mfma16bf(A[0].p[ia], XP[1].p[ib], H[0][1]);             \
+    H[1][0] = mfma16bf(A[1].p[ia], XP[0].p[ib], H[1][0]);             \
+    H[1][1] = mfma16bf(A[1].p[ia], XP[1].p[ib], H[1][1]);
+    RESMLP_X3_TERM(2, 0) RESMLP_X3_TERM(1, 1) RESMLP_X3_TERM(0, 2) RESMLP_X3_TERM(1, 0) RESMLP_X3_TERM(0, 1) RESMLP_X3_TERM(0, 0)
+#undef RESMLP_X3_TERM
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        const f32x4 b = v4(ld4(b1s + c * 32 + 16 * jb + 4 * q));
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H[jb][st][r] = leaky(H[jb][st][r] + b[r]);
     }
-    if (LEAKY) {
-        // f32 MFMA and VALU work share the SIMD's FMA lanes (times add, tools/ubench/mfma_valu_overlap.hip) and every switch
-        // between the two costs issue slots: keep the element-wise block in one piece instead of sprinkled between MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) H[jb][st][r] = leaky(H[jb][st][r]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---------------------------------------------------------------- forward partial of one residual block
 template <int IN>
 struct FwdSmem {
-    float W1s[HS * (IN + 4)];    // [hidden j][input i]
     float W2s[IN * (HS + 4)];    // [output o][hidden j]
     float b1s[HS];
+    uint4 W1p[3 * HS * 4];       // [piece][hidden j][k-group q] = eight bf16: W1[j][4 q + r], then W1[j][16 + 4 q + r] (rb1: zeros)
 };
 
 // pout[net][slice][n][IN] = W2[:, slice] leaky(W1[slice] X + b1[slice])
@@ -173,11 +187,19 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
                                                        float* __restrict__ h1buf, long long n, int groups,
                                                        float* __restrict__ pout) {
     __shared__ __attribute__((aligned(16))) FwdSmem<IN> sm;
-    constexpr int S1 = IN + 4, S2 = HS + 4, NB = IN / 16;
+    constexpr int S2 = HS + 4, NB = IN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, q = lane >> 4;
     const WG wg = decode_block(blockIdx.x, n_nets, groups);
     const float* __restrict__ pn = params + ((net_base + wg.net_i) ? rp::P_ACTOR : 0);
-    for (int k = tid; k < HS * IN; k += kThreads) sm.W1s[(k / IN) * S1 + (k % IN)] = pn[Blk<IN>::W1 + (wg.sl * HS + k / IN) * IN + (k % IN)];
+    for (int k = tid; k < HS * 4; k += kThreads) {
+        const int j = k >> 2, kq = k & 3;
+        const float* wr = pn + Blk<IN>::W1 + (wg.sl * HS + j) * IN;
+        const float4 lo = ld4(wr + 4 * kq), hi = (IN == 32) ? ld4(wr + (IN == 32 ? 16 : 0) + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const bf16x3::Pieces P = bf16x3::split8(v);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sm.W1p[(i * HS + j) * 4 + kq] = P.p[i];
+    }
     for (int k = tid; k < IN * HS; k += kThreads) sm.W2s[(k / HS) * S2 + (k % HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
     if (tid < HS) sm.b1s[tid] = pn[Blk<IN>::B1 + wg.sl * HS + tid];
     __syncthreads();
@@ -223,10 +245,23 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
         f32x4 Y[NB][2];
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) Y[ob][0] = Y[ob][1] = zero4();
+        bf16x3::Pieces XP[2];   // the tile's input rows as the B operand of the H product, split once per tile (rb1: k-slots 4 .. 7 empty)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if constexpr (IN == 32) {
+                const float v[8] = {X[0][st][0], X[0][st][1], X[0][st][2], X[0][st][3], X[NB - 1][st][0], X[NB - 1][st][1], X[NB - 1][st][2], X[NB - 1][st][3]};
+                XP[st] = bf16x3::split8(v);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) XP[st].p[i] = make_uint4(0u, 0u, 0u, 0u);
+                bf16x3::split_pair(X[0][st][0], X[0][st][1], XP[st].p[0].x, XP[st].p[1].x, XP[st].p[2].x);
+                bf16x3::split_pair(X[0][st][2], X[0][st][3], XP[st].p[0].y, XP[st].p[1].y, XP[st].p[2].y);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             f32x4 H[2][2];
-            hidden_chunk<IN>(sm.W1s, sm.b1s, c, X, H, l15, q);
+            hidden_chunk_x3(sm.W1p, sm.b1s, c, XP, H, l15, q);
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
                 f32x4 a[NB];
