@@ -37,8 +37,9 @@
 // of rb1 waste nothing) -- except, since round 5, the H products of the two FORWARD kernels, which run as float32 products from
 // three-piece bf16 splits on v_mfma_f32_16x16x32_bf16 (hidden_chunk_x3: both operands of that product are narrow -- weights and
 // the 16 / 32 inputs of a sample -- so nothing has to be split per hidden value; resmlp_fwd<32> 1781 -> 1340 us, resmlp_fwd<16>
-// 870 -> 820 us per epoch).  The same move on dH^T = dY^T W2 in resmlp_bwd<32> was measured and is not in: that kernel has no
-// registers for the pieces (66 -> 125 spilled, 4999 vs 4988-5132 us).  Layout ("16-layout"): a [rows, 32 samples] activation lives as f32x4 v[rows / 16][2]: lane
+// 870 -> 820 us per epoch) and the H^T / dH^T products of resmlp_bwd<32>, which for that runs 4 waves x 512 registers (at 8 waves the
+// pieces cost 66 -> 125 spilled registers and the gain: 4999 vs 4988-5132 us; on 4 waves 4607 us).  resmlp_bwd<16> (K = 16 fills
+// half a k-step, 256 registers in use) stays on the f32 MFMA: 2208 vs 2269-2308 us measured, not worth a second code path.  Layout ("16-layout"): a [rows, 32 samples] activation lives as f32x4 v[rows / 16][2]: lane
 // (n = lane & 15, q = lane >> 4) holds rows 16 b + 4 q + r (r = 0..3) of sample 16 st + n -- which is both the C/D layout of
 // the MFMA and, register r taken as the B operand of step r, a legal k-pairing when the A operand (weights) is read
 // k-permuted: lane (m, q) fetches columns 16 b + 4 q .. + 3 of its row with ONE ds_read_b128.  Products that contract over
@@ -77,6 +78,10 @@ constexpr int NSL = 4;               // hidden slices
 constexpr int HS = rp::HID / NSL;    // 128 hidden units per slice
 constexpr int NCH = HS / 32;         // chunks of 32 hidden units per slice
 constexpr int kWaves = 8, kThreads = 64 * kWaves;
+#ifndef RESMLP_BWD2_WAVES
+#define RESMLP_BWD2_WAVES 4
+#endif
+constexpr int kBwd2Waves = RESMLP_BWD2_WAVES;   // waves per workgroup of resmlp_bwd<32> (4: with its narrow products on the bf16 MFMA)
 constexpr int LT = 36;               // row pitch of the wave tiles (floats): 16-byte rows, conflict-free ds_read_b128
 constexpr int kMaxWG = 256;          // one persistent workgroup per CU
 constexpr int kWRows = kMaxWG / NSL * kWaves;   // partial-gradient rows: 2 nets x 32 groups x 8 waves
@@ -297,14 +302,16 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
 // dY^T / X^T (lane = output / input unit, registers = samples) come from two wave-private LDS tiles written once per tile.
 // Only rb2's input gradient Q = W1[:, 16:32]^T dH contracts over hidden units again: dH makes one trip through an LDS tile
 // (ds_write_b128 rows, conflict-free ds_read_b32 columns).
-template <int IN>
+template <int IN, int NWV>
 struct BwdSmem {
-    float W1s[HS * (IN + 4)];     // [hidden j][input i]
-    float W2Ts[HS * (IN + 4)];    // [hidden j][output o]
+    static constexpr bool X3 = (IN == 32 && NWV == 4);   // rb2 on 4 waves: H^T and dH^T as bf16x3 products (below)
+    float W1s[HS * (IN + 4)];     // [hidden j][input i]   (X3: still the source of Q's A operand)
+    float W2Ts[X3 ? 4 : HS * (IN + 4)];    // [hidden j][output o]
     float b1s[HS];
-    float tiles[kWaves * (2 * IN + (IN == 32 ? 32 : 0)) * LT];   // per wave: TX [IN][32] | TDY [IN][32] | TH [32][32] (rb2)
+    uint4 W1p[X3 ? 3 * HS * 4 : 1], W2Tp[X3 ? 3 * HS * 4 : 1];   // X3: [piece][hidden j][k-group q] = eight bf16 (hidden_chunk_x3's order)
+    float tiles[NWV * (2 * IN + (IN == 32 ? 32 : 0)) * LT];   // per wave: TX [IN][32] | TDY [IN][32] | TH [32][32] (rb2)
 };
-static_assert(sizeof(BwdSmem<32>) <= 160 * 1024, "LDS");
+static_assert(sizeof(BwdSmem<32, 8>) <= 160 * 1024 && sizeof(BwdSmem<32, 4>) <= 160 * 1024, "LDS");
 
 // dypre [net][n][32] = dL / d(pre-activation of h2) (the streaming kernel E2 writes it).  rb2 (IN == 32) uses it as is and
 // writes qout[net][slice][n][16] = W1[slice][:, 16:32]^T dH; rb1 (IN == 16) forms ITS output gradient on the way in,
@@ -316,13 +323,19 @@ static_assert(sizeof(BwdSmem<32>) <= 160 * 1024, "LDS");
 // to a whole 32 x 32 chunk of H / dH (NST = 2), mostly outside the tile loop (27 scratch accesses per tile); measured
 // alternatives, all slower: half chunks (NST = 1: no fewer spills, twice the weight reads, 5.54 vs 5.10 ms), 4 waves x 512
 // registers with two tiles in flight (no spills, but ~270 AGPR <-> VGPR moves per tile: 5.53 ms).
-template <int IN, int NST>
-__global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__ params, int n_nets, const float* __restrict__ obs,
+// NWV = waves per workgroup.  rb2 runs 4 (one per SIMD, 512 registers each): its two products with narrow operands -- H^T = X W1^T and
+// dH^T = dY^T W2, K = 32 -- then fit as float32 products from three-piece bf16 splits (hidden_chunk_x3's scheme with the operands
+// swapped: A = the lane's own eight X / dY registers split once per tile, B = the weight pieces), which the 8-wave build has no
+// registers for (66 -> 125 spilled).
+template <int IN, int NST, int NWV>
+__global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__ params, int n_nets, const float* __restrict__ obs,
                                                        const float* __restrict__ h1buf, const float* __restrict__ dypre,
                                                        long long n, int groups, float* __restrict__ wpart,
                                                        float* __restrict__ qout, const float* __restrict__ qin) {
-    __shared__ __attribute__((aligned(16))) BwdSmem<IN> sm;
+    __shared__ __attribute__((aligned(16))) BwdSmem<IN, NWV> sm;
     constexpr int S1 = IN + 4, NB = IN / 16;
+    constexpr int kWaves = NWV, kThreads = 64 * NWV;   // (shadow the 8-wave constants of the file)
+    constexpr bool X3 = BwdSmem<IN, NWV>::X3;
     constexpr bool NEED_DX = IN == 32;
     constexpr bool PREFETCH = IN == 16;   // rb2 has no registers to spare for the next tile's rows
     constexpr int TILE_F = (2 * IN + (IN == 32 ? 32 : 0)) * LT;
@@ -330,7 +343,26 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
     const WG wg = decode_block(blockIdx.x, n_nets, groups);
     const float* __restrict__ pn = params + (wg.net_i ? rp::P_ACTOR : 0);
     for (int k = tid; k < HS * IN; k += kThreads) sm.W1s[(k / IN) * S1 + (k % IN)] = pn[Blk<IN>::W1 + (wg.sl * HS + k / IN) * IN + (k % IN)];
-    for (int k = tid; k < IN * HS; k += kThreads) sm.W2Ts[(k % HS) * S1 + (k / HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
+    if constexpr (X3) {
+        for (int k = tid; k < HS * 4; k += kThreads) {
+            const int j = k >> 2, kq = k & 3;
+            const float* wr = pn + Blk<IN>::W1 + (wg.sl * HS + j) * IN;
+            const float4 lo = ld4(wr + 4 * kq), hi = ld4(wr + 16 + 4 * kq);
+            const float* wc = pn + Blk<IN>::W2 + wg.sl * HS + j;
+            const float v1[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            float v2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v2[e] = wc[(size_t)((e < 4 ? 0 : 16) + 4 * kq + (e & 3)) * rp::HID];
+            const bf16x3::Pieces P1 = bf16x3::split8(v1), P2 = bf16x3::split8(v2);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sm.W1p[(i * HS + j) * 4 + kq] = P1.p[i];
+                sm.W2Tp[(i * HS + j) * 4 + kq] = P2.p[i];
+            }
+        }
+    } else {
+        for (int k = tid; k < IN * HS; k += kThreads) sm.W2Ts[(k % HS) * S1 + (k / HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
+    }
     if (tid < HS) sm.b1s[tid] = pn[Blk<IN>::B1 + wg.sl * HS + tid];
     __syncthreads();
     float* const TX = sm.tiles + wave * TILE_F;
@@ -412,6 +444,17 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
                     TDY[wr + (16 * b + r) * LT + 16 * st] = DY[b][st][r];
                 }
         f32x4 dXa[2] = {zero4(), zero4()};
+        bf16x3::Pieces XP[2], DYP[2];   // X3: the tile's rows / output gradients as A operands, split once per tile
+        if constexpr (X3) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const float vx[8] = {X[0][st][0], X[0][st][1], X[0][st][2], X[0][st][3], X[NB - 1][st][0], X[NB - 1][st][1], X[NB - 1][st][2], X[NB - 1][st][3]};
+                const float vd[8] = {DY[0][st][0], DY[0][st][1], DY[0][st][2], DY[0][st][3], DY[NB - 1][st][0], DY[NB - 1][st][1], DY[NB - 1][st][2], DY[NB - 1][st][3]};
+                XP[st] = bf16x3::split8(vx);
+                DYP[st] = bf16x3::split8(vd);
+            }
+        }
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // bf16x3 term order: small terms first, a0 b0 last
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -422,6 +465,32 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
                 __builtin_amdgcn_sched_barrier(0);
                 // H^T (R-layout: lane = hidden unit 16 jb + l15 of the chunk, register r = sample 16 st + 4 q + r)
                 f32x4 H[2][NST], dH[2][NST];
+                if constexpr (X3) {
+                    bf16x3::Pieces Wp[2];
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) Wp[jb].p[i] = sm.W1p[(i * HS + c * 32 + 16 * jb + l15) * 4 + q];
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int k = 0; k < NST; ++k) H[jb][k] = zero4();
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int k = 0; k < NST; ++k) {
+                            H[0][k] = mfma16bf(XP[s0 + k].p[TA[t]], Wp[0].p[TB[t]], H[0][k]);
+                            H[1][k] = mfma16bf(XP[s0 + k].p[TA[t]], Wp[1].p[TB[t]], H[1][k]);
+                        }
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const float bj = sm.b1s[c * 32 + 16 * jb + l15];
+#pragma unroll
+                        for (int k = 0; k < NST; ++k)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) H[jb][k][r] += bj;
+                    }
+                } else {
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) {   // (the bias 8-fold in LDS, one ds_read_b128 per tile instead of 4 v_mov: measured no gain)
                     const float bj = sm.b1s[c * 32 + 16 * jb + l15];
@@ -440,11 +509,26 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
                             H[1][k] = mfma16(X[b][s0 + k][r], w1[r], H[1][k]);
                         }
                 }
+                }
                 // dH^T = (dY^T W2[:, chunk]) . leaky'
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
                     for (int k = 0; k < NST; ++k) dH[jb][k] = zero4();
+                if constexpr (X3) {
+                    bf16x3::Pieces Wp[2];
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) Wp[jb].p[i] = sm.W2Tp[(i * HS + c * 32 + 16 * jb + l15) * 4 + q];
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int k = 0; k < NST; ++k) {
+                            dH[0][k] = mfma16bf(DYP[s0 + k].p[TA[t]], Wp[0].p[TB[t]], dH[0][k]);
+                            dH[1][k] = mfma16bf(DYP[s0 + k].p[TA[t]], Wp[1].p[TB[t]], dH[1][k]);
+                        }
+                } else {
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob) {
                     const f32x4 w0 = v4(ld4(sm.W2Ts + (c * 32 + l15) * S1 + 16 * ob + 4 * q));
@@ -456,6 +540,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_bwd(const float* __restrict__
                             dH[0][k] = mfma16(DY[ob][s0 + k][r], w0[r], dH[0][k]);
                             dH[1][k] = mfma16(DY[ob][s0 + k][r], w1[r], dH[1][k]);
                         }
+                }
                 }
                 if (PREFETCH && c == NCH - 1 && s0 + NST == 2) request(raw, tile + stride);   // X / DY are dead: the next tile streams in
                 float db[2] = {0.f, 0.f};
@@ -865,19 +950,19 @@ int loss_grad_impl(const char* name, bool adam, float* params, const float* obs,
     launch_forward(p, params, 0, 2, obs, n, st);
     hipLaunchKernelGGL(resmlp_e2<false>, dim3(p.e_blocks, 2), dim3(kEThreads), 0, st, (const float*)params, 0, obs, (const float*)p.h1,
                        (const float*)p.p2, act, logp_old, rtg, adv, (long long)n, var, clip, inv_n, p.dy2, p.epart, (float*)nullptr);
-    hipLaunchKernelGGL((resmlp_bwd<32, 2>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
+    hipLaunchKernelGGL((resmlp_bwd<32, 2, kBwd2Waves>), dim3(p.wgs), dim3(64 * kBwd2Waves), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
                        (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb, (const float*)nullptr);
-    hipLaunchKernelGGL((resmlp_bwd<16, 2>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
+    hipLaunchKernelGGL((resmlp_bwd<16, 2, kWaves>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
                        (const float*)p.dy2, (long long)n, p.groups, p.wpart, (float*)nullptr, (const float*)p.qb);
     const int rblocks = (rp::P_ACTOR + rp::P_CRITIC + 63) / 64;
     if (adam) {
         const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
         const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
         hipLaunchKernelGGL(resmlp_reduce<true>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kWaves,
-                           p.groups * kWaves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, params, adam_m, adam_v, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+                           p.groups * kBwd2Waves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, params, adam_m, adam_v, lr, beta1, beta2, eps, bc1, bc2_sqrt);
     } else {
         hipLaunchKernelGGL(resmlp_reduce<false>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kWaves,
-                           p.groups * kWaves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f,
+                           p.groups * kBwd2Waves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f,
                            0.f, 0.f, 0.f, 1.f, 1.f);
     }
     return launch_ok(name) ? 0 : -2;
