@@ -455,6 +455,22 @@ __global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__
             }
         }
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // bf16x3 term order: small terms first, a0 b0 last
+        // X3: the weight-gradient products contract over the tile's 32 samples = ONE k-step of v_mfma_f32_16x16x32_bf16.  Their narrow
+        // partners -- dY^T (A of dW2) and X^T (B of dW1), lane = unit, k-group q = samples 4 q + r and 16 + 4 q + r -- are split once
+        // per tile; H^T / dH^T (the other operands) are split per chunk from the registers they are in, in the same k-slot order.
+        bf16x3::Pieces DYTP[NB], XTP[NB];
+        if constexpr (X3) {
+            wave_lds_fence();
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float4 d0 = ld4(TDY + rr + 16 * b * LT), d1 = ld4(TDY + rr + 16 * b * LT + 16);
+                const float4 x0 = ld4(TX + rr + 16 * b * LT), x1 = ld4(TX + rr + 16 * b * LT + 16);
+                const float vd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                const float vx[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                DYTP[b] = bf16x3::split8(vd);
+                XTP[b] = bf16x3::split8(vx);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -569,6 +585,32 @@ __global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__
                                 make_float4(dH[jb][k][0], dH[jb][k][1], dH[jb][k][2], dH[jb][k][3]);
                     wave_lds_fence();
                 }
+                if constexpr (X3 && NST == 2) {
+                    // dW2 / dW1 on the bf16 MFMA: the chunk's H^T and dH^T registers (samples 4 q + r of both sample tiles = the eight
+                    // k-slots of k-group q) split here, four 16 x 16 outputs each, six piece products per output
+                    bf16x3::Pieces HP[2], DHP[2];
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const float vh[8] = {H[jb][0][0], H[jb][0][1], H[jb][0][2], H[jb][0][3], H[jb][1][0], H[jb][1][1], H[jb][1][2], H[jb][1][3]};
+                        const float vg[8] = {dH[jb][0][0], dH[jb][0][1], dH[jb][0][2], dH[jb][0][3], dH[jb][1][0], dH[jb][1][1], dH[jb][1][2], dH[jb][1][3]};
+                        HP[jb] = bf16x3::split8(vh);
+                        DHP[jb] = bf16x3::split8(vg);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int ob = 0; ob < NB; ++ob) {
+                            aW2[c][ob][0] = mfma16bf(DYTP[ob].p[TA[t]], HP[0].p[TB[t]], aW2[c][ob][0]);
+                            aW2[c][ob][1] = mfma16bf(DYTP[ob].p[TA[t]], HP[1].p[TB[t]], aW2[c][ob][1]);
+                        }
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int ib = 0; ib < NB; ++ib) {
+                            aW1[c][0][ib] = mfma16bf(DHP[0].p[TA[t]], XTP[ib].p[TB[t]], aW1[c][0][ib]);
+                            aW1[c][1][ib] = mfma16bf(DHP[1].p[TA[t]], XTP[ib].p[TB[t]], aW1[c][1][ib]);
+                        }
+                } else {
                 // dW2[o][j] += sum_s dY[o][s] H[j][s]: A = dY^T from the tile, B = the H^T registers
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob)
@@ -593,6 +635,7 @@ __global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__
                             aW1[c][1][ib] = mfma16(dH[1][k][r], x[r], aW1[c][1][ib]);
                         }
                     }
+                }
                 if (NEED_DX) {   // Q[i][s] += sum_j W1[j][16 + i] dH[j][s]: A = a column of W1, B = a column of the dH tile, per step
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb)
