@@ -33,13 +33,20 @@
 // (4 KB per sample and net).  MFMA work per sample and net: 2 x 155,648 MAC = 311 kFLOP -> 1.31 TFLOP per epoch at
 // BASELINE configs[1] = 8.3 ms at the 157.3 TF f32-MFMA peak.
 //
-// The GEMMs are v_mfma_f32_16x16x4_f32 (exact k-ordered f32 fma chains; same rate as 32x32x2, and the 16-row output blocks
-// of rb1 waste nothing) -- except, since round 5, the H products of the two FORWARD kernels, which run as float32 products from
-// three-piece bf16 splits on v_mfma_f32_16x16x32_bf16 (hidden_chunk_x3: both operands of that product are narrow -- weights and
-// the 16 / 32 inputs of a sample -- so nothing has to be split per hidden value; resmlp_fwd<32> 1781 -> 1340 us, resmlp_fwd<16>
-// 870 -> 820 us per epoch) and the H^T / dH^T products of resmlp_bwd<32>, which for that runs 4 waves x 512 registers (at 8 waves the
-// pieces cost 66 -> 125 spilled registers and the gain: 4999 vs 4988-5132 us; on 4 waves 4607 us).  resmlp_bwd<16> (K = 16 fills
-// half a k-step, 256 registers in use) stays on the f32 MFMA: 2208 vs 2269-2308 us measured, not worth a second code path.  Layout ("16-layout"): a [rows, 32 samples] activation lives as f32x4 v[rows / 16][2]: lane
+// The GEMMs were all v_mfma_f32_16x16x4_f32 through round 4 (exact k-ordered f32 fma chains; same rate as 32x32x2, and the 16-row
+// output blocks of rb1 waste nothing).  Since round 5 the products that fill a whole k-step of v_mfma_f32_16x16x32_bf16 run as
+// float32 products from three-piece bf16 splits ("bf16x3": csrc/bf16x3.h; six piece products, float32 accumulate, small terms
+// first -- float32-equivalent, the same gates as before: tests/test_gpu_resmlp512.py):
+//   * narrow x narrow (weights x the 16 / 32 values a sample carries in or out; nothing to split per hidden value): H of both
+//     forward kernels (hidden_chunk_x3), H^T and dH^T of resmlp_bwd<32>;
+//   * one operand hidden, K = 32 and 32 outputs (the split of a hidden register, 27 cycles, against 2 x 32 cycles of f32 MFMA it
+//     replaces): Y = W2 leaky(H) of resmlp_fwd<32>, dW2 and dW1 of resmlp_bwd<32> (one 32-sample k-step each).
+// resmlp_bwd<32> runs 4 waves x 512 registers for that (at 8 x 256 the pieces cost 66 -> 125 spilled registers and the gain).
+// Per epoch: resmlp_fwd<32> 1781 -> 1143 us, resmlp_fwd<16> 876 -> 819, resmlp_bwd<32> 4988 -> 4304-4338; 11.18 -> 9.90 ms.  Left on
+// the f32 MFMA because the count says so or the measurement did: rb1's 16-wide products with a hidden operand (the split costs
+// more than it saves), resmlp_bwd<16> altogether (K = 16 fills half a k-step; both narrow products split: 2208 vs 2269-2308 us,
+// no room in its 256 registers), Q = W1^T dH of resmlp_bwd<32> (dH would need a second, transposed split).
+// Layout ("16-layout"): a [rows, 32 samples] activation lives as f32x4 v[rows / 16][2]: lane
 // (n = lane & 15, q = lane >> 4) holds rows 16 b + 4 q + r (r = 0..3) of sample 16 st + n -- which is both the C/D layout of
 // the MFMA and, register r taken as the B operand of step r, a legal k-pairing when the A operand (weights) is read
 // k-permuted: lane (m, q) fetches columns 16 b + 4 q .. + 3 of its row with ONE ds_read_b128.  Products that contract over
@@ -177,8 +184,11 @@ __device__ __forceinline__ void hidden_chunk_x3(const uint4* W1p /* [3][HS][4] *
 // ---------------------------------------------------------------- forward partial of one residual block
 template <int IN>
 struct FwdSmem {
-    float W2s[IN * (HS + 4)];    // [output o][hidden j]
+    float W2s[(IN == 32) ? 4 : IN * (HS + 4)];    // [output o][hidden j] (rb1; rb2 holds W2 as bf16 pieces)
     float b1s[HS];
+    // rb2: W2 as pieces in the order the Y product consumes them: [piece][chunk c][output block ob][lane (m, q)] = eight bf16
+    // W2[16 ob + m][32 c + 4 q + r], W2[16 ob + m][32 c + 16 + 4 q + r] -- the k-slots in which lane (n, q) holds its own H registers
+    uint4 W2p[(IN == 32) ? 3 * NCH * 2 * 64 : 1];
     uint4 W1p[3 * HS * 4];       // [piece][hidden j][k-group q] = eight bf16: W1[j][4 q + r], then W1[j][16 + 4 q + r] (rb1: zeros)
 };
 
@@ -205,7 +215,19 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < 3; ++i) sm.W1p[(i * HS + j) * 4 + kq] = P.p[i];
     }
-    for (int k = tid; k < IN * HS; k += kThreads) sm.W2s[(k / HS) * S2 + (k % HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
+    if constexpr (IN == 32) {
+        for (int k = tid; k < NCH * NB * 64; k += kThreads) {
+            const int ln = k & 63, ob = (k >> 6) % NB, c = k / (64 * NB), m = ln & 15, kq = ln >> 4;
+            const float* wr = pn + Blk<IN>::W2 + (size_t)(16 * ob + m) * rp::HID + wg.sl * HS + 32 * c + 4 * kq;
+            const float4 lo = ld4(wr), hi = ld4(wr + 16);
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const bf16x3::Pieces P = bf16x3::split8(v);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sm.W2p[((i * NCH + c) * NB + ob) * 64 + ln] = P.p[i];
+        }
+    } else {
+        for (int k = tid; k < IN * HS; k += kThreads) sm.W2s[(k / HS) * S2 + (k % HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
+    }
     if (tid < HS) sm.b1s[tid] = pn[Blk<IN>::B1 + wg.sl * HS + tid];
     __syncthreads();
     float* __restrict__ po = pout + (size_t)(wg.net_i * NSL + wg.sl) * n * IN;
@@ -267,6 +289,26 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
         for (int c = 0; c < NCH; ++c) {
             f32x4 H[2][2];
             hidden_chunk_x3(sm.W1p, sm.b1s, c, XP, H, l15, q);
+            if constexpr (IN == 32) {
+                // Y += W2[:, chunk] leaky(H): the chunk's 32 hidden units are ONE k-step; a lane's eight H registers per sample tile
+                // (units 4 q + r and 16 + 4 q + r) are its k-slots, split here -- 2 x 44 vector instructions against 24 MFMAs of 16
+                // cycles instead of 32 of 32 (rb1's 16 outputs would not pay for the split: it keeps the f32 chain below)
+                bf16x3::Pieces HP[2];
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const float v[8] = {H[0][st][0], H[0][st][1], H[0][st][2], H[0][st][3], H[1][st][0], H[1][st][1], H[1][st][2], H[1][st][3]};
+                    HP[st] = bf16x3::split8(v);
+                }
+                constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int ob = 0; ob < NB; ++ob) {
+                        const uint4 a = sm.W2p[((TA[t] * NCH + c) * NB + ob) * 64 + lane];
+                        Y[ob][0] = mfma16bf(a, HP[0].p[TB[t]], Y[ob][0]);
+                        Y[ob][1] = mfma16bf(a, HP[1].p[TB[t]], Y[ob][1]);
+                    }
+            } else
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
                 f32x4 a[NB];
