@@ -328,15 +328,16 @@ def resmlp512_leg(n_envs, rollout, epochs, steps=2):
                     "reduce+Adam)", achieved=round(flop / ms / 1e9, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                     frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4), epoch_ms=round(ms, 3), flop_per_epoch=flop, traffic=None,
                     detail="f32-input MFMA (v_mfma_f32_16x16x4_f32); f32 MFMA and VALU share the SIMD's FMA lanes and the loop "
-                           "sustains ~2.2 GHz, so ~0.85 of the nominal peak is the practical ceiling.  Since round 5 the H products of "
-                           "resmlp_fwd<16|32> run as float32 products from three-piece bf16 splits on the bf16 MFMA (both operands "
-                           "narrow: no per-hidden-value split) -- `achieved` stays the algorithmic float32 FLOP")
+                           "sustains ~2.2 GHz, so ~0.85 of the nominal peak is the practical ceiling.  Since round 5 the products that fill a k-step of "
+                           "v_mfma_f32_16x16x32_bf16 (H, Y of resmlp_fwd<32>; H^T, dH^T, dW2, dW1 of resmlp_bwd<32> on 4 waves x 512 registers; "
+                           "H of resmlp_fwd<16>) run as float32 products from three-piece bf16 splits -- `achieved` stays the algorithmic "
+                           "float32 FLOP against the f32-MFMA peak")
     env.close()
     return dict(policy="resmlp512", value=round(steps * rollout * n_envs / dt, 1), unit="env-steps/s", steps=steps,
                 ms_per_step=round(dt / steps * 1e3, 2), rollout_ms=round(r / steps * 1e3, 2), update_ms=round(u / steps * 1e3, 2),
                 rollout=("persistent kernel (navsim_rollout_resmlp512: rollout_resmlp_kernel, 16 envs on 8 waves)"
                          if tr.uses_persistent_rollout else "hipGraph of per-step launches"),
-                update="fused MFMA kernels (f32-input MFMA; the H products of the forward kernels as bf16x3 float32 products)" if up.fused_resmlp512 else "PyTorch-ROCm", update_roofline=roof)
+                update="fused MFMA kernels (products that fill a bf16 k-step as bf16x3 float32 products, the rest on the f32-input MFMA)" if up.fused_resmlp512 else "PyTorch-ROCm", update_roofline=roof)
 
 
 def ppo_shard_leg(n_envs, world, n_beams, obs_f16, sampler, rollout, epochs, detail, steps=2):
