@@ -390,3 +390,47 @@ def test_persistent_resmlp512_rollout_against_the_oracle(N, T, cap, lo, n_s):
     from test_gpu_parity import assert_rtg_close
     assert_rtg_close(tr.rtg_buf[:, sl].cpu().numpy(), O.compute_rtgs_tn(g["rew"], g["ended"], cfg.gamma))
     env.close()
+
+
+@pytest.mark.parametrize("n", [128 * 300 + 7, 1 << 17])
+def test_fused_resmlp512_gradients_against_float64(n):
+    """Since round 5 the products of these kernels that fill a k-step of the bf16 MFMA run as float32 products from three-piece bf16
+    splits (csrc/bf16x3.h; csrc/ppo_resmlp512.hip, header): float32-equivalent means that against FLOAT64 autograd of the same losses
+    (ppo.py:307-349,386) the fused gradients are not further off than float32 arithmetic is -- per parameter tensor, as a fraction of
+    the tensor's gradient scale: the median rms error over the 28 tensors at the level of half a float32 ulp of a tensor's largest
+    entry and not above PyTorch's own float32 autograd (x 1.5), every tensor inside the 2e-4 bound of the autograd tests.
+    (LeakyReLU has no dead side, so a unit within round-off of its kink moves a gradient entry by 0.8 of one sample's share, not by all
+    of it; the clip kink of the surrogate is the same as for the 64-wide heads: tests/_kinks.py.)"""
+    import copy
+    dev = torch.device("cuda")
+    a, c = _policy(dev)
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(policy="resmlp512"), None, dev)
+    obs, acts, logp, rtg, adv = _batch(n, n + 1, dev)
+    a64, c64 = copy.deepcopy(a).double(), copy.deepcopy(c).double()
+    nets.Linear.SPLIT_ROWS = 1 << 62
+    try:
+        al, cl, _, _, _ = ppo.ppo_losses(a64, c64, obs.double(), acts.double(), logp.double(), rtg.double(), adv.double(),
+                                         torch.tensor(0.5, dtype=torch.float64, device=dev), 0.2)
+        p64 = [p for m in (a64, c64) for k, p in m.named_parameters() if ".bn" not in "." + k and not k.startswith("bn")]
+        g64 = torch.cat([t.reshape(-1) for t in torch.autograd.grad(al + cl, p64)])
+        a32, c32 = copy.deepcopy(a), copy.deepcopy(c)
+        al2, cl2, _, _, _ = ppo.ppo_losses(a32, c32, obs, acts, logp, rtg, adv, torch.tensor(0.5, device=dev), 0.2)
+        p32 = [p for m in (a32, c32) for k, p in m.named_parameters() if ".bn" not in "." + k and not k.startswith("bn")]
+        g32 = torch.cat([t.reshape(-1) for t in torch.autograd.grad(al2 + cl2, p32)])
+    finally:
+        nets.Linear.SPLIT_ROWS = 1 << 16
+    up._fused_loss_grad(obs, acts, logp, rtg, adv, 0.5)
+    torch.cuda.synchronize()
+    g = up.fp.grad
+    assert g.numel() == g64.numel() == g32.numel()
+    offs = np.cumsum([0] + [q.numel() for q in up.fp.params])
+    def errs(x):
+        rms = [(((g64[o:e] - x[o:e].double()) ** 2).mean().sqrt() / (g64[o:e].abs().max() + 1e-300)).item() for o, e in zip(offs[:-1], offs[1:])]
+        mx = [((g64[o:e] - x[o:e].double()).abs().max() / (g64[o:e].abs().max() + 1e-300)).item() for o, e in zip(offs[:-1], offs[1:])]
+        return np.array(rms), np.array(mx)
+    rk, mk = errs(g)
+    rt, mt = errs(g32)
+    print(f"n = {n}: median rms error / tensor scale: fused kernels {np.median(rk):.2e}, PyTorch float32 autograd {np.median(rt):.2e}; "
+          f"worst tensor (max error) {mk.max():.2e} vs {mt.max():.2e}")
+    assert np.median(rk) <= 1.5 * np.median(rt) + 1e-9 and np.median(rk) <= 2e-7
+    assert mk.max() <= max(2e-4, 2 * mt.max())
