@@ -8,14 +8,15 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 from navbot_ppo_amd import build
 name, flags = sys.argv[1], sys.argv[2:]
+SRC = os.environ.get("VARIANT_SRC", "ppo_mlp64.hip")   # or ppo_resmlp512.hip
 build.build_native()   # the product objects are current
 objdir = os.path.join(R, "build", "obj_" + name)
 os.makedirs(objdir, exist_ok=True)
-obj = os.path.join(objdir, "ppo_mlp64.hip.o")
+obj = os.path.join(objdir, SRC + ".o")
 cflags = [f for f in build.HIPCC_FLAGS if f != "-shared"]
 subprocess.check_call([build.hipcc()] + cflags + flags + ["-I", build.INC, "-I", os.path.join(build.HERE, "csrc"), "-c",
-                                                         os.path.join(build.HERE, "csrc", "ppo_mlp64.hip"), "-o", obj])
-objs = [os.path.join(R, "build", "obj", f) for f in ("navsim.hip.o", "ppo_resmlp512.hip.o")] + [obj]
+                                                         os.path.join(build.HERE, "csrc", SRC), "-o", obj])
+objs = [os.path.join(R, "build", "obj", f) for f in ("navsim.hip.o", "ppo_mlp64.hip.o", "ppo_resmlp512.hip.o") if f != SRC + ".o"] + [obj]
 out = os.path.join(R, "build", f"libnavsim_{name}.so")
 subprocess.check_call([build.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", out])
 print(out)
