@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NAVSIM_ABI_VERSION 5
+#define NAVSIM_ABI_VERSION 6
 
 #define NAVSIM_OK 0
 #define NAVSIM_E_ARG (-1)   /* bad argument / unsupported configuration */
@@ -74,8 +74,9 @@ const char* navsim_last_error(void);
 /* Fills *cfg with the reference defaults (N=1, B=10, train threshold, stage_1 spawn and goal box). */
 void navsim_default_cfg(navsim_cfg* cfg);
 
-/* Env.__init__  (environment_new.py:27-47).  Allocates per-env state in HBM on the current device.  Reads nothing from the
- * process environment: everything a handle does follows from cfg, its map and navsim_set_shape. */
+/* Env.__init__  (environment_new.py:27-47).  Allocates per-env state in HBM on the current device.  No entry point of the
+ * library reads the process environment: everything a handle does follows from cfg, its map and navsim_set_shape, everything
+ * a free function does from its arguments. */
 int navsim_create(const navsim_cfg* cfg, navsim_t** out);
 void navsim_destroy(navsim_t* h);
 
@@ -91,8 +92,9 @@ int navsim_set_shape(navsim_t* h, int32_t envs_per_workgroup, int32_t pair_cast)
  * What the handle is and which kernel instantiation each entry point would launch right now (a profile can then name the
  * kernel it timed).  `*_epb` = envs per workgroup, `*_waves` = waves per workgroup, `*_cast`: 0 = 64-segment passes,
  * 1 = 128-segment passes, 2 = 128-segment passes with non-temporal loads, 3 = tile bounding boxes.
- * rollout_kind: 0 = navsim_rollout_mlp64 unavailable for this handle, 1 = rollout_kernel (EPB envs on 8 waves),
- * 2 = rollout_big_kernel (64 envs on 16 waves).
+ * rollout_kind: 0 = navsim_rollout_mlp64 unavailable for this handle, 1 = rollout_kernel (rollout_epb = 4 | 8 | 16 envs on 8
+ * waves), 2 = rollout_big_kernel (rollout_epb = 64 envs on 16 waves, or 32 envs on 8 waves: tile-box maps on 4097..8192 envs and
+ * the forced 32-env shape).  forced_epb / forced_pair_cast: what navsim_set_shape was last given (0 / -1 = the rule).
  */
 typedef struct navsim_info {
     int32_t abi_version, n_envs, n_beams, obs_f16;
@@ -208,11 +210,12 @@ int navsim_set_state(navsim_t* h, const double* pose_host, const double* goal_ho
  * accumulated in float64 and stored as float32 like the reference (:665,:669).
  * N % 16 == 0 runs the scan split over T (chunk-local scans composed through float64 carries): every stored float32 is
  * within ONE ulp of the reference's serial recurrence (identical behind an episode end inside its 32-row chunk; elsewhere
- * a store differs with probability ~2e-8).  Any other N, or NAVSIM_RTG_EXACT=1 in the environment, runs the serial
- * recurrence: bit-identical, about 4x slower.
+ * a store differs with probability ~2e-8).  Any other N, or exact != 0, runs the serial recurrence: bit-identical, about 4x
+ * slower.  (ABI v6: `exact` is an argument; up to v5 it was NAVSIM_RTG_EXACT in the process environment -- the library reads
+ * nothing from the environment any more.)
  */
 int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, int32_t N, double gamma,
-                    float* out_dev, void* stream);
+                    float* out_dev, int32_t exact, void* stream);
 
 /*
  * Generalised advantage estimation -- the "GAE / return scan" BASELINE.json's north_star names; an EXTENSION: the reference
@@ -223,10 +226,10 @@ int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, i
  *     R[t] = rew[t] + (ended[t] ? 0 : gamma (1 - lam) V[t+1] + gamma lam R[t+1])          float64 accumulate
  *     ret_dev [T,N] (nullable) = float32(R[t]) -- the lambda-return, the critic's target;   adv_dev [T,N] = float32(R[t]) - V[t]
  * lam = 1 and last_value_dev = NULL: ret_dev is bit-identical to navsim_rtg_scan's output and adv_dev to rtgs - V.  Same
- * kernel, same <= 1 ulp contract and the same NAVSIM_RTG_EXACT / N % 16 rule as navsim_rtg_scan.
+ * kernel, same <= 1 ulp contract and the same `exact` / N % 16 rule as navsim_rtg_scan.
  */
 int navsim_gae_scan(const float* rew_dev, const uint8_t* ended_dev, const float* value_dev, const float* last_value_dev, int32_t T,
-                    int32_t N, double gamma, double lam, float* adv_dev, float* ret_dev, void* stream);
+                    int32_t N, double gamma, double lam, float* adv_dev, float* ret_dev, int32_t exact, void* stream);
 
 /*
  * The hot loop of PPO.rollout (project_ppo/src/ppo.py:505-594) for the (B + 6)-64-64 policy, all n_steps steps in ONE launch:
@@ -243,9 +246,11 @@ int navsim_gae_scan(const float* rew_dev, const uint8_t* ended_dev, const float*
  *   var_dev  device scalar: exploration variance (ppo.py:123-124)
  *   act_seed, step_base_dev (device scalar, nullable = 0): action noise = Philox(act_seed, env id, *step_base_dev + t)
  * Workgroup shapes, same rows bit for bit: 16 envs on 8 waves (a latency chain per workgroup, one round of workgroups up to
- * 4096 envs; no tile boxes in the cast; the only shape with 36 beams) and, with 10 beams beyond 4096 envs per GPU, 64 envs on
- * 16 waves with the cast variants of navsim_step (tile boxes of shared 65..4096-segment maps, 128-segment passes of per-env
- * maps): the closed-loop form of navsim_step_seq (navsim_set_shape: 4 | 8 | 16 | 64 forces a shape; navsim_get_info reports it).
+ * 4096 envs; 64-segment passes, or tile boxes on shared 65..4096-segment maps; the only shape with 36 beams) and, with 10 beams
+ * beyond 4096 envs per GPU, 64 envs on 16 waves with the cast variants of navsim_step (tile boxes, 128-segment passes of per-env
+ * maps) -- 32 envs on 8 waves for tile-box maps on 4097..8192 envs: the closed-loop form of navsim_step_seq (navsim_set_shape:
+ * 4 | 8 | 16 | 32 | 64 forces a shape; navsim_get_info reports the one a launch would take).  params_dev and obs_buf_dev must be
+ * 16-byte aligned, act_buf_dev 8-byte (NAVSIM_E_ARG otherwise).
  */
 int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, void* obs_buf_dev, float* act_buf_dev,
                          float* logp_buf_dev, float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev,

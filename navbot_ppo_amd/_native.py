@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NAVSIM_LIB: another build of the same library (tools/build_variant.py A/B timing); never a different implementation
 LIB_PATH = os.environ.get("NAVSIM_LIB") or os.path.join(_HERE, "libnavsim.so")
 
-NAVSIM_ABI_VERSION = 5
+NAVSIM_ABI_VERSION = 6
 
 
 class NavsimError(RuntimeError):
@@ -61,8 +61,8 @@ SYMBOLS = [
     ("navsim_step", C.c_int, [_vp] * 12),
     ("navsim_get_state", C.c_int, [_vp] * 8),
     ("navsim_set_state", C.c_int, [_vp] * 8),
-    ("navsim_rtg_scan", C.c_int, [_vp, _vp, _i32, _i32, _d, _vp, _vp]),
-    ("navsim_gae_scan", C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _d, _d, _vp, _vp, _vp]),
+    ("navsim_rtg_scan", C.c_int, [_vp, _vp, _i32, _i32, _d, _vp, _i32, _vp]),
+    ("navsim_gae_scan", C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _d, _d, _vp, _vp, _i32, _vp]),
     ("navsim_raycast", C.c_int, [_vp, _vp, _vp, _vp]),
     ("navsim_odometry", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("navsim_rollout_mlp64", C.c_int, [_vp] * 13 + [C.c_uint64, _vp, _i32, _vp]),

@@ -1965,7 +1965,7 @@ __global__ void spawn_obs_kernel(const float* __restrict__ best, int n, int belo
 // Every row behind (earlier than) an episode end inside its chunk carries the reference's bits by construction; the others see
 // a carry-in whose float64 rounding differs from the serial chain's (relative 1e-15), which moves the float32 store by one ulp
 // with probability ~2e-8 per element.  Contract: <= 1 float32 ulp from ppo.py:660-669, flags untouched (tests state it);
-// NAVSIM_RTG_EXACT=1 selects the serial kernel below, which is bit-identical.  "if ended: disc = 0" is folded into the
+// `exact` != 0 (argument of navsim_rtg_scan / navsim_gae_scan) selects the serial kernel below, which is bit-identical.  "if ended: disc = 0" is folded into the
 // factor: disc * 0 is (+-)0 and r + (+-)0 == r, so the value is that of ppo.py:660-665 while the select leaves the chain.
 // T > 512: super-chunks of 512 rows from the batch end, the carry between them is the stored float64 of pass 2.
 constexpr int kRtgCols = 16, kRtgChunks = 16, kRtgRows = 32, kRtgSuper = kRtgChunks * kRtgRows;
@@ -2118,6 +2118,7 @@ struct navsim {
     // below; pair_cast false = 64-segment passes for every map
     int force_epb = 0;
     bool pair_cast = true;
+    int pair_cast_request = -1;   // what navsim_set_shape was given (-1 = the rule): reported by navsim_get_info
 };
 
 // Envs per workgroup.  Bigger workgroups make the float64 lanes of the geometry / rules phases denser (a wave instruction
@@ -2432,6 +2433,7 @@ int navsim_set_shape(navsim_t* h, int32_t envs_per_workgroup, int32_t pair_cast)
         return fail(NAVSIM_E_ARG, "navsim_set_shape: envs_per_workgroup is 0 | 4 | 8 | 16 | 32 | 64, pair_cast -1 | 0 | 1");
     h->force_epb = v;
     h->pair_cast = pair_cast != 0;
+    h->pair_cast_request = pair_cast;
     return NAVSIM_OK;
 }
 
@@ -2442,7 +2444,7 @@ int navsim_get_info(navsim_t* h, navsim_info* out) {
     out->n_envs = h->P.N; out->n_beams = h->P.B; out->obs_f16 = h->P.obs_f16;
     out->n_segments = h->P.S; out->per_env_map = h->P.per_env & 1; out->tile_boxes = h->P.tile_box != nullptr;
     out->has_map = h->has_map;
-    out->forced_epb = h->force_epb; out->forced_pair_cast = h->pair_cast ? -1 : 0;
+    out->forced_epb = h->force_epb; out->forced_pair_cast = h->pair_cast_request;
     if (h->has_map) {
         const ShapePick a = pick_shape(h, false), b = pick_shape(h, true);
         out->step_epb = a.epb; out->step_waves = a.waves; out->step_cast = a.cast;
@@ -2646,8 +2648,8 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, void* obs_b
     if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_rollout_mlp64: call navsim_set_map first");
     const RolloutPick rp = pick_rollout(h);
     if (rp.kind == 0) return fail(NAVSIM_E_ARG, "navsim_rollout_mlp64: the (B + 6)-64-64 policy needs 10 or 36 beams");
-    if (((uintptr_t)actor_params_dev & 15) || ((uintptr_t)act_buf_dev & 7))
-        return fail(NAVSIM_E_ARG, "navsim_rollout_mlp64: params must be 16-byte and act 8-byte aligned");
+    if (((uintptr_t)actor_params_dev & 15) || ((uintptr_t)act_buf_dev & 7) || ((uintptr_t)obs_buf_dev & 15))
+        return fail(NAVSIM_E_ARG, "navsim_rollout_mlp64: params and obs must be 16-byte, act 8-byte aligned");
     if (n_steps == 0) return NAVSIM_OK;
     RolloutArgs R;
     R.params = actor_params_dev; R.obs_buf = obs_buf_dev; R.act_buf = act_buf_dev; R.logp_buf = logp_buf_dev;
@@ -2858,12 +2860,10 @@ int navsim_set_state(navsim_t* h, const double* pose, const double* goal, const 
 }
 
 int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, int32_t N, double gamma,
-                    float* out_dev, void* stream) {
+                    float* out_dev, int32_t exact, void* stream) {
     if (T < 0 || N < 0) return fail(NAVSIM_E_ARG, "navsim_rtg_scan: negative size");
     if (T == 0 || N == 0) return NAVSIM_OK;  // empty batch: nothing to scan (pointers may be null)
     if (!rew_dev || !ended_dev || !out_dev) return fail(NAVSIM_E_ARG, "navsim_rtg_scan: null buffer");
-    const char* ex = std::getenv("NAVSIM_RTG_EXACT");
-    const bool exact = ex && ex[0] == '1';
     if (N % kRtgCols == 0 && !exact)
         hipLaunchKernelGGL(rtg_kernel_split<false>, dim3(N / kRtgCols), dim3(256), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N, gamma,
                            out_dev, (const float*)nullptr, (const float*)nullptr, 1.0, (float*)nullptr);
@@ -2875,13 +2875,11 @@ int navsim_rtg_scan(const float* rew_dev, const uint8_t* ended_dev, int32_t T, i
 }
 
 int navsim_gae_scan(const float* rew_dev, const uint8_t* ended_dev, const float* value_dev, const float* last_value_dev, int32_t T,
-                    int32_t N, double gamma, double lam, float* adv_dev, float* ret_dev, void* stream) {
+                    int32_t N, double gamma, double lam, float* adv_dev, float* ret_dev, int32_t exact, void* stream) {
     if (T < 0 || N < 0) return fail(NAVSIM_E_ARG, "navsim_gae_scan: negative size");
     if (T == 0 || N == 0) return NAVSIM_OK;
     if (!rew_dev || !ended_dev || !value_dev || !adv_dev) return fail(NAVSIM_E_ARG, "navsim_gae_scan: null buffer");
     if (!(lam >= 0.0 && lam <= 1.0)) return fail(NAVSIM_E_ARG, "navsim_gae_scan: lambda outside [0, 1]");
-    const char* ex = std::getenv("NAVSIM_RTG_EXACT");
-    const bool exact = ex && ex[0] == '1';
     if (N % kRtgCols == 0 && !exact)
         hipLaunchKernelGGL(rtg_kernel_split<true>, dim3(N / kRtgCols), dim3(256), 0, (hipStream_t)stream, rew_dev, ended_dev, T, N, gamma,
                            ret_dev, value_dev, last_value_dev, lam, adv_dev);

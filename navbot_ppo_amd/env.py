@@ -48,6 +48,10 @@ class NavSim:
         if not torch.cuda.is_available():
             raise NavsimError("navbot_ppo_amd needs a HIP device (MI355X); there is no CPU path")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise NavsimError(f"navbot_ppo_amd needs a HIP device, got device={device!r}; there is no CPU path")
+        if self.device.index is None:   # "cuda" names the current device: tensors report "cuda:N", and _chk compares devices
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.N, self.B, self.D = int(n_envs), int(n_beams), int(n_beams) + 6
         self.obs_dtype = torch.float16 if obs_f16 else torch.float32
         self.cfg = NavsimCfg(self.N, self.B, int(max_episode_steps), int(bool(auto_reset)), int(bool(respawn_on_arrive)),
@@ -59,10 +63,15 @@ class NavSim:
             check(lib().navsim_create(C.byref(self.cfg), C.byref(self._h)), "navsim_create")
         self._seg = None  # keeps the map tensor alive: the handle only borrows the pointer
         self.generation = 0  # bumped whenever device pointers / scalars a captured hipGraph would have frozen change
-        if envs_per_workgroup is None and os.environ.get("NAVSIM_EPB"):
-            envs_per_workgroup = int(os.environ["NAVSIM_EPB"])
-        if pair_cast is None and os.environ.get("NAVSIM_PAIR_CAST"):
-            pair_cast = int(os.environ["NAVSIM_PAIR_CAST"]) != 0
+        def knob(name):   # a dev tool's environment variable; anything that is not an integer is ignored, as the library used to
+            try:
+                return int(os.environ[name])
+            except (KeyError, ValueError):
+                return None
+        if envs_per_workgroup is None and knob("NAVSIM_EPB") is not None:
+            envs_per_workgroup = knob("NAVSIM_EPB")
+        if pair_cast is None and knob("NAVSIM_PAIR_CAST") is not None:
+            pair_cast = knob("NAVSIM_PAIR_CAST") != 0
         if envs_per_workgroup is not None or pair_cast is not None:
             self.set_shape(envs_per_workgroup or 0, pair_cast)
 
@@ -228,8 +237,9 @@ class NavSim:
             check(lib().navsim_set_state(self._h, *[_np_ptr(a) for a in arrs], _stream()), "navsim_set_state")
 
 
-def rtg_scan(rew, ended, gamma, out=None):
-    """PPO.compute_rtgs (ppo.py:643-671) on [T,N] device tensors; see navsim_rtg_scan."""
+def rtg_scan(rew, ended, gamma, out=None, exact=False):
+    """PPO.compute_rtgs (ppo.py:643-671) on [T,N] device tensors; see navsim_rtg_scan.  exact: the serial recurrence (every
+    bit the reference's) instead of the T-split scan (<= 1 float32 ulp)."""
     if not rew.is_cuda:
         raise NavsimError("rtg_scan needs device tensors; there is no CPU path")
     T, N = rew.shape
@@ -239,7 +249,7 @@ def rtg_scan(rew, ended, gamma, out=None):
     if out is None:
         out = torch.empty_like(rew)
     with torch.cuda.device(rew.device):
-        check(lib().navsim_rtg_scan(_ptr(rew), _ptr(ended), T, N, float(gamma), _ptr(out), _stream()), "navsim_rtg_scan")
+        check(lib().navsim_rtg_scan(_ptr(rew), _ptr(ended), T, N, float(gamma), _ptr(out), int(bool(exact)), _stream()), "navsim_rtg_scan")
     return out
 
 
@@ -257,7 +267,7 @@ def odometry(x, y, quat, goal):
     return out
 
 
-def gae_scan(rew, ended, value, gamma, lam, last_value=None, want_returns=True):
+def gae_scan(rew, ended, value, gamma, lam, last_value=None, want_returns=True, exact=False):
     """GAE(lambda) on [T,N] device tensors (navsim_gae_scan): returns (adv, lambda_returns).  lam = 1 without `last_value`
     is PPO.compute_rtgs followed by A = rtgs - V (ppo.py:277, 643-671), bit for bit."""
     if not rew.is_cuda:
@@ -272,7 +282,7 @@ def gae_scan(rew, ended, value, gamma, lam, last_value=None, want_returns=True):
     ret = torch.empty_like(rew) if want_returns else None
     with torch.cuda.device(rew.device):
         check(lib().navsim_gae_scan(_ptr(rew), _ptr(ended), _ptr(value), _ptr(last_value), T, N, float(gamma), float(lam),
-                                    _ptr(adv), _ptr(ret), _stream()), "navsim_gae_scan")
+                                    _ptr(adv), _ptr(ret), int(bool(exact)), _stream()), "navsim_gae_scan")
     return adv, ret
 
 

@@ -50,9 +50,11 @@ class PPOConfig:
     use_graph: bool = True                 # capture the T-step rollout in one hipGraph
     persistent_rollout: bool = True        # on GPU: all T steps in ONE launch (navsim_rollout_mlp64 / navsim_rollout_resmlp512)
     fused_update: bool = True              # on GPU: fused HIP loss+gradient kernels (csrc/ppo_mlp64.hip, csrc/ppo_resmlp512.hip)
-    # arithmetic of the fused 16-64-64 update's matrix products: "bf16x3" = float32 products out of operands split into three bf16
+    # arithmetic of the fused update's matrix products: "bf16x3" = float32 products out of operands split into three bf16
     # pieces on the bf16 MFMA (six piece products, float32 accumulate: float32-equivalent by measurement), "f32" =
     # the f32-input MFMA (native float32 fma chains).  Inputs, outputs and everything around the products are float32 either way.
+    # mlp64x2: both builds exist.  resmlp512: the fused kernels are "bf16x3" (split products where a k-step of the bf16 MFMA is
+    # filled, f32-input MFMA elsewhere; V0 from navppo_resmlp512_value included); "f32" selects the PyTorch float32 path with a warning.
     update_arith: str = "bf16x3"
     # multi-GPU, mlp64x2: False = fused passes of both nets -> ONE all-reduce of the flat gradient -> Adam (the default: at one
     # RCCL rank this path costs 9-24 us per epoch over the single-GPU epoch, the per-net pipeline below 59-74 us, because two
@@ -222,11 +224,19 @@ class PPOUpdater:
         self.fused_mlp64 = (on_gpu and cfg.policy == "mlp64x2" and isinstance(actor, nets.MLP64Actor)
                             and actor.layer1.in_features in (16, 42))
         self.obs_dim = actor.layer1.in_features if isinstance(actor, nets.MLP64Actor) else actor.rb1.f_in
-        self.fused_resmlp512 = (on_gpu and cfg.policy == "resmlp512" and isinstance(actor, nets.ResMLPActor)
-                                and actor.rb1.f_in == 16 and actor.rb1.fc1.out_features == 512)
-        self.fused = "navppo_mlp64" if self.fused_mlp64 else "navppo_resmlp512" if self.fused_resmlp512 else None
         if cfg.update_arith not in ("f32", "bf16x3"):
             raise ValueError(f"update_arith {cfg.update_arith!r}: 'f32' or 'bf16x3'")
+        self.fused_resmlp512 = (on_gpu and cfg.policy == "resmlp512" and isinstance(actor, nets.ResMLPActor)
+                                and actor.rb1.f_in == 16 and actor.rb1.fc1.out_features == 512)
+        if self.fused_resmlp512 and cfg.update_arith == "f32":
+            # the fused 512-wide kernels exist in ONE arithmetic (csrc/ppo_resmlp512.hip: the products that fill a k-step of the
+            # bf16 MFMA are split-bf16 float32 products, the rest f32-input MFMA).  A caller who asks for native float32
+            # products gets them -- from PyTorch's float32 GEMMs, ~4 x slower per epoch -- instead of being ignored.
+            import warnings
+            warnings.warn("update_arith='f32' with policy='resmlp512': the fused 512-wide kernels have no all-f32-MFMA build; "
+                          "this updater runs the PyTorch float32 path (slower).  Use update_arith='bf16x3' (default) for the fused kernels.")
+            self.fused_resmlp512 = False
+        self.fused = "navppo_mlp64" if self.fused_mlp64 else "navppo_resmlp512" if self.fused_resmlp512 else None
         self.bf16x3 = self.fused_mlp64 and cfg.update_arith == "bf16x3"   # (16- and 42-column rows, float32 or float16)
         self._prep = self._prep_key = None
         if self.fused:
@@ -282,7 +292,14 @@ class PPOUpdater:
             raise RuntimeError(f"navppo_mlp64_bf16x3_prepare failed: {L.navppo_last_error().decode()}")
         self._prep_key = (obs.data_ptr(), tuple(obs.shape), obs.dtype, obs._version)
 
+    def invalidate_prepared(self):
+        """The rows behind a prepared tensor changed without torch noticing (the HIP rollout / step kernels write the trainer's
+        buffers through raw pointers: no version bump).  PPOTrainer.rollout() calls this; any other writer of such a buffer must."""
+        self._prep_key = None
+
     def _prepared(self, obs):
+        """The pre-split pieces of `obs`.  Reused while `obs` is the very tensor prepare() saw, unchanged as far as torch knows
+        (pointer, shape, dtype, version counter) AND nobody called invalidate_prepared() since."""
         import ctypes as C
         if self._prep_key != (obs.data_ptr(), tuple(obs.shape), obs.dtype, obs._version):
             self.prepare(obs)
@@ -593,6 +610,7 @@ class PPOTrainer:
         self._decay_exploration()
         self.epret_buf.zero_()
         self.eplen_buf.zero_()
+        self.updater.invalidate_prepared()   # the kernels below rewrite obs_buf behind torch's version counter
         self.env.sim.reset(self.obs_buf[0])  # ppo.py:486: every batch starts from a reset
         sim = self.env.sim
         # (round 5: both rollout kernels have the tile-box cast of shared 65..4096-segment maps; until then shards up to 4096 envs on

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     bound = {n for n, _, _ in _native.SYMBOLS}
     assert set(declared) == bound, (set(declared) ^ bound)
-    assert lib.navsim_version() == 5
+    assert lib.navsim_version() == _native.NAVSIM_ABI_VERSION == 6
 
 
 def test_default_cfg_matches_reference_constants():
@@ -75,6 +75,15 @@ def test_library_reads_no_shape_knobs_from_the_environment():
     code = re.sub(r"//[^\n]*", "", src)
     assert "NAVSIM_EPB" not in code and "NAVSIM_PAIR_CAST" not in code
     assert not re.search(r"\bg_epb\b|\bg_pair_cast\b", code)
+    # ... and nothing else either: no translation unit of the library calls getenv (NAVSIM_RTG_EXACT became the `exact` argument
+    # of navsim_rtg_scan / navsim_gae_scan in ABI v6), and the shared object does not import the symbol
+    for f in os.listdir(os.path.join(REPO, "navbot_ppo_amd", "csrc")):
+        txt = re.sub(r"//[^\n]*", "", open(os.path.join(REPO, "navbot_ppo_amd", "csrc", f)).read())
+        assert "getenv" not in txt, f
+    import subprocess
+    from navbot_ppo_amd import _native as _n
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", _n.LIB_PATH], text=True)
+    assert "getenv" not in undefined
     from navbot_ppo_amd import _native
     L = _native.lib()
     # argument checks run without a device

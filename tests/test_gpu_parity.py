@@ -265,9 +265,7 @@ def test_rtg_scan_parity_and_golden(monkeypatch):
             cs = np.concatenate([np.zeros((1, N), np.int64), np.cumsum(ended, 0)])
             has_end_ahead = cs[chunk_end[:, 0]] - cs[:-1] > 0   # an end in rows [t, chunk_end)
             np.testing.assert_array_equal(got[has_end_ahead], ref[has_end_ahead])
-            monkeypatch.setenv("NAVSIM_RTG_EXACT", "1")   # the serial kernel on the same input: every bit
-            ex = rtg_scan(torch.from_numpy(rew).cuda(), torch.from_numpy(ended).cuda(), 0.99).cpu().numpy()
-            monkeypatch.delenv("NAVSIM_RTG_EXACT")
+            ex = rtg_scan(torch.from_numpy(rew).cuda(), torch.from_numpy(ended).cuda(), 0.99, exact=True).cpu().numpy()   # the serial kernel: every bit
             np.testing.assert_array_equal(ex, ref)
     # reference golden (ragged episodes of one env -> one column)
     d = np.load(os.path.join(G, "g5_rtgs.npz"))
@@ -913,18 +911,18 @@ def test_gae_scan(T, N, monkeypatch):
     V = (rng.standard_normal((T, N)) * 50).astype(np.float32)
     last = (rng.standard_normal(N) * 50).astype(np.float32)
     cu = lambda a: torch.from_numpy(a).cuda()
-    for exact in ("0", "1"):
-        monkeypatch.setenv("NAVSIM_RTG_EXACT", exact)
-        rtg = rtg_scan(cu(rew), cu(ended), 0.99)
-        adv, ret = gae_scan(cu(rew), cu(ended), cu(V), 0.99, 1.0)
+    for exact in (False, True):
+        rtg = rtg_scan(cu(rew), cu(ended), 0.99, exact=exact)
+        adv, ret = gae_scan(cu(rew), cu(ended), cu(V), 0.99, 1.0, exact=exact)
         assert torch.equal(ret, rtg)
         assert torch.equal(adv, rtg - cu(V))
         for lam, lv in ((0.95, None), (0.9, last), (0.0, None), (1.0, last)):
-            adv, ret = gae_scan(cu(rew), cu(ended), cu(V), 0.99, lam, last_value=None if lv is None else cu(lv))
+            adv, ret = gae_scan(cu(rew), cu(ended), cu(V), 0.99, lam, last_value=None if lv is None else cu(lv), exact=exact)
             want = _gae_ref(rew, ended, V, 0.99, lam, lv)
             np.testing.assert_allclose(ret.cpu().numpy(), want, rtol=2e-6, atol=2e-5)
             np.testing.assert_allclose(adv.cpu().numpy(), want.astype(np.float32) - V, rtol=0, atol=3e-4)
-            adv2, none = gae_scan(cu(rew), cu(ended), cu(V), 0.99, lam, last_value=None if lv is None else cu(lv), want_returns=False)
+            adv2, none = gae_scan(cu(rew), cu(ended), cu(V), 0.99, lam, last_value=None if lv is None else cu(lv), want_returns=False,
+                                  exact=exact)
             assert none is None and torch.equal(adv2, adv)
 
 

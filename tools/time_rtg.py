@@ -15,12 +15,12 @@ for T, N, p in ((512, 4096, .01), (512, 4096, .001), (512, 4096, 0.), (512, 4097
 T, N = 512, 4096
 rew = torch.randn((T, N), device="cuda"); ended = (torch.rand((T, N), device="cuda") < 0.01).to(torch.uint8); out = torch.empty_like(rew)
 for mode in ("0", "1"):
-    os.environ["NAVSIM_RTG_EXACT"] = mode
-    for _ in range(10): rtg_scan(rew, ended, 0.99, out=out)
+    ex = mode == "1"
+    for _ in range(10): rtg_scan(rew, ended, 0.99, out=out, exact=ex)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()   # 32 launches per replay: the python launch path is not what is measured
     with torch.cuda.graph(g):
-        for _ in range(32): rtg_scan(rew, ended, 0.99, out=out)
+        for _ in range(32): rtg_scan(rew, ended, 0.99, out=out, exact=ex)
     g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
