@@ -28,7 +28,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SRCS + [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h", "resmlp_policy.h", "bf16x3.h")]
+    deps = SRCS + [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h", "resmlp_policy.h", "bf16x3.h", "ppo_mlp64_x3s.h")]
     return any(os.path.getmtime(p) > t for p in deps)
 
 
@@ -72,7 +72,7 @@ def build_native(force=False, verbose=False, navsim_src=None, out=None, extra=()
     procs, objs = [], []
     srcs = SRCS if navsim_src is None else [navsim_src] + SRCS[1:]
     lib_out = LIB if out is None else out
-    hdrs = [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h", "resmlp_policy.h", "bf16x3.h")]
+    hdrs = [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h", "resmlp_policy.h", "bf16x3.h", "ppo_mlp64_x3s.h")]
     for k, src in enumerate(srcs):   # the sources compile side by side
         obj = os.path.join(objdir, os.path.basename(SRCS[k]) + ".o")
         per_src = [] if os.environ.get("NAVSIM_NO_EXTRA_FLAGS") == "1" else EXTRA_FLAGS.get(os.path.basename(SRCS[k]), [])   # (A/B builds)

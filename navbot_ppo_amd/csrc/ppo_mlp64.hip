@@ -1261,6 +1261,13 @@ __global__ __launch_bounds__(64 * XPad<IN>::NW) void mlp64_pass_both_x3(const fl
     if (net_mask & 2) pass_body_x3<false, IN>(sm, params + Layout<IN>::P_ACTOR, prep, act, logp_old, rtg, adv, M, var, clip, inv_n, partial_c, stats_partial_c);
 }
 
+// round 6: the 16-column split pass as a hand-placed stream (4 waves x 512 registers, pieces transposed through LDS); the kernel above
+// stays for the 42-column rows and, under -DX3_SCHED=0, as the 16-column A/B partner (tools/build_mlp64_variant.py)
+#ifndef X3_SCHED
+#define X3_SCHED 1
+#endif
+#include "ppo_mlp64_x3s.h"
+
 // grad[p] = sum over the workgroups' partial rows, for BOTH nets; ADAM (single-GPU epoch): then torch.optim.Adam's update (ppo.py:116-117,381,392; defaults betas
 // (0.9, 0.999), eps 1e-8, no weight decay) applied in place -- one launch instead of two reductions + an optimiser launch.
 // One block owns 64 parameters and ALL rows (no atomics): grad[p] is stored, not accumulated.  pa / pc: parameters of the actor /
@@ -1690,7 +1697,11 @@ static int x3_epoch(const char* who, float* params_dev, const void* prep_dev, in
     }
     hipStream_t st = (hipStream_t)stream;
     const PassPlan pl = plan_pass(workspace_dev, n_samples, obs_dim);
-    if (obs_dim == 16)
+    if (obs_dim == 16 && X3_SCHED)
+        hipLaunchKernelGGL(mlp64_pass_both_x3s, dim3(pl.blocks), dim3(64 * x3s::SW), 0, st, params_dev,
+                           reinterpret_cast<const unsigned char*>(prep_dev), act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip,
+                           pl.inv_n, net_mask, pl.partial, pl.stats_partial, pl.partial_c, pl.stats_partial_c);
+    else if (obs_dim == 16)
         hipLaunchKernelGGL(mlp64_pass_both_x3<16>, dim3(pl.blocks), dim3(64 * XPad<16>::NW), 0, st, params_dev,
                            reinterpret_cast<const unsigned char*>(prep_dev), act_dev, logp_old_dev, rtg_dev, adv_dev, (long long)n_samples, var, clip,
                            pl.inv_n, net_mask, pl.partial, pl.stats_partial, pl.partial_c, pl.stats_partial_c);
