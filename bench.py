@@ -29,7 +29,9 @@ Besides the contract fields, rank 0 adds
                       house map, f16 observations, start / goal tables): us per step (launch per step / tape), env-steps/s
   traffic_source      which rocprofv3 --pmc file the `traffic` fields come from (--with-pmc-file: the same gpurun call as this run)
   roofline_timed_region   the persistent rollout kernel of the timed workload
-  update_roofline     the update kernels of the timed workload (94 % of the timed region): MFMA FLOPs of one epoch / its duration
+  update_roofline     the update kernels of the timed workload (94 % of the timed region).  Split-bf16 pass: EXECUTED bf16 MFMA FLOPs of one
+                      epoch / its duration against the dense bf16 MFMA peak (the unit it runs on), with the algorithmic float32 FLOP against
+                      the f32-input MFMA peak beside it (`f32_equivalent`); f32 pass: algorithmic FLOP against the f32-input MFMA peak
   time_to_reward_s    PPO wall-clock until mean episode return >= +100 (ppo.py:833) from a fresh policy
   resmlp512           the same iteration with the reference's active 512-wide residual nets (fused f32-MFMA kernels of
                       csrc/ppo_resmlp512.hip) + `update_roofline`: MFMA FLOPs of one epoch / its duration vs the 157.3 TF peak
@@ -418,26 +420,39 @@ def mlp64_update_roofline(tr, reps=40, arith=None):
     # MACs per sample and net: F1 64 D + F2 4096 + B2 4096 + G2 4096 + G1 64 D on MFMA (D = 16: 14,336), output units / their
     # gradients on the vector units (actor 384, critic 192): D = 16: 2 x (2 x 14,336 + 576) = 58,496 FLOP per sample
     flop = (2 * 2 * (12288 + 128 * D) + 2 * 576) * T * N
-    out = dict(bound="mfma", arith="bf16x3" if x3 else "f32",
-               kernel=("navppo_mlp64_bf16x3_update_epoch (mlp64_pass_both_x3 + reduce_adam)" if x3 else
-                       "navppo_mlp64_update_epoch (mlp64_pass_both + reduce_adam)"),
-               achieved=round(flop / ms / 1e9, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4),
-               epoch_us=round(ms * 1e3, 1), flop_per_epoch=flop, samples=T * N, traffic=None)
-    if x3:
-        # what the matrix pipe executes: six bf16 piece products per float32 product (v_mfma_f32_32x32x16_bf16 / 16x16x32), priced
-        # against the dense bf16 MFMA peak; `achieved` / `frac` above stay the ALGORITHMIC float32 FLOP against the f32-MFMA peak,
-        # like for like with the native path and with earlier rounds (a frac above 1 there would mean: beyond what f32 MFMA can do)
-        mfma_flop = 6 * 2 * 2 * (12288 + 128 * (16 if D == 16 else 48)) * T * N   # (42-column rows are 48 columns on chip)
-        out["bf16_mfma"] = dict(executed_tflops=round(mfma_flop / ms / 1e9, 1), peak=MFMA_BF16_PEAK_TF, frac=round(mfma_flop / ms / 1e9 / MFMA_BF16_PEAK_TF, 4))
-        out["split_obs_us_per_update"] = round(split_ms * 1e3, 1)
-        out["detail"] = ("float32 products from operands split into three bf16 pieces, six piece products each on the bf16 MFMA, float32 "
-                         "accumulate (float32-equivalent: tests/test_gpu_bf16x3.py).  Bound by the vector unit, not the matrix pipe: per "
-                         "32-sample tile and net 180 MFMAs (5,376 cycles: SQ_VALU_MFMA_BUSY = 33 % of the launch) beside ~1,465 vector "
-                         "instructions (880 of them the five 32-value splits, SQ_ACTIVE_INST_VALU = 41 %) at 16 columns; bf16 MFMA and vector "
-                         "work of the two waves of a SIMD do not overlap (tools/ubench/bf16_mfma_valu_overlap.hip) -- profiles/r05_bf16x3_pmc.txt"
-                         + ("" if D == 16 else ".  42-column rows (48 on chip): 252 MFMAs per tile and net, 4 waves x 512 registers "
-                            "(the 8-wave build does not fit the LDS)"))
+    f32_equiv = dict(achieved=round(flop / ms / 1e9, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4),
+                     flop_per_epoch=flop, note="ALGORITHMIC float32 FLOP of the epoch against the f32-input MFMA peak")
+    if not x3:
+        out = dict(bound="mfma", arith="f32", kernel="navppo_mlp64_update_epoch (mlp64_pass_both + reduce_adam)", **{k: f32_equiv[k] for k in
+                   ("achieved", "peak", "unit", "frac")}, epoch_us=round(ms * 1e3, 1), flop_per_epoch=flop, samples=T * N, traffic=None)
     else:
+        # The split pass runs on the bf16 matrix pipe: `achieved` / `peak` / `frac` are what THAT unit executes -- six bf16 piece products
+        # per float32 product (v_mfma_f32_32x32x16_bf16 / 16x16x32; 16 columns: + the ones-products of db1) -- against the dense bf16 MFMA
+        # peak.  The algorithmic float32 FLOP against the f32-input MFMA peak (the number earlier rounds printed as `frac`: a value
+        # above 1 there means "beyond what the f32 MFMA can do", not a utilisation) is kept beside it as `f32_equivalent`.
+        sched = D == 16   # the hand-placed stream of round 6 (csrc/ppo_mlp64_x3s.h); 42-column rows run round 5's pass
+        mfma_flop = 6 * 2 * 2 * (12288 + 128 * (16 if D == 16 else 48)) * T * N   # (42-column rows are 48 columns on chip)
+        if sched:
+            mfma_flop += 2 * 12 * 16384 * ((T * N + 31) // 32)   # db1 = dH1^T 1: 12 v_mfma_f32_16x16x32_bf16 per tile and net
+        out = dict(bound="mfma", arith="bf16x3",
+                   kernel=("navppo_mlp64_bf16x3_update_epoch (mlp64_pass_both_x3s + reduce_adam)" if sched else
+                           "navppo_mlp64_bf16x3_update_epoch (mlp64_pass_both_x3 + reduce_adam)"),
+                   achieved=round(mfma_flop / ms / 1e9, 1), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s (bf16 MFMA, executed)",
+                   frac=round(mfma_flop / ms / 1e9 / MFMA_BF16_PEAK_TF, 4), epoch_us=round(ms * 1e3, 1), flop_per_epoch=mfma_flop, samples=T * N,
+                   traffic=None, f32_equivalent=f32_equiv, split_obs_us_per_update=round(split_ms * 1e3, 1))
+        if sched:
+            out["detail"] = ("float32 products from operands split into three bf16 pieces, six piece products each on the bf16 MFMA, float32 "
+                             "accumulate (float32-equivalent: tests/test_gpu_bf16x3.py).  Round 6 (csrc/ppo_mlp64_x3s.h): one hand-placed stream per "
+                             "wave, 4 waves x 512 registers, every operand split once and transposed as bf16 pieces through LDS "
+                             "(ds_read_b64_tr_b16); per 32-sample tile and net 156 + 36 MFMAs (5,568 cycles: SQ_VALU_MFMA_BUSY = 48 % of the "
+                             "launch) beside ~1,200 vector and ~270 LDS instructions; the clock settles at ~2.0 GHz under this stream "
+                             "(2.2 under round 5's, 2.4 under the f32 pass) -- profiles/r06_x3s_pmc.txt")
+        else:
+            out["detail"] = ("float32 products from operands split into three bf16 pieces, six piece products each on the bf16 MFMA, float32 "
+                             "accumulate (float32-equivalent: tests/test_gpu_bf16x3.py).  Round 5's compiler-scheduled pass (8 waves at 16 columns; "
+                             "42-column rows -- 48 on chip, 252 MFMAs per tile and net -- 4 waves x 512 registers): 180 MFMAs beside ~1,465 vector "
+                             "instructions at 16 columns, SQ_VALU_MFMA_BUSY = 33 % of the launch -- profiles/r05_bf16x3_pmc.txt")
+    if not x3:
         out["detail"] = ("f32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): 14,336 MFMA cycles + ~575 vector instructions per 32-sample "
                          "tile and net at D = 16; f32 MFMA and VALU share the SIMD's FMA lanes, the loop sustains ~2.2 GHz")
     return out

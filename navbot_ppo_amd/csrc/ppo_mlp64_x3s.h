@@ -72,7 +72,6 @@ static_assert(sizeof(SmemS::img) / SW >= 96 * 64 * sizeof(float), "lane partials
 
 // the vector unit may read / overwrite these accumulators from here on (8-pass XDL write -> VALU: 11 wait states)
 __device__ __forceinline__ void settle(f32x16& a, f32x16& b) { asm volatile("s_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void settle_a(f32x16& a, f32x16& b) { asm volatile("s_nop 7\n\ts_nop 3" : "+a"(a), "+a"(b)); }   // (accumulators in AGPRs)
 
 // (a, b) -> p0 and the residuals: 5 instructions
 __device__ __forceinline__ void split_a(unsigned& p0, float& ra, float& rb, const float a, const float b) {
@@ -95,14 +94,16 @@ __device__ __forceinline__ void split_b(unsigned& p1, unsigned& p2, const float 
                  : "=&v"(p1), "=&v"(p2), "=&v"(t0), "=&v"(t1) : "v"(ra), "v"(rb));
 }
 // four accumulator registers: x = relu(x + b) -- 8 instructions (v_max_i32 on the bit pattern: relu_bits)
-__device__ __forceinline__ void bias_relu4(f32x16& c, const int g, const v4f b) {
-    float x0 = c[4 * g], x1 = c[4 * g + 1], x2 = c[4 * g + 2], x3 = c[4 * g + 3];
-    asm volatile("v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %7\n\t"
+// (accumulator values live on as SCALARS behind the MFMA chain: writing an asm result back into an element of the 16-register
+// tuple costs a v_mov per value)
+__device__ __forceinline__ void bias_relu4(float (&h)[16], const f32x16& c, const int g, const v4f b) {
+    float y0, y1, y2, y3;   // fresh outputs, not tied to the tuple's registers (a tied operand costs a v_mov per value)
+    asm volatile("v_add_f32 %0, %4, %8\n\tv_add_f32 %1, %5, %9\n\tv_add_f32 %2, %6, %10\n\tv_add_f32 %3, %7, %11\n\t"
                  "v_max_i32 %0, %0, 0\n\tv_max_i32 %1, %1, 0\n\tv_max_i32 %2, %2, 0\n\tv_max_i32 %3, %3, 0"
-                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
-    c[4 * g] = x0; c[4 * g + 1] = x1; c[4 * g + 2] = x2; c[4 * g + 3] = x3;
+                 : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+                 : "v"(c[4 * g]), "v"(c[4 * g + 1]), "v"(c[4 * g + 2]), "v"(c[4 * g + 3]), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+    h[4 * g] = y0; h[4 * g + 1] = y1; h[4 * g + 2] = y2; h[4 * g + 3] = y3;
 }
-
 // one value of the head's backward: h = H2 (>= 0) -> dH2 in place; the lane's partial sums  (7 / 5 instructions)
 //   pw3 += h g3 ; pw4 += h g4 ; d = g3 w3 + g4 w4 (fma(g3, w3, g4 w4)) ; h = h > 0 ? d : 0 ; pb2 += h
 template <bool ACTOR>
@@ -127,17 +128,18 @@ __device__ __forceinline__ void dh2_value(float& h, float& pw3, float& pw4, floa
                      : "+v"(h), "+v"(pw3), "+v"(pb2), "=&v"(d) : "v"(g3), "v"(w3) : "vcc");
 }
 
-// x_k = (bf16 half k of the words (w0, w1) != 0) ? x_k : 0 -- the relu mask from packed leading pieces: 8 instructions
-__device__ __forceinline__ void mask4(float& x0, float& x1, float& x2, float& x3, const unsigned w0, const unsigned w1) {
-    asm volatile("v_cmp_ne_u16 vcc, 0, %4\n\t"
-                 "v_cndmask_b32 %0, 0, %0, vcc\n\t"
-                 "v_cmp_lt_u32 vcc, 0xffff, %4\n\t"
-                 "v_cndmask_b32 %1, 0, %1, vcc\n\t"
-                 "v_cmp_ne_u16 vcc, 0, %5\n\t"
-                 "v_cndmask_b32 %2, 0, %2, vcc\n\t"
-                 "v_cmp_lt_u32 vcc, 0xffff, %5\n\t"
-                 "v_cndmask_b32 %3, 0, %3, vcc"
-                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(w0), "v"(w1) : "vcc");
+// y_k = (bf16 half k of the words (w0, w1) != 0) ? x_k : 0 -- the relu mask from packed leading pieces: 8 instructions
+__device__ __forceinline__ void mask4(float& y0, float& y1, float& y2, float& y3, const float x0, const float x1, const float x2,
+                                      const float x3, const unsigned w0, const unsigned w1) {
+    asm volatile("v_cmp_ne_u16 vcc, 0, %8\n\t"
+                 "v_cndmask_b32 %0, 0, %4, vcc\n\t"
+                 "v_cmp_lt_u32 vcc, 0xffff, %8\n\t"
+                 "v_cndmask_b32 %1, 0, %5, vcc\n\t"
+                 "v_cmp_ne_u16 vcc, 0, %9\n\t"
+                 "v_cndmask_b32 %2, 0, %6, vcc\n\t"
+                 "v_cmp_lt_u32 vcc, 0xffff, %9\n\t"
+                 "v_cndmask_b32 %3, 0, %7, vcc"
+                 : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w0), "v"(w1) : "vcc");
 }
 
 struct P3 {   // one k-step's operand: eight values as three packed pieces
@@ -280,14 +282,10 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
     struct G1Ops {
         P3 da[4];
     };
-    auto g1_gather = [&](G1Ops& o) {
-        int hb0 = h_base0, hb1 = h_base1;
-        asm volatile("" : "+v"(hb0), "+v"(hb1));   // the eight gather addresses are formed here, per tile: not hoisted into eight registers
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                o.da[u].p[i] = cat(tr_read(smb + (hb0 ^ (u << 5)) + IMG_D + i * kPieceB), tr_read(smb + (hb1 ^ (u << 5)) + IMG_D + i * kPieceB));
+    // pair q of 0..11: (unit tile u = q / 3, piece i = q % 3) -- two 8-byte gathers; the caller spreads the twelve over MFMA slots
+    auto g1_gather_pair = [&](G1Ops& o, const int q, const int hb0, const int hb1) {
+        const int u = q / 3, i = q % 3;
+        o.da[u].p[i] = cat(tr_read(smb + (hb0 ^ (u << 5)) + IMG_D + i * kPieceB), tr_read(smb + (hb1 ^ (u << 5)) + IMG_D + i * kPieceB));
     };
     auto g1_step = [&](const int k, const G1Ops& o, const u32x4 (&xb)[3], const bool guard = false) {
         const int t1 = k / 18, q = k % 18, u = 2 * t1 + (q & 1), e = q >> 1;   // e of 0..8: the pair's e-th product
@@ -315,7 +313,7 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
     struct SplitState {
         float ra[4], rb[4];
     };
-    auto split_block = [&](const f32x16& c, const int j, const int b, P3& q, SplitState& ss) {
+    auto split_block = [&](const float (&c)[16], const int j, const int b, P3& q, SplitState& ss) {
         const int pr = b >> 1;
         if ((b & 1) == 0) {
             unsigned p0;
@@ -367,34 +365,36 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
             wn[1][i] = ldw(&sm.W2p[0][0][0], 1, 0, i);
         }
         settle(c1[0], c1[1]);
+        float h1[2][16];   // H1 = relu(b1 + ..): the values the split reads
         {
             v4f bn = ldv(sm.b1, 0, 0);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {   // (t, g) = (q >> 2, q & 3); the next group's bias is requested before this one is used
                 const v4f bc = bn;
                 if (q < 7) bn = ldv(sm.b1, (q + 1) >> 2, (q + 1) & 3);
-                bias_relu4(c1[q >> 2], q & 3, bc);
+                bias_relu4(h1[q >> 2], c1[q >> 2], q & 3, bc);
             }
         }
 
         // ================================================================ F2: H2^T = relu(b2 + W2 H1^T); H1 split once, k-step s = (t1, j)
         f32x16 c2[2];
+        G1Ops g1o;
         {
             P3 hb[4];
-            u32x4 wk[4][2];   // the leading weight pieces of every k-step, kept for the big terms
+            u32x4 wk[4][2];   // the leading weight pieces again, for the big terms: requested behind k-step 3 (its slots carry no split)
             SplitState ss;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) split_block(c1[0], 0, b, hb[0], ss);   // k-step 0: nothing to hide it behind
+            for (int b = 0; b < 8; ++b) split_block(h1[0], 0, b, hb[0], ss);   // k-step 0: nothing to hide it behind
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 u32x4 w[2][3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { w[0][i] = wn[0][i]; w[1][i] = wn[1][i]; }
-                wk[s][0] = w[0][0]; wk[s][1] = w[1][0];
                 // the stream of k-step s: 10 MFMAs; behind them the split of k-step s + 1 (8 blocks), this step's piece stores and the
                 // next step's weight rows
                 auto filler = [&](const int slot) {
-                    if (s < 3 && slot >= 1 && slot <= 8) split_block(c1[(s + 1) >> 1], (s + 1) & 1, slot - 1, hb[s + 1], ss);
+                    if (s < 3 && slot >= 1 && slot <= 8) split_block(h1[(s + 1) >> 1], (s + 1) & 1, slot - 1, hb[s + 1], ss);
+                    if (s == 3 && slot < 8) wk[slot >> 1][slot & 1] = ldw(&sm.W2p[0][0][0], slot & 1, slot >> 1, 0);
                     if (s < 3 && (slot == 0 || slot == 4 || slot == 9)) {
                         const int i = slot == 0 ? 0 : slot == 4 ? 1 : 2;
                         wn[0][i] = ldw(&sm.W2p[0][0][0], 0, s + 1, i);
@@ -415,26 +415,31 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
                 X3S_MFMA32_V_AV(c2[0], w[0][0], hb[s].p[1]); filler(8);
                 X3S_MFMA32_V_AV(c2[1], w[1][0], hb[s].p[1]); filler(9);
             }
+            // the big terms; behind them the operand gathers of the PREVIOUS tile's G1 (its dH1 pieces are still in imgD)
+            int hb0 = h_base0, hb1 = h_base1;
+            asm volatile("" : "+v"(hb0), "+v"(hb1));   // the eight gather addresses are formed here, per tile: not hoisted into eight registers
+            int gq = 0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {   // the big terms
+            for (int s = 0; s < 4; ++s) {
                 X3S_MFMA32_V_AV(c2[0], wk[s][0], hb[s].p[0]);
+                g1_gather_pair(g1o, gq++, hb0, hb1); g1_gather_pair(g1o, gq++, hb0, hb1);
                 X3S_MFMA32_V_AV(c2[1], wk[s][1], hb[s].p[0]);
+                g1_gather_pair(g1o, gq++, hb0, hb1);
             }
         }
         settle(c2[0], c2[1]);
 
         // ================================================================ heads, loss, dH2 (in place), the lane's share of db2 / dW3 / dW4;
-        // behind the vector work: G1 of the PREVIOUS tile (its dH1 pieces are still in imgD), 36 MFMAs placed one by one
-        G1Ops g1o;
-        g1_gather(g1o);
+        // behind the vector work: G1 of the PREVIOUS tile, 36 MFMAs placed one by one
         int g1k = 0;
+        float h2[2][16];   // H2, then dH2 in place
         {
             v4f bn = ldv(sm.b2, 0, 0);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const v4f bc = bn;
                 if (q < 7) bn = ldv(sm.b2, (q + 1) >> 2, (q + 1) & 3);
-                bias_relu4(c2[q >> 2], q & 3, bc);
+                bias_relu4(h2[q >> 2], c2[q >> 2], q & 3, bc);
                 g1_step(g1k++, g1o, xb);
                 g1_step(g1k++, g1o, xb);
             }
@@ -447,12 +452,12 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const v4f w = ldv(sm.w3, t, g);
-                    z3 = fmaf(c2[t][4 * g], w.x, z3); z3 = fmaf(c2[t][4 * g + 1], w.y, z3);
-                    z3 = fmaf(c2[t][4 * g + 2], w.z, z3); z3 = fmaf(c2[t][4 * g + 3], w.w, z3);
+                    z3 = fmaf(h2[t][4 * g], w.x, z3); z3 = fmaf(h2[t][4 * g + 1], w.y, z3);
+                    z3 = fmaf(h2[t][4 * g + 2], w.z, z3); z3 = fmaf(h2[t][4 * g + 3], w.w, z3);
                     if (ACTOR) {
                         const v4f v = ldv(sm.w4, t, g);
-                        z4 = fmaf(c2[t][4 * g], v.x, z4); z4 = fmaf(c2[t][4 * g + 1], v.y, z4);
-                        z4 = fmaf(c2[t][4 * g + 2], v.z, z4); z4 = fmaf(c2[t][4 * g + 3], v.w, z4);
+                        z4 = fmaf(h2[t][4 * g], v.x, z4); z4 = fmaf(h2[t][4 * g + 1], v.y, z4);
+                        z4 = fmaf(h2[t][4 * g + 2], v.z, z4); z4 = fmaf(h2[t][4 * g + 3], v.w, z4);
                     }
                 }
             z3 += __shfl_xor(z3, 32, 64);
@@ -504,9 +509,7 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g + j;
-                    float h = c2[t][r];
-                    dh2_value<ACTOR>(h, pw3[t][r], pw4[t][r], pb2[t][r], g3, g4, wv3[j], wv4[j]);
-                    c2[t][r] = h;
+                    dh2_value<ACTOR>(h2[t][r], pw3[t][r], pw4[t][r], pb2[t][r], g3, g4, wv3[j], wv4[j]);
                     if (g1k < 36 && (j & 1)) g1_step(g1k++, g1o, xb);
                 }
                 if (g1k < 36 && (g & 1)) g1_step(g1k++, g1o, xb);
@@ -515,7 +518,9 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
         while (g1k < 36) g1_step(g1k++, g1o, xb);   // (none left: 16 + 16 + 4)
 
         // ================================================================ B2: dH1^T = (W2^T dH2^T) . [H1 > 0]; dH2 split once, k-step s = (t2, j)
-        f32x16 c3[2];   // accumulated in AGPRs: the vector registers are full here (lane partials, H1 for the mask, dH2 and its pieces)
+        f32x16 c3[2];
+        P3 hB[2][2], dA[2][2];   // G2's operands, [unit tile][sample k-step]: gathered behind B2's stream
+        u32x2 mw[8];           // the leading piece of H1 at the lane's own slots: the relu mask of layer 1
         {
             P3 db[4];
             u32x4 wk[4][2];
@@ -526,15 +531,26 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
                 wn[1][i] = ldw(&sm.W2Tp[0][0][0], 1, 0, i);
             }
 #pragma unroll
-            for (int b = 0; b < 8; ++b) split_block(c2[0], 0, b, db[0], ss);
+            for (int b = 0; b < 8; ++b) split_block(h2[0], 0, b, db[0], ss);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 u32x4 w[2][3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { w[0][i] = wn[0][i]; w[1][i] = wn[1][i]; }
-                wk[s][0] = w[0][0]; wk[s][1] = w[1][0];
                 auto filler = [&](const int slot) {
-                    if (s < 3 && slot >= 1 && slot <= 8) split_block(c2[(s + 1) >> 1], (s + 1) & 1, slot - 1, db[s + 1], ss);
+                    if (s < 3 && slot >= 1 && slot <= 8) split_block(h2[(s + 1) >> 1], (s + 1) & 1, slot - 1, db[s + 1], ss);
+                    if (s == 3 && slot < 8) wk[slot >> 1][slot & 1] = ldw(&sm.W2Tp[0][0][0], slot & 1, slot >> 1, 0);
+                    // H1's side of G2 (imgH is complete since F2): pair q = (t, sk, i) of 0..11, three per k-step
+                    if (slot == 2 || slot == 5 || slot == 8) {
+                        const int q = 3 * s + (slot - 2) / 3, t = q / 6, sk = (q / 3) & 1, i = q % 3;
+                        hB[t][sk].p[i] = cat(tr_read(smb + g_off(t, sk, 0) + IMG_H + i * kPieceB), tr_read(smb + g_off(t, sk, 1) + IMG_H + i * kPieceB));
+                    }
+                    if (s == 3 && (slot == 3 || slot == 4 || slot == 6 || slot == 7)) {   // the mask words: two 8-byte reads per slot
+                        const int k0 = 2 * (slot - 3 - (slot > 4));
+#pragma unroll
+                        for (int k = k0; k < k0 + 2; ++k)
+                            mw[k] = *reinterpret_cast<const u32x2*>(smb + st_off(k >> 2, (k >> 1) & 1, k & 1) + IMG_H);
+                    }
                     if (s < 3 && (slot == 0 || slot == 4 || slot == 9)) {
                         const int i = slot == 0 ? 0 : slot == 4 ? 1 : 2;
                         wn[0][i] = ldw(&sm.W2Tp[0][0][0], 0, s + 1, i);
@@ -542,23 +558,31 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
                     }
                     if (slot == 9) store_pieces(IMG_D, s >> 1, s & 1, db[s]);
                 };
-                if (s == 0) { X3S_MFMA32_AZ_AV(c3[0], w[0][2], db[s].p[0]); } else { X3S_MFMA32_A_AV(c3[0], w[0][2], db[s].p[0]); }
+                if (s == 0) { X3S_MFMA32_VZ_AV(c3[0], w[0][2], db[s].p[0]); } else { X3S_MFMA32_V_AV(c3[0], w[0][2], db[s].p[0]); }
                 filler(0);
-                if (s == 0) { X3S_MFMA32_AZ_AV(c3[1], w[1][2], db[s].p[0]); } else { X3S_MFMA32_A_AV(c3[1], w[1][2], db[s].p[0]); }
+                if (s == 0) { X3S_MFMA32_VZ_AV(c3[1], w[1][2], db[s].p[0]); } else { X3S_MFMA32_V_AV(c3[1], w[1][2], db[s].p[0]); }
                 filler(1);
-                X3S_MFMA32_A_AV(c3[0], w[0][1], db[s].p[1]); filler(2);
-                X3S_MFMA32_A_AV(c3[1], w[1][1], db[s].p[1]); filler(3);
-                X3S_MFMA32_A_AV(c3[0], w[0][0], db[s].p[2]); filler(4);
-                X3S_MFMA32_A_AV(c3[1], w[1][0], db[s].p[2]); filler(5);
-                X3S_MFMA32_A_AV(c3[0], w[0][1], db[s].p[0]); filler(6);
-                X3S_MFMA32_A_AV(c3[1], w[1][1], db[s].p[0]); filler(7);
-                X3S_MFMA32_A_AV(c3[0], w[0][0], db[s].p[1]); filler(8);
-                X3S_MFMA32_A_AV(c3[1], w[1][0], db[s].p[1]); filler(9);
+                X3S_MFMA32_V_AV(c3[0], w[0][1], db[s].p[1]); filler(2);
+                X3S_MFMA32_V_AV(c3[1], w[1][1], db[s].p[1]); filler(3);
+                X3S_MFMA32_V_AV(c3[0], w[0][0], db[s].p[2]); filler(4);
+                X3S_MFMA32_V_AV(c3[1], w[1][0], db[s].p[2]); filler(5);
+                X3S_MFMA32_V_AV(c3[0], w[0][1], db[s].p[0]); filler(6);
+                X3S_MFMA32_V_AV(c3[1], w[1][1], db[s].p[0]); filler(7);
+                X3S_MFMA32_V_AV(c3[0], w[0][0], db[s].p[1]); filler(8);
+                X3S_MFMA32_V_AV(c3[1], w[1][0], db[s].p[1]); filler(9);
             }
+            int dq = 0;   // dH2's side of G2 behind the big terms (every piece store of imgD is issued): pair q = (t, sk, i)
+            auto gather_d = [&]() {
+                const int t = dq / 6, sk = (dq / 3) & 1, i = dq % 3;
+                dA[t][sk].p[i] = cat(tr_read(smb + g_off(t, sk, 0) + IMG_D + i * kPieceB), tr_read(smb + g_off(t, sk, 1) + IMG_D + i * kPieceB));
+                ++dq;
+            };
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                X3S_MFMA32_A_AV(c3[0], wk[s][0], db[s].p[0]);
-                X3S_MFMA32_A_AV(c3[1], wk[s][1], db[s].p[0]);
+                X3S_MFMA32_V_AV(c3[0], wk[s][0], db[s].p[0]);
+                gather_d(); gather_d();
+                X3S_MFMA32_V_AV(c3[1], wk[s][1], db[s].p[0]);
+                gather_d();
             }
         }
 
@@ -566,38 +590,23 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
         // transposed from the piece images; behind it: the relu mask of layer 1 on dH1, its split, its piece stores (into imgD: every
         // gather of dH2 is issued before the first of them)
         {
-            P3 hB[2][2], dA[2][2];   // [unit tile][sample k-step s]
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        dA[t][s].p[i] = cat(tr_read(smb + g_off(t, s, 0) + IMG_D + i * kPieceB), tr_read(smb + g_off(t, s, 1) + IMG_D + i * kPieceB));
-                        hB[t][s].p[i] = cat(tr_read(smb + g_off(t, s, 0) + IMG_H + i * kPieceB), tr_read(smb + g_off(t, s, 1) + IMG_H + i * kPieceB));
-                    }
-            settle_a(c3[0], c3[1]);
+            settle(c3[0], c3[1]);
             // [H1 > 0] from the leading piece of H1, read back from the lane's own slots of the image (keeping H1 itself would hold 32
             // vector registers through F2 / B2, where the file is full): bf16(H1) != 0.  Differs from H1 > 0 only for
             // 0 < H1 < 2^-126 (the bf16 conversion flushes / rounds such values to zero) -- not a value a sum of O(1) terms takes.
+            float d1[2][16];   // dH1 = (W2^T dH2^T) . [H1 > 0]
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const u32x2 w = *reinterpret_cast<const u32x2*>(smb + st_off(t, j, b) + IMG_H);
-                        float x0 = c3[t][8 * j + 4 * b], x1 = c3[t][8 * j + 4 * b + 1], x2 = c3[t][8 * j + 4 * b + 2], x3 = c3[t][8 * j + 4 * b + 3];
-                        mask4(x0, x1, x2, x3, w.x, w.y);
-                        c3[t][8 * j + 4 * b] = x0; c3[t][8 * j + 4 * b + 1] = x1; c3[t][8 * j + 4 * b + 2] = x2; c3[t][8 * j + 4 * b + 3] = x3;
-                    }
+            for (int k = 0; k < 8; ++k) {   // k = (t, j, b): registers 8 j + 4 b .. + 3 of c3[t]
+                const int t = k >> 2, r0 = 8 * ((k >> 1) & 1) + 4 * (k & 1);
+                mask4(d1[t][r0], d1[t][r0 + 1], d1[t][r0 + 2], d1[t][r0 + 3], c3[t][r0], c3[t][r0 + 1], c3[t][r0 + 2], c3[t][r0 + 3], mw[k].x, mw[k].y);
+            }
             P3 eb[4];
             SplitState ss;
             int blk = 0;   // 32 split blocks + 4 x 6 stores behind 48 MFMAs
             auto filler = [&]() {
                 if (blk < 32) {
                     const int s = blk >> 3;
-                    split_block(c3[s >> 1], s & 1, blk & 7, eb[s], ss);
+                    split_block(d1[s >> 1], s & 1, blk & 7, eb[s], ss);
                     if ((blk & 7) == 7) store_pieces(IMG_D, s >> 1, s & 1, eb[s]);
                 }
                 ++blk;
@@ -623,7 +632,8 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
     if (have_prev) {   // G1 of the last tile
         const u32x4 xb[3] = {xbn[0], xbn[1], xbn[2]};
         G1Ops g1o;
-        g1_gather(g1o);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) g1_gather_pair(g1o, q, h_base0, h_base1);
 #pragma unroll
         for (int k = 0; k < 36; ++k) g1_step(k, g1o, xb, true);
     }
