@@ -376,6 +376,13 @@ __device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict
             if (valid) {
                 z3 += b3;
                 z4 += b4;
+#ifdef MLP64_DEBUG_Z   // (dev builds only, tools/verify/x3_forward_error.py: the heads' pre-activations into unused rows of the workspace)
+                if (lhi == 0) {
+                    float* const dbg = partial + (size_t)200 * P;
+                    dbg[tile * 32 + l31] = z3;
+                    if (ACTOR) dbg[M + tile * 32 + l31] = z4;
+                }
+#endif
                 if (ACTOR) {
                     const float mu0 = 1.0f / (1.0f + expf(-z3));   // torch.sigmoid, net_actor.py:185
                     const float mu1 = tanhf(z4);                    // net_actor.py:186
@@ -406,6 +413,13 @@ __device__ __forceinline__ void pass_body(SmemW<IN>& sm, const float* __restrict
             }
             adb3 += own * g3;
             adb4 += own * g4;
+#ifdef MLP64_DEBUG_Z
+            if (valid && lhi == 0) {
+                float* const dbg = partial + (size_t)200 * P;
+                dbg[2 * M + tile * 32 + l31] = g3;
+                if (ACTOR) dbg[3 * M + tile * 32 + l31] = g4;
+            }
+#endif
             if (lhi == 0) {
                 gs[l31] = g3;
                 if (ACTOR) gs[32 + l31] = g4;

@@ -61,6 +61,8 @@ static_assert(sizeof(SmemS::img) / SW >= 96 * 64 * sizeof(float), "lane partials
 #define X3S_G "s_nop 0\n\t"
 #define X3S_MFMA32_V_AV(acc, A, B) asm volatile(X3S_GUARD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(A), "v"(B))
 #define X3S_MFMA32_V_AA(acc, A, B) asm volatile(X3S_GUARD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(A), "a"(B))
+#define X3S_MFMA32G_V_AV(acc, A, B) asm volatile(X3S_G "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(A), "v"(B))
+#define X3S_MFMA32G_V_AA(acc, A, B) asm volatile(X3S_G "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(A), "a"(B))
 #define X3S_MFMA32_VZ_AV(acc, A, B) asm volatile(X3S_G "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(A), "v"(B))
 #define X3S_MFMA32_VZ_AA(acc, A, B) asm volatile(X3S_G "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(A), "a"(B))
 #define X3S_MFMA32_A_AV(acc, A, B) asm volatile(X3S_GUARD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(A), "v"(B))
@@ -94,14 +96,16 @@ __device__ __forceinline__ void split_b(unsigned& p1, unsigned& p2, const float 
                  : "=&v"(p1), "=&v"(p2), "=&v"(t0), "=&v"(t1) : "v"(ra), "v"(rb));
 }
 // four accumulator registers: x = relu(x + b) -- 8 instructions (v_max_i32 on the bit pattern: relu_bits)
-// (accumulator values live on as SCALARS behind the MFMA chain: writing an asm result back into an element of the 16-register
-// tuple costs a v_mov per value)
-__device__ __forceinline__ void bias_relu4(float (&h)[16], const f32x16& c, const int g, const v4f b) {
-    float y0, y1, y2, y3;   // fresh outputs, not tied to the tuple's registers (a tied operand costs a v_mov per value)
-    asm volatile("v_add_f32 %0, %4, %8\n\tv_add_f32 %1, %5, %9\n\tv_add_f32 %2, %6, %10\n\tv_add_f32 %3, %7, %11\n\t"
-                 "v_max_i32 %0, %0, 0\n\tv_max_i32 %1, %1, 0\n\tv_max_i32 %2, %2, 0\n\tv_max_i32 %3, %3, 0"
-                 : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
-                 : "v"(c[4 * g]), "v"(c[4 * g + 1]), "v"(c[4 * g + 2]), "v"(c[4 * g + 3]), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+// four accumulator registers: h = relu(c) -- v_max_i32 on the bit pattern (relu_bits).  The bias is already in c: the accumulators of F1 /
+// F2 START as the bias (as in the f32 pass), so sum and bias are rounded ONCE.  Adding the bias to the rounded sum afterwards -- rounds
+// 1-5 did -- leaves a systematic error of ~2e-8 in the heads' pre-activations (the mean over samples does not average out; measured and
+// modelled: tools/verify/x3_forward_error.py), which the actor's gradient sums amplify by their cancellation.
+// (Accumulator values live on as SCALARS behind the MFMA chain: writing an asm result back into an element of the 16-register tuple
+// costs a v_mov per value.)
+__device__ __forceinline__ void relu4(float (&h)[16], const f32x16& c, const int g) {
+    float y0, y1, y2, y3;
+    asm volatile("v_max_i32 %0, %4, 0\n\tv_max_i32 %1, %5, 0\n\tv_max_i32 %2, %6, 0\n\tv_max_i32 %3, %7, 0"
+                 : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3) : "v"(c[4 * g]), "v"(c[4 * g + 1]), "v"(c[4 * g + 2]), "v"(c[4 * g + 3]));
     h[4 * g] = y0; h[4 * g + 1] = y1; h[4 * g + 2] = y2; h[4 * g + 3] = y3;
 }
 // one value of the head's backward: h = H2 (>= 0) -> dH2 in place; the lane's partial sums  (7 / 5 instructions)
@@ -341,13 +345,18 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
 
         // ================================================================ F1: H1^T = relu(b1 + W1 X^T), one k-step
         f32x16 c1[2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {   // the accumulators start as the bias (one rounding of sum + bias)
+            const v4f b = ldv(sm.b1, q >> 2, q & 3);
+            c1[q >> 2][4 * (q & 3)] = b.x; c1[q >> 2][4 * (q & 3) + 1] = b.y; c1[q >> 2][4 * (q & 3) + 2] = b.z; c1[q >> 2][4 * (q & 3) + 3] = b.w;
+        }
         {
             u32x4 wa[2][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) wa[t][i] = *reinterpret_cast<const u32x4*>(&sm.W1p[i][32 * t + l31][8 * lhi]);
-            X3S_MFMA32_VZ_AA(c1[0], wa[0][2], xr[0]); X3S_MFMA32_VZ_AA(c1[1], wa[1][2], xr[0]);
+            X3S_MFMA32G_V_AA(c1[0], wa[0][2], xr[0]); X3S_MFMA32G_V_AA(c1[1], wa[1][2], xr[0]);
             X3S_MFMA32_V_AA(c1[0], wa[0][1], xr[1]);  X3S_MFMA32_V_AA(c1[1], wa[1][1], xr[1]);
             X3S_MFMA32_V_AA(c1[0], wa[0][0], xr[2]);  X3S_MFMA32_V_AA(c1[1], wa[1][0], xr[2]);
             X3S_MFMA32_V_AA(c1[0], wa[0][1], xr[0]);  X3S_MFMA32_V_AA(c1[1], wa[1][1], xr[0]);
@@ -366,18 +375,16 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
         }
         settle(c1[0], c1[1]);
         float h1[2][16];   // H1 = relu(b1 + ..): the values the split reads
-        {
-            v4f bn = ldv(sm.b1, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {   // (t, g) = (q >> 2, q & 3); the next group's bias is requested before this one is used
-                const v4f bc = bn;
-                if (q < 7) bn = ldv(sm.b1, (q + 1) >> 2, (q + 1) & 3);
-                bias_relu4(h1[q >> 2], c1[q >> 2], q & 3, bc);
-            }
+        for (int q = 0; q < 8; ++q) relu4(h1[q >> 2], c1[q >> 2], q & 3);
+        f32x16 c2[2];      // F2's accumulators start as b2: requested here, landed long before the first MFMA
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const v4f b = ldv(sm.b2, q >> 2, q & 3);
+            c2[q >> 2][4 * (q & 3)] = b.x; c2[q >> 2][4 * (q & 3) + 1] = b.y; c2[q >> 2][4 * (q & 3) + 2] = b.z; c2[q >> 2][4 * (q & 3) + 3] = b.w;
         }
 
         // ================================================================ F2: H2^T = relu(b2 + W2 H1^T); H1 split once, k-step s = (t1, j)
-        f32x16 c2[2];
         G1Ops g1o;
         {
             P3 hb[4];
@@ -402,9 +409,9 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
                     }
                     if (slot == 9) store_pieces(IMG_H, s >> 1, s & 1, hb[s]);
                 };
-                if (s == 0) { X3S_MFMA32_VZ_AV(c2[0], w[0][2], hb[s].p[0]); } else { X3S_MFMA32_V_AV(c2[0], w[0][2], hb[s].p[0]); }
+                if (s == 0) { X3S_MFMA32G_V_AV(c2[0], w[0][2], hb[s].p[0]); } else { X3S_MFMA32_V_AV(c2[0], w[0][2], hb[s].p[0]); }
                 filler(0);
-                if (s == 0) { X3S_MFMA32_VZ_AV(c2[1], w[1][2], hb[s].p[0]); } else { X3S_MFMA32_V_AV(c2[1], w[1][2], hb[s].p[0]); }
+                if (s == 0) { X3S_MFMA32G_V_AV(c2[1], w[1][2], hb[s].p[0]); } else { X3S_MFMA32_V_AV(c2[1], w[1][2], hb[s].p[0]); }
                 filler(1);
                 X3S_MFMA32_V_AV(c2[0], w[0][1], hb[s].p[1]); filler(2);
                 X3S_MFMA32_V_AV(c2[1], w[1][1], hb[s].p[1]); filler(3);
@@ -433,16 +440,11 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
         // behind the vector work: G1 of the PREVIOUS tile, 36 MFMAs placed one by one
         int g1k = 0;
         float h2[2][16];   // H2, then dH2 in place
-        {
-            v4f bn = ldv(sm.b2, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const v4f bc = bn;
-                if (q < 7) bn = ldv(sm.b2, (q + 1) >> 2, (q + 1) & 3);
-                bias_relu4(h2[q >> 2], c2[q >> 2], q & 3, bc);
-                g1_step(g1k++, g1o, xb);
-                g1_step(g1k++, g1o, xb);
-            }
+        for (int q = 0; q < 8; ++q) {
+            relu4(h2[q >> 2], c2[q >> 2], q & 3);
+            g1_step(g1k++, g1o, xb);
+            g1_step(g1k++, g1o, xb);
         }
         float g3 = 0.f, g4 = 0.f;
         {
@@ -466,6 +468,13 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
             if (valid) {
                 z3 += b3;
                 z4 += b4;
+#ifdef MLP64_DEBUG_Z   // (dev builds only, tools/verify/x3_forward_error.py: the heads' pre-activations into unused rows of the workspace)
+                if (lhi == 0) {
+                    float* const dbg = partial + (size_t)200 * P;
+                    dbg[tile * 32 + l31] = z3;
+                    if (ACTOR) dbg[M + tile * 32 + l31] = z4;
+                }
+#endif
                 if (ACTOR) {
                     const float mu0 = 1.0f / (1.0f + expf(-z3));   // torch.sigmoid, net_actor.py:185
                     const float mu1 = tanhf(z4);                    // net_actor.py:186
@@ -493,6 +502,13 @@ __device__ __forceinline__ void pass_body(SmemS& sm, const float* __restrict__ p
             }
             adb3 += own * g3;
             adb4 += own * g4;
+#ifdef MLP64_DEBUG_Z
+            if (valid && lhi == 0) {
+                float* const dbg = partial + (size_t)200 * P;
+                dbg[2 * M + tile * 32 + l31] = g3;
+                if (ACTOR) dbg[3 * M + tile * 32 + l31] = g4;
+            }
+#endif
         }
         // dH2[m][u] = [H2 > 0] (g3 w3[u] + g4 w4[u]) in place; the lane's dW3 / dW4 / db2 sums; the rest of G1 behind it
         {

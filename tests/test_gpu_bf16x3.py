@@ -73,24 +73,83 @@ def _errors_vs_float64(n, half, seed, dev, d=16):
     return out
 
 
-@pytest.mark.parametrize("n,d", [(128 * 300 + 7, 16), (1 << 17, 16), (512 * 4096, 16),   # the last one is the bench's own batch
-                                 (128 * 300 + 7, 42), (512 * 4096, 42)])              # 42-column rows: configs[3]'s shard
-def test_bf16x3_error_is_not_above_the_f32_paths_error_against_float64(n, d):
-    """Gradients of both arithmetics against float64 autograd of the same losses (ppo.py:307-349,386) on the same rows -- float32
-    and float16 rows, three seeds -- per parameter tensor, as a fraction of the tensor's gradient scale.
+def _kink_free_errors(n, seed, dev, d=16, half=False, with_torch32=False):
+    """rms / max error per parameter tensor of both arithmetics (and PyTorch's float32 autograd) against float64 autograd on a batch
+    whose samples near a relu / clip kink are replaced (tests/_kinks.py): what is left is arithmetic."""
+    from _kinks import replace_kink_samples
+    a, c = _nets(dev, seed=3 + seed, d=d)
+    batch = _batch(n, 100 + n + seed, dev, half, d)
+    obs, acts, logp, rtg, adv = batch
+    n_kink = replace_kink_samples(a, c, obs, acts, logp, rtg, adv, 0.5)
+    assert n_kink <= 2 + n // 100, n_kink   # the batches are not being edited wholesale (0.4 % at these weights)
+    a64, c64 = copy.deepcopy(a).double(), copy.deepcopy(c).double()
+    al, cl, _, _, _ = ppo.ppo_losses(a64, c64, obs.double(), acts.double(), logp.double(), rtg.double(), adv.double(),
+                                     torch.tensor(0.5, dtype=torch.float64, device=dev), 0.2)
+    g64 = torch.cat([t.reshape(-1) for t in torch.autograd.grad(al + cl, list(a64.parameters()) + list(c64.parameters()))])
+    rows = {}
+    for arith in ("f32", "bf16x3"):
+        up, g, st = _grad(a, c, arith, batch, dev)
+        assert st[0].item() == pytest.approx(al.item(), rel=1e-4, abs=1e-6) and st[4].item() == pytest.approx(cl.item(), rel=1e-4)
+        rows[arith] = g
+    if with_torch32:
+        a32, c32 = copy.deepcopy(a), copy.deepcopy(c)
+        al2, cl2, _, _, _ = ppo.ppo_losses(a32, c32, obs.float(), acts, logp, rtg, adv, torch.tensor(0.5, device=dev), 0.2)
+        rows["torch32"] = torch.cat([t.reshape(-1) for t in torch.autograd.grad(al2 + cl2, list(a32.parameters()) + list(c32.parameters()))])
+    offs = np.cumsum([0] + [q.numel() for q in up.fp.params])
+    out = {}
+    for k, g in rows.items():
+        rms = [(((g64[o:e] - g[o:e].double()) ** 2).mean().sqrt() / (g64[o:e].abs().max() + 1e-300)).item() for o, e in zip(offs[:-1], offs[1:])]
+        mx = [((g64[o:e] - g[o:e].double()).abs().max() / (g64[o:e].abs().max() + 1e-300)).item() for o, e in zip(offs[:-1], offs[1:])]
+        out[k] = (np.array(rms), np.array(mx))
+    return out
 
-    What the comparison can and cannot resolve (tools/bf16x3_error.py, profiles/r05_bf16x3_error.txt, with PyTorch's own float32
-    autograd as a third column): the ARITHMETIC error of either path is a few 1e-8 of a tensor's scale -- half a float32 ulp of
-    its largest entry, the floor for any float32 result -- but every float32 evaluation also differs from float64 by discrete
-    events: a relu unit or, in the actor, a probability ratio within float32 round-off of its kink (1 +- clip) evaluates on the
-    other side, moving a mean-gradient entry by up to ~1e-4 of a small tensor's scale at the bench batch.  The events hit the
-    f32-MFMA path, the split path and PyTorch alike, on different tensors from seed to seed.  So:
-      * on the CRITIC's tensors (no clip kink; relu events are rare and small) the median rms error of the split path over row
-        types and seeds is not above the f32 path's (x 1.2: what a median of 36 values resolves);
-      * over ALL tensors the median is of the same size (x 1.75: actor tensors carry clip events in either path) and below 1.5e-7;
-      * every tensor of the split path stays inside the bound of the autograd tests, 2e-4 of its scale, or within 1.5 x the f32
-        path's own worst tensor (events included);
-      * the loss statistics of the two paths agree to float32 round-off."""
+
+@pytest.mark.parametrize("n,seeds", [(128 * 300 + 7, 6), (512 * 4096, 4)])   # the second one is the bench's own batch
+def test_bf16x3_error_against_float64_is_not_above_the_f32_paths_on_kink_free_batches(n, seeds):
+    """The gate VERDICT round 5 set for `dtype: "f32"` on the split path: gradients of both arithmetics against float64 autograd of
+    the same losses (ppo.py:307-349,386) on KINK-FREE batches -- with the relu / clip events gone the comparison is about arithmetic,
+    no slack for events -- several seeds, rms and max error per parameter tensor as a fraction of the tensor's gradient scale.
+
+    What two float32 evaluations of equal quality can and cannot satisfy (tools/bf16x3_error_kinkfree.py prints the table,
+    profiles/r06_bf16x3_error_kinkfree.txt): per tensor and seed the ratio of their errors scatters between 0.3 and 3 -- half of the
+    14 tensors are vectors or scalars whose error is ONE rounding history -- so "<= 1.0 on every tensor" would fail for the f32 path
+    against itself.  What does hold, deterministically for these seeds, and is asserted:
+      * pooled over tensors and seeds (root of the mean squared rms error) the split path is NOT ABOVE the f32-MFMA path: ratio <= 1.0
+        (measured 0.71 at n = 38,407 and 0.94 / 0.65 at the bench batch with 4 / 8 seeds), and below PyTorch's own float32 autograd
+        -- the reference's arithmetic (0.38 / 0.84);
+      * the worst element error of any tensor and seed is not above the f32 path's worst (7.4e-7 vs 1.3e-6; 3.43e-7 vs 3.47e-7);
+      * no tensor's pooled error is more than 2.5 x the f32 path's (the weight-gradient tensors reach 1.3 - 2 x at the bench batch: a
+        wave of the 4-wave pass sums 64 tiles into its accumulators, a wave of the 8-wave f32 pass 32 -- summation order, not product
+        arithmetic; at 38,407 samples, one or two tiles per wave in both, they are at 0.9 - 1.25).
+    Round 6 found and removed the one systematic term: rounds 4-5 added the layer bias to the ROUNDED matrix product, which leaves a
+    mean error of ~2e-8 in the heads' pre-activations that the actor's gradient sums amplify 50-fold (actor tensors were 2 - 3.5 x the
+    f32 path's error, kink-free); the accumulators now start as the bias, like the f32 pass's (csrc/ppo_mlp64_x3s.h: relu4)."""
+    dev = torch.device("cuda")
+    R = {k: [] for k in ("f32", "bf16x3", "torch32")}
+    M = {k: [] for k in ("f32", "bf16x3", "torch32")}
+    for seed in range(seeds):
+        out = _kink_free_errors(n, seed, dev, with_torch32=True)
+        for k in R:
+            R[k].append(out[k][0])
+            M[k].append(out[k][1])
+    pooled = {k: np.sqrt(np.mean(np.square(np.stack(R[k])), 0)) for k in R}   # per tensor, over seeds
+    tot = {k: float(np.sqrt(np.mean(pooled[k] ** 2))) for k in R}
+    worst = {k: float(np.stack(M[k]).max()) for k in M}
+    print(f"n = {n}, {seeds} seeds, kink-free: pooled rms error / tensor scale  f32-MFMA {tot['f32']:.2e}  bf16x3 {tot['bf16x3']:.2e}  "
+          f"PyTorch float32 {tot['torch32']:.2e};  worst element error {worst['f32']:.2e} / {worst['bf16x3']:.2e} / {worst['torch32']:.2e};  "
+          f"per-tensor ratio bf16x3 / f32: " + " ".join(f"{v:.2f}" for v in pooled["bf16x3"] / pooled["f32"]))
+    assert tot["bf16x3"] <= 1.0 * tot["f32"], (tot["bf16x3"], tot["f32"])
+    assert tot["bf16x3"] <= 1.0 * tot["torch32"], (tot["bf16x3"], tot["torch32"])
+    assert worst["bf16x3"] <= 1.0 * worst["f32"], (worst["bf16x3"], worst["f32"])
+    assert (pooled["bf16x3"] <= 2.5 * pooled["f32"]).all(), pooled["bf16x3"] / pooled["f32"]
+    assert tot["bf16x3"] < 1.5e-7
+
+
+@pytest.mark.parametrize("n,d", [(128 * 300 + 7, 42), (512 * 4096, 42)])   # 42-column rows: configs[3]'s shard (round 5's compiler-scheduled pass)
+def test_bf16x3_error_is_not_above_the_f32_paths_error_against_float64(n, d):
+    """The 42-column rows run round 5's split pass (8 / 4 waves, compiler-scheduled; bias added behind the product): its round-5 gate,
+    unchanged -- medians over row types and seeds on batches WITH their kink events (critic tensors <= 1.2 x the f32 path, all tensors
+    <= 1.75 x and < 1.5e-7), every tensor inside the autograd bound or within 1.5 x the f32 path's worst."""
     dev = torch.device("cuda")
     r32, rx3 = [], []
     for half in (False, True):
@@ -117,7 +176,8 @@ def test_gradients_match_autograd_on_both_arithmetics(n, d, arith):
     batch = _batch(n, n, dev, d=d)
     obs, acts, logp, rtg, adv = batch
     from _kinks import replace_kink_samples
-    replace_kink_samples(a, c, obs, acts, logp, rtg, adv, 0.5)   # (tests/_kinks.py: the bound below is about arithmetic)
+    n_kink = replace_kink_samples(a, c, obs, acts, logp, rtg, adv, 0.5)   # (tests/_kinks.py: the bound below is about arithmetic)
+    assert n_kink <= 2 + n // 100, n_kink   # ... on the batch as drawn, not on one edited wholesale
     up, g, st = _grad(a, c, arith, batch, dev)
     a2, c2 = copy.deepcopy(a), copy.deepcopy(c)
     al, cl, ratios, lp, _ = ppo.ppo_losses(a2, c2, obs, acts, logp, rtg, adv, torch.tensor(0.5, device=dev), 0.2)
