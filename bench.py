@@ -25,6 +25,8 @@ Besides the contract fields, rank 0 adds
   roofline_at_l3 (+ _closed_loop, _open_loop_tape)   the same three with S=1024 per env: 268 MB per step = the Infinity Cache size
   roofline_hbm (+ _closed_loop, _open_loop_tape)     the same three with S=2048 per env: 537 MB per step = 2x the Infinity Cache, the
                       HBM-bound regime; `frac` of the 8 TB/s spec, `frac_of_achievable_hbm` of the ~6.3 TB/s the guide calls achievable
+  cfg4_ppo_shard / cfg5_ppo_shard / cfg5_ppo_shard_resmlp512   the same shards as PPO workloads end to end (rollout + 50 epochs) per GPU on
+                      their own row formats: 42-D float32 rows, 16-D float16 rows; the last one with the reference's ACTIVE 512-wide nets
   cfg4_shard / cfg5_shard    one GPU's shard of BASELINE configs[3] (4096 envs, stage_4, 36 beams) and configs[4] (8192 envs, 2048-segment
                       house map, f16 observations, start / goal tables): us per step (launch per step / tape), env-steps/s
   traffic_source      which rocprofv3 --pmc file the `traffic` fields come from (--with-pmc-file: the same gpurun call as this run)
@@ -288,6 +290,41 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 
 MFMA_F32_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 
 
+def resmlp512_update_roofline(tr, reps=5):
+    """The update kernels of the 512-wide nets alone: HIP events around whole epochs on the trainer's own buffers (the epoch is 8
+    launches on one stream).  `achieved` / `frac` count the ALGORITHMIC float32 FLOP -- 131,072 MACs per sample and net (W1a 16x512,
+    W2a 512x16, W1b 32x512, W2b 512x32, forward + both backward products) -- against the f32-input MFMA peak; `executed` adds the
+    hidden layers the backward kernels recompute instead of storing (155,648 MACs)."""
+    up = tr.updater
+    if not up.fused_resmlp512:
+        return None
+    T, N, D = tr.cfg.rollout_len, tr.env.N, tr.env.D
+    obs, acts = tr.obs_buf[:T].reshape(T * N, D), tr.act_buf.reshape(T * N, 2)
+    logp, rtg = tr.logp_buf.reshape(T * N), tr.rtg_buf.reshape(T * N)
+    adv = torch.randn(T * N, device=obs.device)
+    st = torch.zeros(8, device=obs.device)
+    up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flop = 2 * 2 * 131072 * T * N
+    flop_exec = 2 * 2 * 155648 * T * N
+    return dict(bound="mfma", kernel="navppo_resmlp512_update_epoch (resmlp_fwd<16|32>, resmlp_bwd<16|32>, 3 streaming kernels, reduce+Adam)",
+                achieved=round(flop / ms / 1e9, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4),
+                epoch_ms=round(ms, 3), flop_per_epoch=flop, traffic=None,
+                executed=dict(achieved=round(flop_exec / ms / 1e9, 2), frac=round(flop_exec / ms / 1e9 / MFMA_F32_PEAK_TF, 4), flop_per_epoch=flop_exec,
+                              note="incl. the hidden layers recomputed in the backward kernels (155,648 instead of 131,072 MACs per sample and net)"),
+                detail="algorithmic float32 FLOP against the f32-input MFMA peak.  The products that fill a k-step of v_mfma_f32_16x16x32_bf16 "
+                       "(H, Y of resmlp_fwd<32>; H^T, dH^T, dW2, dW1 of resmlp_bwd<32> on 4 waves x 512 registers; H of resmlp_fwd<16>) run as "
+                       "float32 products from three-piece bf16 splits, the rest on v_mfma_f32_16x16x4_f32 (f32 MFMA and VALU share the SIMD's FMA "
+                       "lanes, the loop sustains ~2.2 GHz)")
+
+
 def resmlp512_leg(n_envs, rollout, epochs, steps=2):
     """SURVEY 8(d) cfg 2 "reported alongside": the reference's ACTIVE nets (net_actor.py:56-144, net_critic.py:50-130) on the
     same workload: fused HIP update (csrc/ppo_resmlp512.hip), rollout in one persistent launch (navsim_rollout_resmlp512: the policy
@@ -306,34 +343,8 @@ def resmlp512_leg(n_envs, rollout, epochs, steps=2):
         u += lg["update_time"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # the update kernels alone: HIP events around whole epochs on the trainer's buffers (the epoch is 8 launches on one stream)
-    roof = None
     up = tr.updater
-    if up.fused_resmlp512:
-        T, N, D = rollout, n_envs, env.D
-        obs, acts = tr.obs_buf[:T].reshape(T * N, D), tr.act_buf.reshape(T * N, 2)
-        logp, rtg = tr.logp_buf.reshape(T * N), tr.rtg_buf.reshape(T * N)
-        adv = torch.randn(T * N, device=obs.device)
-        st = torch.zeros(8, device=obs.device)
-        up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
-        e0.record()
-        for _ in range(reps):
-            up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        flop = 2 * 2 * 155648 * T * N   # both nets; 155,648 MACs per sample incl. the hidden layer recomputed in the backward pass
-        roof = dict(bound="mfma", kernel="navppo_resmlp512_update_epoch (resmlp_fwd<16|32>, resmlp_bwd<16|32>, 3 streaming kernels, "
-                    "reduce+Adam)", achieved=round(flop / ms / 1e9, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                    frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4), epoch_ms=round(ms, 3), flop_per_epoch=flop, traffic=None,
-                    detail="f32-input MFMA (v_mfma_f32_16x16x4_f32); f32 MFMA and VALU share the SIMD's FMA lanes and the loop "
-                           "sustains ~2.2 GHz, so ~0.85 of the nominal peak is the practical ceiling.  Since round 5 the products that fill a k-step of "
-                           "v_mfma_f32_16x16x32_bf16 (H, Y of resmlp_fwd<32>; H^T, dH^T, dW2, dW1 of resmlp_bwd<32> on 4 waves x 512 registers; "
-                           "H of resmlp_fwd<16>) run as float32 products from three-piece bf16 splits -- `achieved` stays the algorithmic "
-                           "float32 FLOP against the f32-MFMA peak")
+    roof = resmlp512_update_roofline(tr)
     env.close()
     return dict(policy="resmlp512", value=round(steps * rollout * n_envs / dt, 1), unit="env-steps/s", steps=steps,
                 ms_per_step=round(dt / steps * 1e3, 2), rollout_ms=round(r / steps * 1e3, 2), update_ms=round(u / steps * 1e3, 2),
@@ -342,14 +353,14 @@ def resmlp512_leg(n_envs, rollout, epochs, steps=2):
                 update="fused MFMA kernels (products that fill a bf16 k-step as bf16x3 float32 products, the rest on the f32-input MFMA)" if up.fused_resmlp512 else "PyTorch-ROCm", update_roofline=roof)
 
 
-def ppo_shard_leg(n_envs, world, n_beams, obs_f16, sampler, rollout, epochs, detail, steps=2):
+def ppo_shard_leg(n_envs, world, n_beams, obs_f16, sampler, rollout, epochs, detail, steps=2, policy="mlp64x2"):
     """One GPU's shard of a BASELINE 8-GPU configuration as a PPO workload, end to end: the same timed
     region as the driver line -- persistent HIP rollout on the shard's own observation format (42-D rows with 36 beams, float16
     rows), return scan, V0, advantage normalisation and all epochs of the fused D-64-64 update -- env-steps/s of ONE GPU."""
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
     env = VecEnv(n_envs, map=world, n_beams=n_beams, max_episode_steps=500, seed=0, obs_f16=obs_f16, sampler=sampler)
-    tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=rollout, n_updates_per_iteration=epochs, policy="mlp64x2", seed=0))
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=rollout, n_updates_per_iteration=epochs, policy=policy, seed=0))
     tr.iteration()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -362,6 +373,18 @@ def ppo_shard_leg(n_envs, world, n_beams, obs_f16, sampler, rollout, epochs, det
     dt = time.perf_counter() - t0
     inf = env.sim.info()
     D = env.D
+    if policy == "resmlp512":   # the reference's ACTIVE nets on the shard's own row type (round 6: float16 rows through the 512-wide kernels)
+        out = dict(workload=f"{n_envs} envs, {world} ({env.sim.S} segments, shared map), {n_beams} beams, {D}-D "
+                            f"{'float16' if obs_f16 else 'float32'} rows, PPO resmlp512 (NetActor / NetCritic), rollout={rollout}, {epochs} full-batch epochs",
+                   value=round(steps * rollout * n_envs / dt, 1), unit="env-steps/s per GPU", steps=steps,
+                   ms_per_step=round(dt / steps * 1e3, 3), rollout_ms=round(r / steps * 1e3, 3), update_ms=round(u / steps * 1e3, 3),
+                   rollout_us_per_step=round(r / steps / rollout * 1e6, 2),
+                   rollout="persistent kernel (navsim_rollout_resmlp512)" if tr.uses_persistent_rollout else "hipGraph of per-step launches",
+                   update="navppo_resmlp512_update_epoch" if tr.updater.fused_resmlp512 else "PyTorch-ROCm",
+                   update_roofline=resmlp512_update_roofline(tr, reps=3),
+                   last_iter={k: lg[k] for k in ("avg_ep_rews", "success_rate", "episodes")}, bound_detail=detail)
+        env.close()
+        return out
     roof = mlp64_update_roofline(tr, reps=10)
     roof_f32 = mlp64_update_roofline(tr, reps=10, arith="f32") if roof and roof["arith"] != "f32" else None   # same buffers, same weights
     out = dict(workload=f"{n_envs} envs, {world} ({env.sim.S} segments, shared map), {n_beams} beams, {D}-D "
@@ -761,6 +784,11 @@ def main():
         out["cfg5_ppo_shard"] = ppo_shard_leg(8192, "house", 10, True, "small_house", args.rollout, args.epochs,
                                               "BASELINE configs[4] per GPU: 65536 / 8 envs, 2048-segment house map, start / goal tables, "
                                               "float16 observation buffers")
+        # ... and configs[4]'s shard with the policy the reference actually runs (round 6: the 512-wide kernels read float16 rows)
+        out["cfg5_ppo_shard_resmlp512"] = ppo_shard_leg(8192, "house", 10, True, "small_house", args.rollout, args.epochs,
+                                                        "BASELINE configs[4] per GPU with the reference's ACTIVE nets (net_actor.py:56-144): float16 "
+                                                        "observation buffers read by navsim_rollout_resmlp512 / navppo_resmlp512_*", steps=1,
+                                                        policy="resmlp512")
         if ctx.world == 1:
             ttr = time_to_reward(n_local)
             out["time_to_reward_s"] = ttr["seconds"]

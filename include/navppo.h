@@ -13,8 +13,9 @@
  * arithmetic behind the load is float32 either way.
  *
  * All pointers are DEVICE pointers owned by the caller; calls are asynchronous on `stream` (hipStream_t as void*);
- * return 0 or a negative code, message in navppo_last_error().  float32 arithmetic throughout (f32-input MFMA: exact f32 fma
- * chains); no CPU fallback.  Alignment: params_dev / actor_params_dev 16 bytes, act_dev 8 bytes, obs_dev 16 bytes for
+ * return 0 or a negative code, message in navppo_last_error().  float32 arithmetic throughout (navppo_mlp64_*: f32-input MFMA, exact
+ * f32 fma chains; navppo_mlp64_bf16x3_* and navppo_resmlp512_*: float32 products from three bf16 pieces per operand, see there);
+ * no CPU fallback.  Alignment: params_dev / actor_params_dev 16 bytes, act_dev 8 bytes, obs_dev 16 bytes for
  * 16 columns, 8 bytes for 42 float32 columns, 4 bytes for 42 float16 columns (torch allocations are 256-byte aligned),
  * checked at the call.
  */
@@ -143,8 +144,11 @@ int navppo_mlp64_act(const float* actor_params_dev, const void* obs_dev, int32_t
 /* ------------------------------------------------------------------------------------------------------------------------
  * The reference's ACTIVE nets ("resmlp512"): NetActor / NetCritic (project_ppo/src/net_actor.py:56-144, net_critic.py:50-130),
  * two residual blocks ResBlock(16, 16) and ResBlock(32, 32) with 512 hidden units and LeakyReLU(0.2)
- * (net_actor.py:16-53), actor heads sigmoid(out1) / tanh(out2), critic head out.  Fused f32-MFMA kernels
- * (csrc/ppo_resmlp512.hip); same contracts as the mlp64 entry points above unless stated.
+ * (net_actor.py:16-53), actor heads sigmoid(out1) / tanh(out2), critic head out.  Fused MFMA kernels (csrc/ppo_resmlp512.hip):
+ * float32 in, float32 out, float32 accumulate; the products that fill a k-step of the bf16 MFMA are float32 products rebuilt from three
+ * exact bf16 pieces per operand ("bf16x3", as navppo_mlp64_bf16x3_*), the others run on the f32-input MFMA -- ONE arithmetic, also
+ * for navppo_resmlp512_value (a caller who needs native float32 products throughout uses PyTorch: PPOConfig.update_arith = "f32").
+ * Same contracts as the mlp64 entry points above unless stated.
  *
  *   params_dev  [50290 + 50257] f32   actor then critic, each in nn.Module.named_parameters() order WITHOUT the BatchNorm
  *               entries the reference's forward never uses (net_actor.py:44,48,137):
@@ -159,23 +163,25 @@ int navppo_mlp64_act(const float* actor_params_dev, const void* obs_dev, int32_t
 
 size_t navppo_resmlp512_workspace_bytes(int64_t n_samples);
 
-/* evaluate() + losses + both backward() calls of ppo.py:307-386; grad_dev [50290 + 50257], stats_dev [8] as navppo_mlp64_loss_grad */
-int navppo_resmlp512_loss_grad(const float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
+/* evaluate() + losses + both backward() calls of ppo.py:307-386; grad_dev [50290 + 50257], stats_dev [8] as navppo_mlp64_loss_grad.
+ * obs_dev: [n, 16] rows, float32 (obs_f16 = 0) or float16 (obs_f16 = 1: BASELINE configs[4], navsim_cfg.obs_f16; ABI v6), 16-byte
+ * aligned; half rows are widened as they are loaded, in every entry point below. */
+int navppo_resmlp512_loss_grad(const float* params_dev, const void* obs_dev, int32_t obs_f16, const float* act_dev, const float* logp_old_dev,
                                const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip,
                                float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
 
 /* one whole epoch of ppo.py:305-392 on one GPU (losses, gradients, both Adam steps); as navppo_mlp64_update_epoch */
-int navppo_resmlp512_update_epoch(float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
+int navppo_resmlp512_update_epoch(float* params_dev, const void* obs_dev, int32_t obs_f16, const float* act_dev, const float* logp_old_dev,
                                   const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
                                   float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
                                   float* grad_dev, float* stats_dev, void* workspace_dev, void* stream);
 
 /* V = critic(obs).squeeze() (ppo.py:275, :724); critic_params_dev [50257] (8-byte aligned suffices), value_dev [n] */
-int navppo_resmlp512_value(const float* critic_params_dev, const float* obs_dev, int64_t n_samples, float* value_dev,
+int navppo_resmlp512_value(const float* critic_params_dev, const void* obs_dev, int32_t obs_f16, int64_t n_samples, float* value_dev,
                            void* workspace_dev, void* stream);
 
 /* PPO.get_action() (ppo.py:673-706) for all envs of a shard in one launch; arguments as navppo_mlp64_act, actor_params_dev [50290] */
-int navppo_resmlp512_act(const float* actor_params_dev, const float* obs_dev, const float* noise_dev, int64_t n_envs,
+int navppo_resmlp512_act(const float* actor_params_dev, const void* obs_dev, int32_t obs_f16, const float* noise_dev, int64_t n_envs,
                          const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
                          uint32_t step_offset, float* act_dev, float* logp_dev, float* mean_dev, void* stream);
 

@@ -263,11 +263,12 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, void* obs_b
  * step what navppo_resmlp512_act computes (include/navppo.h) followed by what navsim_step computes, all n_steps steps in ONE launch;
  * buffers, noise keys and bit-for-bit equality with the per-step entry points as for navsim_rollout_mlp64.
  *   actor_params_dev [NAVPPO_RESMLP512_ACTOR_PARAMS = 50290] f32, the layout of navppo.h (no BatchNorm entries)
- *   obs_buf_dev [n_steps + 1, N, 16] f32.   Needs n_beams == 10 and float32 observations (the 512-wide kernels read float32 rows).
+ *   obs_buf_dev [n_steps + 1, N, 16] f32 (f16 if cfg.obs_f16: the policy then reads every row rounded to half, as a reader of the
+ *               buffer would -- the rows still equal the per-step path's bit for bit).   Needs n_beams == 10.
  * 16 envs on 8 waves per workgroup at every shard size (each wave owns 64 hidden units; the 197 KB of weights stream from L2 every
  * step), 64-segment passes for every map (no tile boxes: correct on every map, the house map just tests all its tiles).
  */
-int navsim_rollout_resmlp512(navsim_t* h, const float* actor_params_dev, float* obs_buf_dev, float* act_buf_dev, float* logp_buf_dev,
+int navsim_rollout_resmlp512(navsim_t* h, const float* actor_params_dev, void* obs_buf_dev, float* act_buf_dev, float* logp_buf_dev,
                              float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev, float* ep_return_dev,
                              int32_t* ep_length_dev, float* ep_path_dev, const float* var_dev, uint64_t act_seed,
                              const uint32_t* step_base_dev, int32_t n_steps, void* stream);

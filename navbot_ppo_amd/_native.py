@@ -84,10 +84,10 @@ SYMBOLS = [
     ("navppo_mlp64_bf16x3_loss_grad_net", C.c_int, [_i32, _vp, _vp, _i32] + [_vp] * 4 + [C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     ("navppo_mlp64_bf16x3_update_epoch", C.c_int, [_vp, _vp, _i32] + [_vp] * 4 + [C.c_int64] + [C.c_float] * 6 + [_i32] + [_vp] * 6),
     ("navppo_resmlp512_workspace_bytes", C.c_size_t, [C.c_int64]),
-    ("navppo_resmlp512_loss_grad", C.c_int, [_vp] * 6 + [C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
-    ("navppo_resmlp512_update_epoch", C.c_int, [_vp] * 6 + [C.c_int64] + [C.c_float] * 6 + [_i32] + [_vp] * 6),
-    ("navppo_resmlp512_value", C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
-    ("navppo_resmlp512_act", C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, _vp, _vp, _vp, _vp]),
+    ("navppo_resmlp512_loss_grad", C.c_int, [_vp, _vp, _i32] + [_vp] * 4 + [C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
+    ("navppo_resmlp512_update_epoch", C.c_int, [_vp, _vp, _i32] + [_vp] * 4 + [C.c_int64] + [C.c_float] * 6 + [_i32] + [_vp] * 6),
+    ("navppo_resmlp512_value", C.c_int, [_vp, _vp, _i32, C.c_int64, _vp, _vp, _vp]),
+    ("navppo_resmlp512_act", C.c_int, [_vp, _vp, _i32, _vp, C.c_int64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, _vp, _vp, _vp, _vp]),
 ]
 
 _lib = None

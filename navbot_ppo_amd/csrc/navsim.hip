@@ -1586,7 +1586,10 @@ __global__ __launch_bounds__(64 * 8) void rollout_resmlp_kernel(Params P, Rollou
         sm.st_step[e] = (uint32_t)P.ep_step[i];
         sm.st_ctr[e] = P.rng_ctr[i];
     }
-    for (int k = tid; k < nloc * D; k += kThreads) sm.obs[(k / D) * DP + (k % D)] = reinterpret_cast<const float*>(R.obs_buf)[(size_t)base * D + k];
+    const bool half_rows = P.obs_f16 != 0;   // float16 observation buffers (BASELINE configs[4]): the policy reads what a reader of the buffers would
+    for (int k = tid; k < nloc * D; k += kThreads)
+        sm.obs[(k / D) * DP + (k % D)] = half_rows ? __half2float(reinterpret_cast<const __half*>(R.obs_buf)[(size_t)base * D + k])
+                                                   : reinterpret_cast<const float*>(R.obs_buf)[(size_t)base * D + k];
     for (int k = tid; k < 2 * NB; k += kThreads) sm.beam[k] = P.beam_cs[k];
     for (int k = tid; k < (int)(sizeof(Rects) / 8); k += kThreads)
         reinterpret_cast<uint64_t*>(&sm.rects)[k] = reinterpret_cast<const uint64_t*>(P.rects)[k];
@@ -1613,6 +1616,10 @@ __global__ __launch_bounds__(64 * 8) void rollout_resmlp_kernel(Params P, Rollou
         if (valid) {
             const float* row = sm.obs + l15 * DP + 4 * q;
             xq = resmlp::f32x4{row[0], row[1], row[2], row[3]};
+            if (half_rows) {   // (the tile in LDS is float32; the row in the buffer -- what navppo_resmlp512_act would read -- is its rounding to half)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xq[j] = __half2float(__float2half_rn(xq[j]));
+            }
         }
         float z3, z4;
         resmlp::load_weights_b(R.params, lane, wave, W);   // requested first: in flight while block 1 runs out of LDS
@@ -1628,7 +1635,9 @@ __global__ __launch_bounds__(64 * 8) void rollout_resmlp_kernel(Params P, Rollou
         __syncthreads();
         // ---- the env step: the same step body as every other entry point; behind its barrier B2 the next policy step's weights are
         // requested and its noise is drawn
-        const StepIO io = {nullptr, nullptr, reinterpret_cast<float*>(R.obs_buf) + (tn + N) * D, R.reward + tn, R.done + tn, R.arrive + tn,
+        void* const obs_row = half_rows ? (void*)(reinterpret_cast<__half*>(R.obs_buf) + (tn + N) * D)
+                                        : (void*)(reinterpret_cast<float*>(R.obs_buf) + (tn + N) * D);
+        const StepIO io = {nullptr, nullptr, obs_row, R.reward + tn, R.done + tn, R.arrive + tn,
                            R.ended + tn, R.ep_return ? R.ep_return + tn : nullptr, R.ep_length ? R.ep_length + tn : nullptr,
                            R.ep_path ? R.ep_path + tn : nullptr};
         const bool more = t + 1 < R.T;
@@ -2717,7 +2726,7 @@ int navsim_rollout_mlp64(navsim_t* h, const float* actor_params_dev, void* obs_b
     return NAVSIM_OK;
 }
 
-int navsim_rollout_resmlp512(navsim_t* h, const float* actor_params_dev, float* obs_buf_dev, float* act_buf_dev, float* logp_buf_dev,
+int navsim_rollout_resmlp512(navsim_t* h, const float* actor_params_dev, void* obs_buf_dev, float* act_buf_dev, float* logp_buf_dev,
                              float* reward_dev, uint8_t* done_dev, uint8_t* arrive_dev, uint8_t* ended_dev, float* ep_return_dev,
                              int32_t* ep_length_dev, float* ep_path_dev, const float* var_dev, uint64_t act_seed,
                              const uint32_t* step_base_dev, int32_t n_steps, void* stream) {
@@ -2725,8 +2734,8 @@ int navsim_rollout_resmlp512(navsim_t* h, const float* actor_params_dev, float* 
         !ended_dev || !var_dev || n_steps < 0)
         return fail(NAVSIM_E_ARG, "navsim_rollout_resmlp512: bad argument");
     if (!h->has_map) return fail(NAVSIM_E_STATE, "navsim_rollout_resmlp512: call navsim_set_map first");
-    if (h->P.B != 10 || h->P.obs_f16)
-        return fail(NAVSIM_E_ARG, "navsim_rollout_resmlp512: the reference's nets read 16-wide float32 observations (10 beams, obs_f16 = 0)");
+    if (h->P.B != 10)
+        return fail(NAVSIM_E_ARG, "navsim_rollout_resmlp512: the reference's nets read 16-wide observations (10 beams)");
     if (((uintptr_t)actor_params_dev & 15) || ((uintptr_t)act_buf_dev & 7) || ((uintptr_t)obs_buf_dev & 15))
         return fail(NAVSIM_E_ARG, "navsim_rollout_resmlp512: params and obs must be 16-byte, act 8-byte aligned");
     if (n_steps == 0) return NAVSIM_OK;

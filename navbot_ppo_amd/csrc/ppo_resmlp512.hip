@@ -126,15 +126,27 @@ __device__ __forceinline__ WG decode_block(int b, int n_nets, int groups) {
     return WG{ns >> 2, ns & 3, grp};
 }
 
+// Four consecutive columns of an observation row, element index idx = s * 16 + 4 q: float32 rows, or float16 rows (obs_f16: BASELINE
+// configs[4]'s "fp16 obs buffers", navsim_cfg.obs_f16) widened at the load -- everything behind the load is the same float32 arithmetic.
+__device__ __forceinline__ float4 ldx4(const void* __restrict__ obs, const long long idx, const int obs_f16) {
+    if (obs_f16) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(obs) + idx);
+        const __half2 lo = *reinterpret_cast<const __half2*>(&u.x), hi = *reinterpret_cast<const __half2*>(&u.y);
+        const float2 a = __half22float2(lo), b = __half22float2(hi);
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(obs) + idx);
+}
+
 // the wave's [IN, 32] input tile in the 16-layout: rows 0..15 = observation, rows 16..31 = h1 (IN == 32)
 template <int IN>
-__device__ __forceinline__ void load_x(f32x4 (&X)[IN / 16][2], const float* __restrict__ obs, const float* __restrict__ h1n,
+__device__ __forceinline__ void load_x(f32x4 (&X)[IN / 16][2], const void* __restrict__ obs, const int obs_f16, const float* __restrict__ h1n,
                                        long long n, long long m0, int l15, int q) {
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         const long long s = m0 + 16 * st + l15;
         const bool v = s < n;
-        X[0][st] = v ? v4(ld4(obs + s * 16 + 4 * q)) : zero4();
+        X[0][st] = v ? v4(ldx4(obs, s * 16 + 4 * q, obs_f16)) : zero4();
         if (IN == 32) X[IN / 16 - 1][st] = v ? v4(ld4(h1n + s * 16 + 4 * q)) : zero4();
     }
 }
@@ -198,9 +210,9 @@ struct FwdSmem {
 // store it to h1buf for the kernels behind.
 template <int IN>
 __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__ params, int net_base, int n_nets,
-                                                       const float* __restrict__ obs, const float* __restrict__ p1,
+                                                       const void* __restrict__ obs, const float* __restrict__ p1,
                                                        float* __restrict__ h1buf, long long n, int groups,
-                                                       float* __restrict__ pout) {
+                                                       float* __restrict__ pout, int obs_f16) {
     __shared__ __attribute__((aligned(16))) FwdSmem<IN> sm;
     constexpr int S2 = HS + 4, NB = IN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, q = lane >> 4;
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
         for (int st = 0; st < 2; ++st) {
             const long long s = t * 32 + 16 * st + l15;
             const bool v = s < n;
-            xn[st] = v ? v4(ld4(obs + s * 16 + 4 * q)) : zero4();
+            xn[st] = v ? v4(ldx4(obs, s * 16 + 4 * q, obs_f16)) : zero4();
             if (IN == 32)
 #pragma unroll
                 for (int k = 0; k < NSL; ++k) pa[k][st] = v ? v4(ld4(pp + ((size_t)k * n + s) * 16 + 4 * q)) : zero4();
@@ -370,10 +382,10 @@ static_assert(sizeof(BwdSmem<32, 8>) <= 160 * 1024 && sizeof(BwdSmem<32, 4>) <= 
 // swapped: A = the lane's own eight X / dY registers split once per tile, B = the weight pieces), which the 8-wave build has no
 // registers for (66 -> 125 spilled).
 template <int IN, int NST, int NWV>
-__global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__ params, int n_nets, const float* __restrict__ obs,
+__global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__ params, int n_nets, const void* __restrict__ obs,
                                                        const float* __restrict__ h1buf, const float* __restrict__ dypre,
                                                        long long n, int groups, float* __restrict__ wpart,
-                                                       float* __restrict__ qout, const float* __restrict__ qin) {
+                                                       float* __restrict__ qout, const float* __restrict__ qin, int obs_f16) {
     __shared__ __attribute__((aligned(16))) BwdSmem<IN, NWV> sm;
     constexpr int S1 = IN + 4, NB = IN / 16;
     constexpr int kWaves = NWV, kThreads = 64 * NWV;   // (shadow the 8-wave constants of the file)
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__
         for (int st = 0; st < 2; ++st) {
             const long long s = tile * 32 + 16 * st + l15;
             const bool v = s < n;
-            w.X[0][st] = v ? v4(ld4(obs + s * 16 + 4 * q)) : zero4();
+            w.X[0][st] = v ? v4(ldx4(obs, s * 16 + 4 * q, obs_f16)) : zero4();
             if (NEED_DX) {
                 w.X[NB - 1][st] = v ? v4(ld4(h1n + s * 16 + 4 * q)) : zero4();
 #pragma unroll
@@ -762,12 +774,12 @@ __device__ __forceinline__ void block_sum_to_row(float (&acc)[NV], float* red /*
 // E2: h2, heads, PPO loss / MSE, dpre2, and the sample sums d(heads), db2b, statistics.  thread = (sample, 4 of the 32 units)
 // HEAD_ONLY: V = critic(obs).squeeze() only (ppo.py:275, :724).
 template <bool HEAD_ONLY>
-__global__ __launch_bounds__(kEThreads) void resmlp_e2(const float* __restrict__ params, int net_base, const float* __restrict__ obs,
+__global__ __launch_bounds__(kEThreads) void resmlp_e2(const float* __restrict__ params, int net_base, const void* __restrict__ obs,
                                                        const float* __restrict__ h1buf, const float* __restrict__ p2,
                                                        const float* __restrict__ act, const float* __restrict__ logp_old,
                                                        const float* __restrict__ rtg, const float* __restrict__ adv, long long n,
                                                        float var, float clip, float inv_n, float* __restrict__ dy2,
-                                                       float* __restrict__ epart, float* __restrict__ v_out) {
+                                                       float* __restrict__ epart, float* __restrict__ v_out, int obs_f16) {
     __shared__ float red[(kEThreads / 64) * 8 * 17];
     const int net_i = blockIdx.y, net = net_base + net_i;
     const bool actor = net == 0;
@@ -791,7 +803,7 @@ __global__ __launch_bounds__(kEThreads) void resmlp_e2(const float* __restrict__
     const long long total = n * 8, step = (long long)gridDim.x * kEThreads;
     for (long long g = (long long)blockIdx.x * kEThreads + threadIdx.x; g < total; g += step) {
         const long long s = g >> 3, o = g * 4;   // o == s * 32 + 4 * og
-        const float4 x1 = og < 4 ? ld4(obs + s * 16 + 4 * og) : ld4(hn + s * 16 + 4 * (og - 4));
+        const float4 x1 = og < 4 ? ldx4(obs, s * 16 + 4 * og, obs_f16) : ld4(hn + s * 16 + 4 * (og - 4));
         const float4 a0 = ld4(pp + o), a1 = ld4(pp + (size_t)n * 32 + o), a2 = ld4(pp + (size_t)2 * n * 32 + o),
                      a3 = ld4(pp + (size_t)3 * n * 32 + o);
         float h[4];
@@ -932,16 +944,16 @@ __global__ __launch_bounds__(64 * kRedGroups) void resmlp_reduce(const float* __
 // One workgroup = 16 envs on 8 waves: csrc/resmlp_policy.h (shared with the persistent rollout kernel of navsim.hip: same bits).
 constexpr int kActEnvs = resmlp::kPolEnvs;
 static_assert(kWaves == resmlp::kPolWaves, "the policy step's workgroup");
-__global__ __launch_bounds__(kThreads) void resmlp_act(const float* __restrict__ pa, const float* __restrict__ obs,
+__global__ __launch_bounds__(kThreads) void resmlp_act(const float* __restrict__ pa, const void* __restrict__ obs,
                                                        const float* __restrict__ noise, long long n, const float* __restrict__ var_ptr,
                                                        uint64_t seed, uint64_t env_id_base, const uint32_t* __restrict__ step_base,
                                                        uint32_t step_offset, float* __restrict__ act, float* __restrict__ logp,
-                                                       float* __restrict__ mean_out) {
+                                                       float* __restrict__ mean_out, int obs_f16) {
     __shared__ __attribute__((aligned(16))) resmlp::PolicySmem ps;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, q = lane >> 4;
     const long long e = (long long)blockIdx.x * kActEnvs + l15;
     const bool valid = e < n;
-    const f32x4 xq = valid ? v4(ld4(obs + e * 16 + 4 * q)) : zero4();
+    const f32x4 xq = valid ? v4(ldx4(obs, e * 16 + 4 * q, obs_f16)) : zero4();
     float z3, z4;
     resmlp::policy_preact(pa, xq, lane, w, ps, z3, z4);
     if (w != 0) return;
@@ -1010,14 +1022,14 @@ bool launch_ok(const char* what) {
 }
 
 // forward of `n_nets` nets starting at net_base (0 = actor, 1 = critic) up to the partial sums of rb2
-void launch_forward(const Plan& p, const float* params, int net_base, int n_nets, const float* obs, int64_t n, hipStream_t st) {
+void launch_forward(const Plan& p, const float* params, int net_base, int n_nets, const void* obs, int obs_f16, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(resmlp_fwd<16>, dim3(p.wgs), dim3(kThreads), 0, st, params, net_base, n_nets, obs, (const float*)nullptr,
-                       (float*)nullptr, (long long)n, p.groups, p.p1);
+                       (float*)nullptr, (long long)n, p.groups, p.p1, obs_f16);
     hipLaunchKernelGGL(resmlp_fwd<32>, dim3(p.wgs), dim3(kThreads), 0, st, params, net_base, n_nets, obs, (const float*)p.p1, p.h1,
-                       (long long)n, p.groups, p.p2);
+                       (long long)n, p.groups, p.p2, obs_f16);
 }
 
-int loss_grad_impl(const char* name, bool adam, float* params, const float* obs, const float* act, const float* logp_old,
+int loss_grad_impl(const char* name, bool adam, float* params, const void* obs, int32_t obs_f16, const float* act, const float* logp_old,
                    const float* rtg, const float* adv, int64_t n, float var, float clip, float lr, float beta1, float beta2,
                    float eps, int32_t step, float* adam_m, float* adam_v, float* grad, float* stats, void* ws, void* stream) {
     if (!params || !obs || !act || !logp_old || !rtg || !adv || !grad || !stats || !ws || n < 1 || !(var > 0.f) ||
@@ -1032,13 +1044,14 @@ int loss_grad_impl(const char* name, bool adam, float* params, const float* obs,
     hipStream_t st = (hipStream_t)stream;
     const Plan p = make_plan(ws, n, 2);
     const float inv_n = 1.0f / (float)n;
-    launch_forward(p, params, 0, 2, obs, n, st);
+    const int f16 = obs_f16 != 0;
+    launch_forward(p, params, 0, 2, obs, f16, n, st);
     hipLaunchKernelGGL(resmlp_e2<false>, dim3(p.e_blocks, 2), dim3(kEThreads), 0, st, (const float*)params, 0, obs, (const float*)p.h1,
-                       (const float*)p.p2, act, logp_old, rtg, adv, (long long)n, var, clip, inv_n, p.dy2, p.epart, (float*)nullptr);
+                       (const float*)p.p2, act, logp_old, rtg, adv, (long long)n, var, clip, inv_n, p.dy2, p.epart, (float*)nullptr, f16);
     hipLaunchKernelGGL((resmlp_bwd<32, 2, kBwd2Waves>), dim3(p.wgs), dim3(64 * kBwd2Waves), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
-                       (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb, (const float*)nullptr);
+                       (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb, (const float*)nullptr, f16);
     hipLaunchKernelGGL((resmlp_bwd<16, 2, kWaves>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
-                       (const float*)p.dy2, (long long)n, p.groups, p.wpart, (float*)nullptr, (const float*)p.qb);
+                       (const float*)p.dy2, (long long)n, p.groups, p.wpart, (float*)nullptr, (const float*)p.qb, f16);
     const int rblocks = (rp::P_ACTOR + rp::P_CRITIC + 63) / 64;
     if (adam) {
         const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
@@ -1060,28 +1073,28 @@ extern "C" {
 
 size_t navppo_resmlp512_workspace_bytes(int64_t n_samples) { return n_samples < 1 ? 0 : ws_floats(n_samples) * sizeof(float); }
 
-int navppo_resmlp512_loss_grad(const float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
+int navppo_resmlp512_loss_grad(const float* params_dev, const void* obs_dev, int32_t obs_f16, const float* act_dev, const float* logp_old_dev,
                                const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip,
                                float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
-    const int rc = loss_grad_impl("navppo_resmlp512_loss_grad", false, const_cast<float*>(params_dev), obs_dev, act_dev, logp_old_dev,
+    const int rc = loss_grad_impl("navppo_resmlp512_loss_grad", false, const_cast<float*>(params_dev), obs_dev, obs_f16, act_dev, logp_old_dev,
                                   rtg_dev, adv_dev, n_samples, var, clip, 0.f, 0.f, 0.f, 0.f, 1, nullptr, nullptr, grad_dev, stats_dev,
                                   workspace_dev, stream);
     if (rc != 0) navppo_set_error(g_err.c_str());
     return rc;
 }
 
-int navppo_resmlp512_update_epoch(float* params_dev, const float* obs_dev, const float* act_dev, const float* logp_old_dev,
+int navppo_resmlp512_update_epoch(float* params_dev, const void* obs_dev, int32_t obs_f16, const float* act_dev, const float* logp_old_dev,
                                   const float* rtg_dev, const float* adv_dev, int64_t n_samples, float var, float clip, float lr,
                                   float beta1, float beta2, float eps, int32_t step, float* adam_m_dev, float* adam_v_dev,
                                   float* grad_dev, float* stats_dev, void* workspace_dev, void* stream) {
-    const int rc = loss_grad_impl("navppo_resmlp512_update_epoch", true, params_dev, obs_dev, act_dev, logp_old_dev, rtg_dev, adv_dev,
+    const int rc = loss_grad_impl("navppo_resmlp512_update_epoch", true, params_dev, obs_dev, obs_f16, act_dev, logp_old_dev, rtg_dev, adv_dev,
                                   n_samples, var, clip, lr, beta1, beta2, eps, step, adam_m_dev, adam_v_dev, grad_dev, stats_dev,
                                   workspace_dev, stream);
     if (rc != 0) navppo_set_error(g_err.c_str());
     return rc;
 }
 
-int navppo_resmlp512_value(const float* critic_params_dev, const float* obs_dev, int64_t n_samples, float* value_dev,
+int navppo_resmlp512_value(const float* critic_params_dev, const void* obs_dev, int32_t obs_f16, int64_t n_samples, float* value_dev,
                            void* workspace_dev, void* stream) {
     if (!critic_params_dev || !obs_dev || !value_dev || !workspace_dev || n_samples < 1 || ((uintptr_t)obs_dev & 15)) {
         navppo_set_error("navppo_resmlp512_value: bad argument (obs must be 16-byte aligned)");
@@ -1091,10 +1104,10 @@ int navppo_resmlp512_value(const float* critic_params_dev, const float* obs_dev,
     const Plan p = make_plan(workspace_dev, n_samples, 1);
     // the kernels index the flat [actor | critic] buffer by net: hand them the address the actor would have
     const float* base = critic_params_dev - rp::P_ACTOR;
-    launch_forward(p, base, 1, 1, obs_dev, n_samples, st);
+    launch_forward(p, base, 1, 1, obs_dev, obs_f16 != 0, n_samples, st);
     hipLaunchKernelGGL(resmlp_e2<true>, dim3(p.e_blocks, 1), dim3(kEThreads), 0, st, base, 1, obs_dev, (const float*)p.h1,
                        (const float*)p.p2, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (long long)n_samples, 1.f, 0.f, 0.f, (float*)nullptr, (float*)nullptr, value_dev);
+                       (long long)n_samples, 1.f, 0.f, 0.f, (float*)nullptr, (float*)nullptr, value_dev, (int)(obs_f16 != 0));
     if (!launch_ok("navppo_resmlp512_value")) {
         navppo_set_error(g_err.c_str());
         return -2;
@@ -1102,7 +1115,7 @@ int navppo_resmlp512_value(const float* critic_params_dev, const float* obs_dev,
     return 0;
 }
 
-int navppo_resmlp512_act(const float* actor_params_dev, const float* obs_dev, const float* noise_dev, int64_t n_envs,
+int navppo_resmlp512_act(const float* actor_params_dev, const void* obs_dev, int32_t obs_f16, const float* noise_dev, int64_t n_envs,
                          const float* var_dev, uint64_t seed, uint64_t env_id_base, const uint32_t* step_base_dev,
                          uint32_t step_offset, float* act_dev, float* logp_dev, float* mean_dev, void* stream) {
     if (!actor_params_dev || !obs_dev || !act_dev || !logp_dev || n_envs < 1 || !var_dev) {
@@ -1115,7 +1128,7 @@ int navppo_resmlp512_act(const float* actor_params_dev, const float* obs_dev, co
     }
     const int blocks = (int)((n_envs + kActEnvs - 1) / kActEnvs);
     hipLaunchKernelGGL(resmlp_act, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, actor_params_dev, obs_dev, noise_dev,
-                       (long long)n_envs, var_dev, seed, env_id_base, step_base_dev, step_offset, act_dev, logp_dev, mean_dev);
+                       (long long)n_envs, var_dev, seed, env_id_base, step_base_dev, step_offset, act_dev, logp_dev, mean_dev, (int)(obs_f16 != 0));
     if (!launch_ok("navppo_resmlp512_act")) {
         navppo_set_error(g_err.c_str());
         return -2;

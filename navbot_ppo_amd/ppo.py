@@ -265,15 +265,17 @@ class PPOUpdater:
         return self._ws
 
     def _obs_args(self, obs):
-        """The observation arguments of the fused entry points: (pointer[, obs_dim, obs_f16]) after checking what is behind the
-        pointer -- rows of self.obs_dim columns, float32 (or float16 for the D-64-64 heads, which widen half rows as they load)."""
+        """The observation arguments of the fused entry points -- (pointer, obs_dim, obs_f16) for the D-64-64 heads, (pointer, obs_f16)
+        for the 512-wide nets -- after checking what is behind the pointer: rows of self.obs_dim columns, float32 or float16 (the
+        kernels widen half rows as they load)."""
         import ctypes as C
-        ok = (torch.float32, torch.float16) if self.fused_mlp64 else (torch.float32,)
+        ok = (torch.float32, torch.float16)
         if obs.dim() != 2 or obs.shape[1] != self.obs_dim or obs.dtype not in ok or not obs.is_contiguous():
             raise ValueError(f"{self.fused}: observations must be contiguous [n, {self.obs_dim}] rows of {ok}, got "
                              f"{tuple(obs.shape)} {obs.dtype}")
         p = C.c_void_p(obs.data_ptr())
-        return (p, self.obs_dim, int(obs.dtype == torch.float16)) if self.fused_mlp64 else (p,)
+        f16 = int(obs.dtype == torch.float16)
+        return (p, self.obs_dim, f16) if self.fused_mlp64 else (p, f16)
 
     def prepare(self, obs):
         """bf16x3: split the batch's observations into bf16 pieces (navppo_mlp64_bf16x3_prepare) -- once per update, the rows do not
@@ -415,7 +417,7 @@ class PPOUpdater:
     def value(self, obs):
         """V = critic(obs).squeeze() (ppo.py:275) for [n, D] rows."""
         with torch.no_grad():
-            if self.fused and obs.is_contiguous() and obs.data_ptr() % 16 == 0 and (obs.dtype == torch.float32 or self.fused_mlp64):
+            if self.fused and obs.is_contiguous() and obs.data_ptr() % 16 == 0 and obs.dtype in (torch.float32, torch.float16):
                 return self._fused_value(obs)
             return self.critic(obs.float()).squeeze(-1)
 
@@ -435,8 +437,8 @@ class PPOUpdater:
         acc = torch.zeros(6, device=obs.device)                # sums over epochs of diagnostics
         self.loss_history = torch.zeros((n_ep, 2), device=obs.device)  # per-epoch (actor, critic) loss, ppo.py:396-397
         var_f = float(var) if self.fused else None
-        if not (self.fused_mlp64 and obs.dtype == torch.float16):
-            obs = obs.float()   # half rows (obs_f16 envs) are consumed as they are by the D-64-64 kernels only
+        if not (self.fused and obs.dtype == torch.float16):
+            obs = obs.float()   # half rows (obs_f16 envs) are consumed as they are by the fused kernels only
         if self.fused:
             obs, acts, logp_old, rtg, adv = (t.contiguous() for t in (obs, acts, logp_old, rtg, adv))
             if self.bf16x3 and n_ep > 0:
@@ -516,11 +518,9 @@ class PPOTrainer:
         dev = self.device
         f32, u8 = torch.float32, torch.uint8
         # the observation rows in the dtype the simulator writes them (float16 on an obs_f16 env: BASELINE configs[4]); half rows
-        # are read directly by the D-64-64 kernels, every other consumer (PyTorch policies, the 512-wide kernels) widens them
+        # are read directly by the fused kernels of both policies (round 6: the 512-wide ones too), a PyTorch policy widens them
         self.obs_buf = torch.zeros((T + 1, N, D), dtype=env.sim.obs_dtype, device=dev)
         self._half_obs = env.sim.obs_dtype == torch.float16
-        if self._half_obs and self.updater.fused_resmlp512:
-            raise ValueError("resmlp512 fused kernels read float32 rows: build the VecEnv with obs_f16=False, or use policy='mlp64x2'")
         self.act_buf = torch.zeros((T, N, 2), dtype=f32, device=dev)
         self.logp_buf = torch.zeros((T, N), dtype=f32, device=dev)
         self.rew_buf = torch.zeros((T, N), dtype=f32, device=dev)
@@ -599,10 +599,10 @@ class PPOTrainer:
     @property
     def uses_persistent_rollout(self):
         """All T steps of PPO.rollout in ONE launch: navsim_rollout_mlp64 (the (B + 6)-64-64 actor, 10 or 36 beams, float32 or float16
-        rows) or navsim_rollout_resmlp512 (the reference's 512-wide actor, 10 beams, float32 rows: round 5).  Anything else runs the
+        rows) or navsim_rollout_resmlp512 (the reference's 512-wide actor, 10 beams, float32 or float16 rows).  Anything else runs the
         hipGraph of per-step launches."""
         return bool(self.cfg.persistent_rollout and ((self.updater.fused_mlp64 and self.env.B in (10, 36)) or
-                                                     (self.updater.fused_resmlp512 and self.env.B == 10 and not self._half_obs)))
+                                                     (self.updater.fused_resmlp512 and self.env.B == 10)))
 
     @torch.no_grad()
     def rollout(self):

@@ -343,8 +343,8 @@ def test_buffers_of_the_wrong_type_are_refused():
                      torch.zeros((4, 64), dtype=torch.uint8, device=dev), torch.zeros((4, 64), dtype=torch.uint8, device=dev))
     tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=8, policy="mlp64x2"))
     assert tr.obs_buf.dtype == torch.float16                  # the trainer's buffers follow the simulator's row type
-    with pytest.raises(ValueError):
-        ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=8, policy="resmlp512"))   # the 512-wide kernels read float32 rows
+    tr5 = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=8, policy="resmlp512"))   # round 6: the 512-wide kernels read float16 rows too
+    assert tr5.obs_buf.dtype == torch.float16 and tr5.updater.fused_resmlp512 and tr5.uses_persistent_rollout
     env.close()
 
 

@@ -178,7 +178,7 @@ def test_fused_resmlp512_act_matches_pytorch_policy_step():
         obs = torch.rand((n, 16), device=dev)
         eps = torch.randn((n, 2), device=dev)
         act, lp, mean = torch.empty((n, 2), device=dev), torch.empty(n, device=dev), torch.empty((n, 2), device=dev)
-        assert L.navppo_resmlp512_act(ptr(up.fp.flat), ptr(obs), ptr(eps), n, ptr(var), 7, 0, None, 0, ptr(act), ptr(lp), ptr(mean), st) == 0
+        assert L.navppo_resmlp512_act(ptr(up.fp.flat), ptr(obs), 0, ptr(eps), n, ptr(var), 7, 0, None, 0, ptr(act), ptr(lp), ptr(mean), st) == 0
         with torch.no_grad():
             m_ref = a(obs)
             raw = m_ref + torch.sqrt(var) * eps
@@ -193,7 +193,15 @@ def test_fused_resmlp512_act_matches_pytorch_policy_step():
     tiny = torch.tensor(1e-4, device=dev)
     sb = torch.tensor(5, dtype=torch.int32, device=dev)
     act, lp, mean = torch.empty((N, 2), device=dev), torch.empty(N, device=dev), torch.empty((N, 2), device=dev)
-    assert L.navppo_resmlp512_act(ptr(up.fp.flat), ptr(obs), None, N, ptr(tiny), 9, 64, ptr(sb), 2, ptr(act), ptr(lp), ptr(mean), st) == 0
+    assert L.navppo_resmlp512_act(ptr(up.fp.flat), ptr(obs), 0, None, N, ptr(tiny), 9, 64, ptr(sb), 2, ptr(act), ptr(lp), ptr(mean), st) == 0
+    # float16 rows: the same entry point on the half copy == on its widened float32 copy, bit for bit
+    oh = obs.half().contiguous()
+    ow = oh.float().contiguous()
+    a_h, l_h, m_h = torch.empty((N, 2), device=dev), torch.empty(N, device=dev), torch.empty((N, 2), device=dev)
+    a_w, l_w, m_w = torch.empty((N, 2), device=dev), torch.empty(N, device=dev), torch.empty((N, 2), device=dev)
+    assert L.navppo_resmlp512_act(ptr(up.fp.flat), ptr(oh), 1, None, N, ptr(tiny), 9, 64, ptr(sb), 2, ptr(a_h), ptr(l_h), ptr(m_h), st) == 0
+    assert L.navppo_resmlp512_act(ptr(up.fp.flat), ptr(ow), 0, None, N, ptr(tiny), 9, 64, ptr(sb), 2, ptr(a_w), ptr(l_w), ptr(m_w), st) == 0
+    assert torch.equal(a_h, a_w) and torch.equal(l_h, l_w) and torch.equal(m_h, m_w)
     e = ((act - mean) / 1e-2).cpu().numpy()
     torch.manual_seed(1)
     a64, c64 = nets.make_policy("mlp64x2")
@@ -434,3 +442,107 @@ def test_fused_resmlp512_gradients_against_float64(n):
           f"worst tensor (max error) {mk.max():.2e} vs {mt.max():.2e}")
     assert np.median(rk) <= 1.5 * np.median(rt) + 1e-9 and np.median(rk) <= 2e-7
     assert mk.max() <= max(2e-4, 2 * mt.max())
+
+
+@pytest.mark.parametrize("n", [1, 1000, 128 * 300 + 7])
+def test_fused_resmlp512_reads_float16_rows(n):
+    """BASELINE configs[4] ("fp16 obs buffers") with the reference's ACTIVE nets (missing #1): the fused 512-wide
+    kernels take float16 observation rows (navppo_resmlp512_*: obs_f16 = 1) and widen them at the load -- gradients, statistics, values
+    and the policy step are BIT-IDENTICAL to the same entry points on the widened float32 copy of the rows (everything behind the load
+    is the same float32 arithmetic), and so inside the autograd bound of the float32 tests."""
+    dev = torch.device("cuda")
+    a, c = _policy(dev)
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(policy="resmlp512"), None, dev)
+    obs, acts, logp, rtg, adv = _batch(n, n + 3, dev)
+    obs_h = obs.half().contiguous()
+    obs_w = obs_h.float().contiguous()
+    up._fused_loss_grad(obs_w, acts, logp, rtg, adv, 0.5)
+    torch.cuda.synchronize()
+    g_w, st_w = up.fp.grad.clone(), up._fstats.clone()
+    up.fp.grad.fill_(5.0)
+    up._fused_loss_grad(obs_h, acts, logp, rtg, adv, 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(up.fp.grad, g_w) and torch.equal(up._fstats, st_w)
+    assert torch.equal(up._fused_value(obs_h), up._fused_value(obs_w))
+    with torch.no_grad():
+        np.testing.assert_allclose(up._fused_value(obs_h).cpu().numpy(), c(obs_w).squeeze(-1).cpu().numpy(), rtol=2e-5, atol=2e-5)
+    with pytest.raises(ValueError):
+        up._fused_loss_grad(obs_h[:, :8].contiguous(), acts, logp, rtg, adv, 0.5)   # rows of the wrong width are refused
+
+
+@pytest.mark.parametrize("N,T,map_name", [(512, 40, "stage_1"), (1000, 34, "house")])
+def test_persistent_resmlp512_rollout_on_float16_rows(N, T, map_name):
+    """navsim_rollout_resmlp512 on an obs_f16 env (configs[4]'s row type): the in-kernel policy reads every row rounded to half, as
+    navppo_resmlp512_act reads it from the buffer, so the persistent rollout and the per-step path (T pairs of act / step launches)
+    write bit-identical float16 rows, actions, log-probs, rewards and flags; the trainer then updates on those rows through the
+    fused kernels (PPOTrainer no longer refuses the combination)."""
+    from navbot_ppo_amd.env import VecEnv
+    outs = []
+    for persistent in (True, False):
+        env = VecEnv(N, map=map_name, max_episode_steps=30, seed=3, obs_f16=True, sampler="small_house" if map_name == "house" else None)
+        cfg = ppo.PPOConfig(rollout_len=T, max_episode_steps=30, n_updates_per_iteration=2, policy="resmlp512", seed=5,
+                            persistent_rollout=persistent, use_graph=False)
+        tr = ppo.PPOTrainer(env, cfg)
+        assert tr.uses_persistent_rollout is persistent and tr.updater.fused_resmlp512 and tr.obs_buf.dtype == torch.float16
+        tr.rollout()
+        torch.cuda.synchronize()
+        outs.append([b.clone() for b in (tr.obs_buf, tr.act_buf, tr.logp_buf, tr.rew_buf, tr.done_buf, tr.arrive_buf, tr.ended_buf, tr.rtg_buf)])
+        if persistent:
+            with torch.no_grad():
+                lp = ppo.gaussian_log_prob(tr.actor(tr.obs_buf[:T].reshape(T * N, 16).float()), tr.act_buf.reshape(T * N, 2), tr.var)
+            np.testing.assert_allclose(tr.logp_buf.reshape(-1).cpu().numpy(), lp.cpu().numpy(), rtol=1e-4, atol=3e-5)
+            w0 = tr.updater.fp.flat.clone()
+            lg = tr.iteration()   # (another rollout + the update on its float16 rows)
+            assert np.isfinite(lg["actor_loss"]) and np.isfinite(lg["critic_loss"]) and not torch.equal(w0, tr.updater.fp.flat)
+        env.close()
+    a, b = outs
+    assert int(a[6].sum()) > N // 4
+    bits = lambda x: x.view(torch.int32) if x.dtype == torch.float32 else x.view(torch.int16) if x.dtype == torch.float16 else x
+    for x, y in zip(a, b):
+        assert torch.equal(bits(x), bits(y))
+
+
+def test_persistent_resmlp512_rollout_on_float16_rows_against_the_oracle():
+    """The float16 closed-loop rollout of the 512-wide actor replayed on the oracle (environment_new.py:272-310 + ppo.py:543-593): the
+    recorded actions of a block of envs drive an OracleSim keyed by the same global env ids; flags bit-exact, every stored row EQUAL to
+    the oracle's row rounded to half (or one half-ulp off where the float32 values sit on a rounding tie: <= 1e-6 before rounding)."""
+    from navbot_ppo_amd import maps
+    from navbot_ppo_amd.env import VecEnv
+    from oracle import navsim_oracle as O
+    N, T, cap, lo, n_s = 1024, 200, 120, 600, 64
+    env = VecEnv(N, map="stage_1", max_episode_steps=cap, seed=7, obs_f16=True)
+    tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=T, max_episode_steps=cap, policy="resmlp512", seed=3))
+    assert tr.updater.fused_resmlp512 and tr.uses_persistent_rollout is True
+    with torch.no_grad():
+        tr.actor.out1.bias.add_(2.0)
+    tr.rollout()
+    torch.cuda.synchronize()
+    sl = slice(lo, lo + n_s)
+    acts = tr.act_buf[:, sl].cpu().numpy()
+    cpu = O.OracleSim(n_s, max_episode_steps=cap, auto_reset=True, seed=7, env_id_base=lo)
+    cpu.set_map(maps.stage_1())
+    rr, rs = maps.goal_rects("stage_1")
+    cpu.set_goal_rects(0, rr)
+    cpu.set_goal_rects(1, rs)
+    obs = tr.obs_buf[:, sl].float().cpu().numpy()
+    half = lambda x: x.astype(np.float32).astype(np.float16).astype(np.float32)
+    def rows_match(got, want, what):
+        w16 = half(want)
+        bad = got != w16
+        if bad.any():   # a float32 value within 1e-6 of a rounding tie of float16 may round the other way
+            up_, dn = np.nextafter(w16.astype(np.float16), np.float16(np.inf)).astype(np.float32), np.nextafter(w16.astype(np.float16), np.float16(-np.inf)).astype(np.float32)
+            tie = np.minimum(np.abs(want - (w16 + up_) / 2), np.abs(want - (w16 + dn) / 2)) <= 1e-6
+            assert (tie | ~bad).all(), what
+            assert bad.mean() < 1e-3, what
+    rows_match(obs[0], cpu.reset(), "reset rows")
+    g = {k: getattr(tr, k + "_buf")[:, sl].cpu().numpy() for k in ("rew", "done", "arrive", "ended")}
+    n_end = 0
+    for t in range(T):
+        out = cpu.step(acts[t])
+        for k in ("done", "arrive", "ended"):
+            np.testing.assert_array_equal(g[k][t], out[k], err_msg=f"{k}, step {t}")
+        rows_match(obs[t + 1], out["obs"], f"obs, step {t}")
+        np.testing.assert_allclose(g["rew"][t], out["reward"], rtol=1e-5, atol=1e-5, err_msg=f"reward, step {t}")
+        n_end += int(out["ended"].sum())
+    assert n_end >= n_s
+    env.close()
