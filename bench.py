@@ -56,6 +56,131 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+# ---- the same legs under rocprofv3 (one source for every roofline number).  HIP events around back-to-back
+# launches overlap a kernel's tail with the next one's ramp and run un-profiled clocks: they sat 3-6 % above what a committed
+# `rocprofv3 --kernel-trace --stats` summary reproduces.  So rank 0 profiles ITSELF: the extras block re-runs every roofline leg in a child
+# process under `rocprofv3 --kernel-trace` (NAVBOT_BENCH_PLAIN=1: plain launches, a marker kernel between the legs) and takes each leg's
+# per-kernel duration from the dispatch trace -- `frac`, `achieved`, `launch_us` come from THAT, the HIP-event figures stay beside them as
+# `*_hip_events`.  If rocprofv3 cannot run, the HIP-event figures are printed and `time_source` says so.
+PLAIN = os.environ.get("NAVBOT_BENCH_PLAIN") == "1"
+_MANIFEST = []
+
+
+def _marker():
+    from navbot_ppo_amd.env import odometry
+    torch.cuda.synchronize()
+    z = torch.zeros(1, dtype=torch.float64, device="cuda")
+    odometry(z, z, torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=torch.float64, device="cuda"), torch.zeros((1, 2), dtype=torch.float64, device="cuda"))
+    torch.cuda.synchronize()
+
+
+def _plain(tag, match, launch, n, per=None, graph=0):
+    """PLAIN mode: a marker launch (navsim_odometry, used by no leg) in front of and behind n launches of the leg -- replayed from a hipGraph
+    of `graph` launches where the HIP-event measurement replays one (the step kernels: back-to-back dispatches, as in a rollout graph);
+    the manifest says which kernel names belong to the leg and how many units (launches / epochs) the summed duration is divided by."""
+    if graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for _ in range(graph):
+                launch()
+        g.replay()
+        _marker()
+        for _ in range(max(1, n // graph)):
+            g.replay()
+        n = max(1, n // graph) * graph
+    else:
+        _marker()
+        for _ in range(n):
+            launch()
+    _marker()
+    _MANIFEST.append(dict(leg=tag, match=list(match), per=int(per if per is not None else n)))
+    return float("nan")
+
+
+def rocprof_legs(argv):
+    """Runs `bench.py --kernel-trace-legs` under rocprofv3 --kernel-trace and returns {leg: {"us": mean kernel time per unit, "n": dispatches}}
+    (None + reason if that is not possible here)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="navbot_rocprof_", dir="/tmp")
+    env = dict(os.environ, NAVBOT_BENCH_PLAIN="1", TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NAVBOT_DIST_FORCE"):
+        env.pop(k, None)
+    cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+           "--kernel-trace-legs"] + list(argv)
+    try:
+        r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("MANIFEST ")]
+        files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not lines or not files:
+            return None, f"rocprofv3 run failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+        manifest = json.loads(lines[-1][len("MANIFEST "):])
+        rows = list(csv.DictReader(open(files[0])))
+        rows.sort(key=lambda x: int(x["Start_Timestamp"]))
+        marks, segs = 0, {}   # leg k = the dispatches between marker 2 k and marker 2 k + 1 (warm-up launches sit outside)
+        for x in rows:
+            name = x["Kernel_Name"]
+            if "odometry_kernel" in name:
+                marks += 1
+                continue
+            if marks % 2 == 1:
+                segs.setdefault(marks // 2, []).append((name, int(x["End_Timestamp"]) - int(x["Start_Timestamp"])))
+        out = {}
+        for k, m in enumerate(manifest):
+            durs = [dur for name, dur in segs.get(k, []) if any(t in name for t in m["match"])]
+            if durs:
+                names = sorted({name.split("(")[0][-70:] for name, dur in segs.get(k, []) if any(t in name for t in m["match"])})
+                out[m["leg"]] = dict(us=sum(durs) / 1e3 / m["per"], n=len(durs), min_us=min(durs) / 1e3, max_us=max(durs) / 1e3, per=m["per"], kernels=names)
+        save = os.environ.get("NAVBOT_BENCH_SAVE_PROF")   # (tools/prof_r06.sh: the per-leg summary the line was computed from, for profiles/)
+        if save:
+            with open(save, "w") as f:
+                f.write("leg,dispatches,units,mean_us_per_unit,min_dispatch_us,max_dispatch_us,kernels\n")
+                for leg, v in out.items():
+                    f.write(f"{leg},{v['n']},{v['per']},{v['us']:.3f},{v['min_us']:.3f},{v['max_us']:.3f},\"{' | '.join(v['kernels'])}\"\n")
+        return out, f"rocprofv3 --kernel-trace of this command's own legs ({len(rows)} dispatches)"
+    except Exception as e:   # noqa: BLE001 -- the bench line must still be printed
+        return None, f"rocprofv3 run failed: {e!r}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def apply_rocprof(leg, prof, key):
+    """A leg's `frac` / `achieved` (+ launch_us / us_per_step / epoch time) from the rocprofv3 kernel time of the same leg; the HIP-event
+    figures move to *_hip_events."""
+    if not leg or not prof or key not in prof:
+        if leg is not None:
+            leg["time_source"] = "hip events (no rocprofv3 figure for this leg)"
+        return leg
+    us = prof[key]["us"]
+    tkey = "launch_us" if "launch_us" in leg else "epoch_us" if "epoch_us" in leg else "epoch_ms" if "epoch_ms" in leg else None
+    if tkey is None:
+        return leg
+    old_us = leg[tkey] * (1e3 if tkey == "epoch_ms" else 1.0)
+    scale = old_us / us
+    leg["frac_hip_events"], leg["achieved_hip_events"], leg[tkey + "_hip_events"] = leg["frac"], leg["achieved"], leg[tkey]
+    leg["frac"] = round(leg["frac"] * scale, 5)
+    leg["achieved"] = round(leg["achieved"] * scale, 2)
+    leg[tkey] = round(us / (1e3 if tkey == "epoch_ms" else 1.0), 3)
+    if "us_per_step" in leg and "steps_per_launch" in leg:
+        leg["us_per_step"] = round(us / leg["steps_per_launch"], 3)
+    if "env_steps_per_sec" in leg:
+        leg["env_steps_per_sec"] = round(leg["env_steps_per_sec"] * scale, 1)
+    for sub in ("f32_equivalent", "executed"):
+        if isinstance(leg.get(sub), dict):
+            leg[sub]["frac"] = round(leg[sub]["frac"] * scale, 4)
+            leg[sub]["achieved"] = round(leg[sub]["achieved"] * scale, 2)
+    if "frac_of_achievable_hbm" in leg:
+        leg["frac_of_achievable_hbm"] = round(leg["frac_of_achievable_hbm"] * scale, 5)
+    leg["time_source"] = f"rocprofv3 --kernel-trace, live ({prof[key]['n']} dispatches)"
+    return leg
+
+
 def _event_time_ms(fn, iters, warm=20, per_graph=64):
     """Mean duration of one `fn()` (one kernel launch on torch's current stream) from HIP events recorded on that
     stream.  The launches are replayed from a hipGraph of `per_graph` launches so the ~12 us python/ctypes launch path
@@ -144,7 +269,7 @@ class CastWorkload:
         return d
 
 
-def step_kernel_roofline(w, iters=640, detail=""):
+def step_kernel_roofline(w, iters=640, detail="", tag=None):
     """HIP-event timing of navsim_step alone -- ONE launch per env step, the entry point a policy outside the kernel drives
     (Env.step, environment_new.py:272-310) -- with random actions resident in HBM."""
     sim = w.sim()
@@ -159,12 +284,12 @@ def step_kernel_roofline(w, iters=640, detail=""):
         sim.step(acts[k[0] & 63], io.obs, io.reward, io.done, io.arrive, io.ended, io.ep_return, io.ep_length)
         k[0] += 1
 
-    ms = _event_time_ms(launch, iters)
+    ms = _plain(tag, ["::step_kernel<"], launch, 320, graph=64) if PLAIN else _event_time_ms(launch, iters)
     sim.close()
     return w.leg("step_kernel<%d beams,%s> (navsim_step: one launch per step)" % (w.B, "per_env" if w.per_env else "shared"), ms, 1, detail)
 
 
-def step_seq_roofline(w, T, reps=12, detail=""):
+def step_seq_roofline(w, T, reps=12, detail="", tag=None):
     """HIP-event timing of navsim_step_seq: T steps of a random action tape (resident in HBM) per launch, the env state on chip
     between the steps.  Algorithmic bytes per launch = T x n_envs x (134 + 16 S) (SURVEY.md 8(d) per env-step)."""
     sim = w.sim()
@@ -182,13 +307,16 @@ def step_seq_roofline(w, T, reps=12, detail=""):
     for _ in range(2):
         launch()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        launch()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    if PLAIN:
+        ms = _plain(tag, ["::steps_kernel<"], launch, min(reps, 6))
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
     sim.close()
     return w.leg("steps_kernel<%d beams,%s> (navsim_step_seq: %d steps per launch, same step body as step_kernel)"
                  % (w.B, "per_env" if w.per_env else "shared", T), ms, T, detail)
@@ -205,7 +333,7 @@ def cpu_baseline(n_envs, procs, budget_s):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-def closed_loop_roofline(w, T, reps=8, detail=""):
+def closed_loop_roofline(w, T, reps=8, detail="", tag=None):
     """HIP-event timing of navsim_rollout_mlp64 at a configs[2]-sized shard (rollout_big_kernel): the ray-cast run CLOSED-LOOP -- the
     16-64-64 actor chooses every action from the observation the previous step left on chip (PPO.rollout, ppo.py:505-594), T steps
     per launch.  Algorithmic bytes per launch = T x n_envs x (134 + 16 S), the env-step figure of SURVEY.md 8(d): the 12 bytes of
@@ -221,13 +349,16 @@ def closed_loop_roofline(w, T, reps=8, detail=""):
     for _ in range(2):
         tr._persistent_rollout()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        tr._persistent_rollout()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    if PLAIN:
+        ms = _plain(tag, ["::rollout_big_kernel<", "::rollout_kernel<"], tr._persistent_rollout, min(reps, 6))
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            tr._persistent_rollout()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
     env.close()
     d = w.leg("rollout_big_kernel<64 envs, 16 waves, %s> (navsim_rollout_mlp64: %d steps per launch, policy phase + the step "
               "body of step_kernel)" % ("per_env" if w.per_env else "shared", T), ms, T, detail)
@@ -235,26 +366,29 @@ def closed_loop_roofline(w, T, reps=8, detail=""):
     return d
 
 
-def rollout_kernel_leg(trainer, reps=6):
+def rollout_kernel_leg(trainer, reps=6, tag=None):
     """The persistent rollout kernel of the timed workload alone (HIP events on its stream)."""
     T, N = trainer.cfg.rollout_len, trainer.env.N
     trainer.env.sim.reset(trainer.obs_buf[0])
     trainer._persistent_rollout()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        trainer._persistent_rollout()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    if PLAIN:
+        ms = _plain(tag, ["::rollout_kernel<", "::rollout_big_kernel<"], trainer._persistent_rollout, reps)
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            trainer._persistent_rollout()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
     alg = T * N * 134 + 16 * 32           # SURVEY 8(d): 134 B per env-step with a shared map (+ the map once)
     ach = alg / (ms * 1e-3) / 1e9
     return dict(bound="hbm", bound_detail="latency chain: one workgroup per CU runs T dependent steps (policy MFMA -> f64 motion -> "
                 "cast -> rules); bytes are irrelevant at this size", kernel="rollout_kernel<16,8 waves>",
                 workload=f"{N} envs x {T} steps, stage_1 (32 segments, shared map), 10 beams, 16-64-64 policy in-kernel",
                 achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
-                launch_us=round(ms * 1e3, 1), us_per_step=round(ms * 1e3 / T, 3), algorithmic_bytes_per_launch=int(alg),
+                launch_us=round(ms * 1e3, 1), steps_per_launch=T, us_per_step=round(ms * 1e3 / T, 3), algorithmic_bytes_per_launch=int(alg),
                 env_steps_per_sec=round(T * N / (ms * 1e-3), 1))
 
 
@@ -290,7 +424,7 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 
 MFMA_F32_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 
 
-def resmlp512_update_roofline(tr, reps=5):
+def resmlp512_update_roofline(tr, reps=5, tag=None):
     """The update kernels of the 512-wide nets alone: HIP events around whole epochs on the trainer's own buffers (the epoch is 8
     launches on one stream).  `achieved` / `frac` count the ALGORITHMIC float32 FLOP -- 131,072 MACs per sample and net (W1a 16x512,
     W2a 512x16, W1b 32x512, W2b 512x32, forward + both backward products) -- against the f32-input MFMA peak; `executed` adds the
@@ -305,13 +439,16 @@ def resmlp512_update_roofline(tr, reps=5):
     st = torch.zeros(8, device=obs.device)
     up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    if PLAIN:
+        ms = _plain(tag, ["resmlp_"], lambda: up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st), reps)
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
     flop = 2 * 2 * 131072 * T * N
     flop_exec = 2 * 2 * 155648 * T * N
     return dict(bound="mfma", kernel="navppo_resmlp512_update_epoch (resmlp_fwd<16|32>, resmlp_bwd<16|32>, 3 streaming kernels, reduce+Adam)",
@@ -325,7 +462,7 @@ def resmlp512_update_roofline(tr, reps=5):
                        "lanes, the loop sustains ~2.2 GHz)")
 
 
-def resmlp512_leg(n_envs, rollout, epochs, steps=2):
+def resmlp512_leg(n_envs, rollout, epochs, steps=2, prof=None):
     """SURVEY 8(d) cfg 2 "reported alongside": the reference's ACTIVE nets (net_actor.py:56-144, net_critic.py:50-130) on the
     same workload: fused HIP update (csrc/ppo_resmlp512.hip), rollout in one persistent launch (navsim_rollout_resmlp512: the policy
     step of csrc/resmlp_policy.h in front of every env step; round 4 ran a hipGraph of policy launch + step launch per step)."""
@@ -344,7 +481,7 @@ def resmlp512_leg(n_envs, rollout, epochs, steps=2):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     up = tr.updater
-    roof = resmlp512_update_roofline(tr)
+    roof = apply_rocprof(resmlp512_update_roofline(tr), prof, "resmlp512.update_roofline")
     env.close()
     return dict(policy="resmlp512", value=round(steps * rollout * n_envs / dt, 1), unit="env-steps/s", steps=steps,
                 ms_per_step=round(dt / steps * 1e3, 2), rollout_ms=round(r / steps * 1e3, 2), update_ms=round(u / steps * 1e3, 2),
@@ -402,7 +539,7 @@ def ppo_shard_leg(n_envs, world, n_beams, obs_f16, sampler, rollout, epochs, det
     return out
 
 
-def mlp64_update_roofline(tr, reps=40, arith=None):
+def mlp64_update_roofline(tr, reps=40, arith=None, tag=None):
     """The update kernels of the TIMED workload alone (94 % of the timed region): HIP events around whole epochs of
     navppo_mlp64[_bf16x3]_update_epoch (pass kernel + reduce_adam) on the trainer's own rollout buffers.  arith: None = the arithmetic
     the trainer runs (PPOConfig.update_arith), "f32" / "bf16x3" = that one (same buffers, same weights: the two legs are like for like)."""
@@ -430,13 +567,16 @@ def mlp64_update_roofline(tr, reps=40, arith=None):
         for _ in range(10):   # the clock settles on the MFMA loop's level within a few epochs
             up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        if PLAIN:
+            ms = _plain(tag, ["::mlp64_pass_both", "::reduce_adam<"], lambda: up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st), min(reps, 20))
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                up._fused_epoch(obs, acts, logp, rtg, adv, 0.8, st)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
         x3 = up.bf16x3
     finally:
         up.bf16x3 = was
@@ -610,14 +750,87 @@ def shard_valu(leg, key):
     leg["valu_issue_frac_step"] = round(v["valu_busy_us_per_simd_at_2p4GHz"] / leg["step_us"], 4) if v else None
 
 
-def shard_leg(w, T, detail):
+def shard_leg(w, T, detail, tag=None, prof=None):
     """One GPU's shard of a BASELINE 8-GPU configuration: us per step one launch per step and one launch per tape, env-steps/s."""
-    a = step_kernel_roofline(w, iters=64 * 200, detail=detail)
-    b = step_seq_roofline(w, T, reps=6, detail=detail)
-    return dict(workload=w.describe(), step_us=a["launch_us"], tape_us_per_step=b["us_per_step"], env_steps_per_sec_step=a["env_steps_per_sec"],
+    a = apply_rocprof(step_kernel_roofline(w, iters=64 * 200, detail=detail, tag=f"{tag}.step"), prof, f"{tag}.step")
+    b = apply_rocprof(step_seq_roofline(w, T, reps=6, detail=detail, tag=f"{tag}.tape"), prof, f"{tag}.tape")
+    if PLAIN:
+        return None
+    return dict(time_source=a.get("time_source"), workload=w.describe(), step_us=a["launch_us"], tape_us_per_step=b["us_per_step"], env_steps_per_sec_step=a["env_steps_per_sec"],
                 env_steps_per_sec_tape=b["env_steps_per_sec"], bytes_per_env_step=w.bytes_per_env_step,
                 hbm_frac_step=a["frac"], hbm_frac_tape=b["frac"], bound_detail=detail,
                 ray_segment_tests_per_sec_tape=round(w.n_envs * w.S * w.B / (b["us_per_step"] * 1e-6), 1))
+
+
+def kernel_legs(trainer, prof):
+    """Every roofline leg of the line, in a fixed order -- run with HIP events by the bench itself and, in the child process under
+    rocprofv3 (PLAIN), as plain launches behind markers; `prof` (the child's per-leg kernel times) then replaces the event figures."""
+    out = {}
+    ap = lambda leg, key: apply_rocprof(leg, prof, key)
+    # GPU legs first and long enough (several seconds in total) for an outside utilisation sampler to see them
+    out["roofline_timed_region"] = ap(rollout_kernel_leg(trainer, tag="roofline_timed_region"), "roofline_timed_region") if trainer.updater.fused_mlp64 else None
+    out["update_roofline"] = ap(mlp64_update_roofline(trainer, tag="update_roofline"), "update_roofline")   # the arithmetic the timed region ran
+    out["update_roofline_f32"] = ap(mlp64_update_roofline(trainer, arith="f32", tag="update_roofline_f32"), "update_roofline_f32")   # the native f32-MFMA pass, same buffers
+    if out["update_roofline"] and out["update_roofline"]["arith"] != "bf16x3":
+        out["update_roofline_bf16x3"] = ap(mlp64_update_roofline(trainer, arith="bf16x3", tag="update_roofline_bf16x3"), "update_roofline_bf16x3")
+    # The ray-cast run of BASELINE configs[2].  `roofline` is the entry point the north star names -- navsim_step, ONE launch per
+    # env step, what a policy outside the kernel drives (Env.step, environment_new.py:272-310; like for like with rounds 1-2) --
+    # and beside it the two persistent forms of the same step body: closed loop (the 16-64-64 policy in the kernel: PPO.rollout,
+    # ppo.py:505-594) and an open-loop action tape (replay / evaluation form: the actions do not depend on the observations).
+    l3 = "working set 35.7 MB per step sits in the 256 MiB Infinity Cache: L3-fed, VALU-issue bound at this size"
+    w = CastWorkload(16384, "stage_2", per_env=True)
+    out["roofline"] = ap(step_kernel_roofline(
+        w, iters=64 * 1500, detail=l3 + "; one step per launch: + launch ramp of 256 x 16 waves, state round trips, graph-node boundary", tag="roofline"), "roofline")
+    out["roofline_closed_loop"] = ap(closed_loop_roofline(
+        w, T=256, detail=l3 + "; the 16-64-64 policy chooses every action in-kernel (PPO.rollout closed-loop): + the policy phase, "
+                           "bound by the SIMDs' f32 MFMA pipes (64 envs x 10.2 kFLOP per CU and step = 1.07 us)", tag="roofline_closed_loop"), "roofline_closed_loop")
+    out["roofline_open_loop_tape"] = ap(step_seq_roofline(
+        w, T=256, detail=l3 + "; open loop: the 256 actions of a launch are known ahead (replay / evaluation), NOT what PPO.rollout does",
+        tag="roofline_open_loop_tape"), "roofline_open_loop_tape")
+    del w
+    # the same three at S = 1024 per env: 16384 x 1024 x 16 B = exactly 256 MiB = the Infinity Cache size (AT the L3, not beyond it)
+    at = "segment stream 268 MB per step = the 256 MiB Infinity Cache size: no L2 reuse, L3 hits possible"
+    w = CastWorkload(16384, "stage_2", per_env=True, sides=248)
+    out["roofline_at_l3"] = ap(step_kernel_roofline(w, iters=64 * 400, detail=at + "; one step per launch", tag="roofline_at_l3"), "roofline_at_l3")
+    out["roofline_at_l3_closed_loop"] = ap(closed_loop_roofline(w, T=64, detail=at + "; closed loop (policy in the kernel)", tag="roofline_at_l3_closed_loop"),
+                                           "roofline_at_l3_closed_loop")
+    out["roofline_at_l3_open_loop_tape"] = ap(step_seq_roofline(w, T=64, detail=at + "; open-loop tape", tag="roofline_at_l3_open_loop_tape"),
+                                              "roofline_at_l3_open_loop_tape")
+    del w
+    torch.cuda.empty_cache()
+    # ... and at S = 2048 per env (the size SURVEY.md section 7 names for the HBM-bound regime): 512 MiB per step = 2x the Infinity
+    # Cache, so every segment byte of a step comes from HBM; frac = of the 8 TB/s spec, frac_of_achievable_hbm = of the ~6.3 TB/s
+    # the guide gives as achievable
+    hb = "segment stream 537 MB per step = 2x the 256 MiB Infinity Cache: HBM-bound"
+    w = CastWorkload(16384, "stage_2", per_env=True, sides=504)
+    out["roofline_hbm"] = ap(step_kernel_roofline(w, iters=64 * 200, detail=hb + "; one step per launch", tag="roofline_hbm"), "roofline_hbm")
+    out["roofline_hbm_closed_loop"] = ap(closed_loop_roofline(w, T=32, reps=6, detail=hb + "; closed loop (policy in the kernel)", tag="roofline_hbm_closed_loop"),
+                                         "roofline_hbm_closed_loop")
+    out["roofline_hbm_open_loop_tape"] = ap(step_seq_roofline(w, T=32, reps=6, detail=hb + "; open-loop tape", tag="roofline_hbm_open_loop_tape"),
+                                            "roofline_hbm_open_loop_tape")
+    del w
+    torch.cuda.empty_cache()
+    if not PLAIN:
+        for k, t in (("roofline", "cfg3_step"), ("roofline_closed_loop", "cfg3_closed_loop"), ("roofline_open_loop_tape", "cfg3_seq"),
+                     ("roofline_at_l3", "s1024_step"), ("roofline_at_l3_closed_loop", "s1024_closed_loop"), ("roofline_at_l3_open_loop_tape", "s1024_seq"),
+                     ("roofline_hbm", "s2048_step"), ("roofline_hbm_closed_loop", "s2048_closed_loop"), ("roofline_hbm_open_loop_tape", "s2048_seq")):
+            out[k]["traffic"] = profiled_traffic(t + "_bytes_per_launch")
+    # one GPU's shard of the two 8-GPU configurations of BASELINE.json (shared maps: VALU-bound, SURVEY 8d caveat -- the byte
+    # fraction is nominal there, the vector-issue fraction from the counters says how busy the SIMDs are)
+    out["cfg4_shard"] = shard_leg(CastWorkload(4096, "stage_4", per_env=False, n_beams=36), 128,
+                                  "BASELINE configs[3] per GPU: 32768 / 8 envs, stage_4 (64 segments, shared), 36 beams", "cfg4_shard", prof)
+    out["cfg5_shard"] = shard_leg(CastWorkload(8192, "house", per_env=False, obs_f16=True, sampler="small_house", house_segments=2048), 64,
+                                  "BASELINE configs[4] per GPU: 65536 / 8 envs, 2048-segment house map (shared, tile boxes), f16 "
+                                  "observations, start / goal tables", "cfg5_shard", prof)
+    if PLAIN:   # the update of the reference's ACTIVE nets (its own leg of the line, resmlp512_leg, takes the figure from here)
+        from navbot_ppo_amd import ppo
+        from navbot_ppo_amd.env import VecEnv
+        env = VecEnv(trainer.env.N, map="stage_1", max_episode_steps=500, seed=0)
+        tr = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=trainer.cfg.rollout_len, n_updates_per_iteration=1, policy="resmlp512", seed=0))
+        tr.iteration()
+        resmlp512_update_roofline(tr, reps=3, tag="resmlp512.update_roofline")
+        env.close()
+    return out
 
 
 def main():
@@ -640,8 +853,22 @@ def main():
                     help="arithmetic of the fused 16-64-64 update's matrix products (PPOConfig.update_arith)")
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="N > 1, mlp64x2: the two-stage per-net pipeline instead of one all-reduce of the flat gradient per epoch")
+    ap.add_argument("--kernel-trace-legs", action="store_true",
+                    help="(run by the bench itself under rocprofv3, NAVBOT_BENCH_PLAIN=1) only the roofline legs, as plain launches behind markers")
     args = ap.parse_args()
     PMC_FILE[0] = args.with_pmc_file
+    if args.kernel_trace_legs:
+        if not PLAIN:
+            raise SystemExit("--kernel-trace-legs is run by bench.py itself (NAVBOT_BENCH_PLAIN=1)")
+        from navbot_ppo_amd import ppo
+        from navbot_ppo_amd.env import VecEnv
+        env = VecEnv(args.envs_per_gpu, map="stage_1", n_beams=10, max_episode_steps=500, auto_reset=True, seed=0)
+        trainer = ppo.PPOTrainer(env, ppo.PPOConfig(rollout_len=args.rollout, max_episode_steps=500, n_updates_per_iteration=1, policy=args.policy,
+                                                    seed=0, update_arith=args.update_arith))
+        trainer.iteration()   # the buffers the update legs run on
+        kernel_legs(trainer, None)
+        print("MANIFEST " + json.dumps(_MANIFEST), flush=True)
+        return
 
     from navbot_ppo_amd import ppo
     from navbot_ppo_amd.env import VecEnv
@@ -720,63 +947,14 @@ def main():
         }
     if not args.no_extras and ctx.rank == 0:   # rank 0 only (the other ranks wait at the barrier below)
         # GPU legs first and long enough (several seconds in total) for an outside utilisation sampler to see them
-        out["roofline_timed_region"] = rollout_kernel_leg(trainer) if trainer.updater.fused_mlp64 else None
-        out["update_roofline"] = mlp64_update_roofline(trainer)                       # the arithmetic the timed region ran
-        out["update_roofline_f32"] = mlp64_update_roofline(trainer, arith="f32")       # the native f32-MFMA pass on the same buffers
-        if out["update_roofline"] and out["update_roofline"]["arith"] != "bf16x3":
-            out["update_roofline_bf16x3"] = mlp64_update_roofline(trainer, arith="bf16x3")
+        prof, prof_src = rocprof_legs(["--envs-per-gpu", str(n_local), "--rollout", str(args.rollout), "--epochs", str(args.epochs), "--policy", args.policy,
+                                       "--update-arith", args.update_arith])
+        out["roofline_time_source"] = prof_src
+        out.update(kernel_legs(trainer, prof))
         del trainer
         torch.cuda.empty_cache()
-        # The ray-cast run of BASELINE configs[2].  `roofline` is the entry point the north star names -- navsim_step, ONE launch per
-        # env step, what a policy outside the kernel drives (Env.step, environment_new.py:272-310; like for like with rounds 1-2) --
-        # and beside it the two persistent forms of the same step body: closed loop (the 16-64-64 policy in the kernel: PPO.rollout,
-        # ppo.py:505-594) and an open-loop action tape (replay / evaluation form: the actions do not depend on the observations).
-        l3 = "working set 35.7 MB per step sits in the 256 MiB Infinity Cache: L3-fed, VALU-issue bound at this size"
-        w = CastWorkload(16384, "stage_2", per_env=True)
-        out["roofline"] = step_kernel_roofline(
-            w, iters=64 * 1500, detail=l3 + "; one step per launch: + launch ramp of 256 x 16 waves, state round trips, graph-node boundary")
-        out["roofline"]["traffic"] = profiled_traffic("cfg3_step_bytes_per_launch")
-        out["roofline_closed_loop"] = closed_loop_roofline(
-            w, T=256, detail=l3 + "; the 16-64-64 policy chooses every action in-kernel (PPO.rollout closed-loop): + the policy phase, "
-                               "bound by the SIMDs' f32 MFMA pipes (64 envs x 10.2 kFLOP per CU and step = 1.07 us)")
-        out["roofline_closed_loop"]["traffic"] = profiled_traffic("cfg3_closed_loop_bytes_per_launch")
-        out["roofline_open_loop_tape"] = step_seq_roofline(
-            w, T=256, detail=l3 + "; open loop: the 256 actions of a launch are known ahead (replay / evaluation), NOT what PPO.rollout does")
-        out["roofline_open_loop_tape"]["traffic"] = profiled_traffic("cfg3_seq_bytes_per_launch")
-        del w
-        # the same three at S = 1024 per env: 16384 x 1024 x 16 B = exactly 256 MiB = the Infinity Cache size (AT the L3, not beyond it)
-        at = "segment stream 268 MB per step = the 256 MiB Infinity Cache size: no L2 reuse, L3 hits possible"
-        w = CastWorkload(16384, "stage_2", per_env=True, sides=248)
-        out["roofline_at_l3"] = step_kernel_roofline(w, iters=64 * 400, detail=at + "; one step per launch")
-        out["roofline_at_l3"]["traffic"] = profiled_traffic("s1024_step_bytes_per_launch")
-        out["roofline_at_l3_closed_loop"] = closed_loop_roofline(w, T=64, detail=at + "; closed loop (policy in the kernel)")
-        out["roofline_at_l3_closed_loop"]["traffic"] = profiled_traffic("s1024_closed_loop_bytes_per_launch")
-        out["roofline_at_l3_open_loop_tape"] = step_seq_roofline(w, T=64, detail=at + "; open-loop tape")
-        out["roofline_at_l3_open_loop_tape"]["traffic"] = profiled_traffic("s1024_seq_bytes_per_launch")
-        del w
-        torch.cuda.empty_cache()
-        # ... and at S = 2048 per env (the size SURVEY.md section 7 names for the HBM-bound regime): 512 MiB per step = 2x the Infinity
-        # Cache, so every segment byte of a step comes from HBM; frac = of the 8 TB/s spec, frac_of_achievable_hbm = of the ~6.3 TB/s
-        # the guide gives as achievable
-        hb = "segment stream 537 MB per step = 2x the 256 MiB Infinity Cache: HBM-bound"
-        w = CastWorkload(16384, "stage_2", per_env=True, sides=504)
-        out["roofline_hbm"] = step_kernel_roofline(w, iters=64 * 200, detail=hb + "; one step per launch")
-        out["roofline_hbm"]["traffic"] = profiled_traffic("s2048_step_bytes_per_launch")
-        out["roofline_hbm_closed_loop"] = closed_loop_roofline(w, T=32, reps=6, detail=hb + "; closed loop (policy in the kernel)")
-        out["roofline_hbm_closed_loop"]["traffic"] = profiled_traffic("s2048_closed_loop_bytes_per_launch")
-        out["roofline_hbm_open_loop_tape"] = step_seq_roofline(w, T=32, reps=6, detail=hb + "; open-loop tape")
-        out["roofline_hbm_open_loop_tape"]["traffic"] = profiled_traffic("s2048_seq_bytes_per_launch")
-        del w
-        torch.cuda.empty_cache()
         out["traffic_source"] = traffic_source()
-        # one GPU's shard of the two 8-GPU configurations of BASELINE.json (shared maps: VALU-bound, SURVEY 8d caveat -- the byte
-        # fraction is nominal there, the vector-issue fraction from the counters says how busy the SIMDs are)
-        out["cfg4_shard"] = shard_leg(CastWorkload(4096, "stage_4", per_env=False, n_beams=36), 128,
-                                      "BASELINE configs[3] per GPU: 32768 / 8 envs, stage_4 (64 segments, shared), 36 beams")
         shard_valu(out["cfg4_shard"], "cfg4_valu")
-        out["cfg5_shard"] = shard_leg(CastWorkload(8192, "house", per_env=False, obs_f16=True, sampler="small_house", house_segments=2048), 64,
-                                      "BASELINE configs[4] per GPU: 65536 / 8 envs, 2048-segment house map (shared, tile boxes), f16 "
-                                      "observations, start / goal tables")
         shard_valu(out["cfg5_shard"], "cfg5_valu")
         # ... and the same shards as PPO workloads on their own observation formats, end to end per GPU
         out["cfg4_ppo_shard"] = ppo_shard_leg(4096, "stage_4", 36, False, None, args.rollout, args.epochs,
@@ -793,7 +971,7 @@ def main():
             ttr = time_to_reward(n_local)
             out["time_to_reward_s"] = ttr["seconds"]
             out["time_to_reward"] = ttr
-            out["resmlp512"] = resmlp512_leg(n_local, args.rollout, args.epochs)
+            out["resmlp512"] = resmlp512_leg(n_local, args.rollout, args.epochs, prof=prof)
             cores = os.cpu_count() or 1
             out["env_n1_step_us"] = env_n1_step_us()
             out["cpu_baseline"] = cpu_baseline(n_local, 1, 8.0)
