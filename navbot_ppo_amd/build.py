@@ -28,7 +28,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SRCS + [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h", "resmlp_policy.h", "bf16x3.h", "ppo_mlp64_x3s.h")]
+    deps = SRCS + [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h", "resmlp_policy.h", "bf16x3.h", "ppo_mlp64_x3s.h", "ppo_resmlp512_bwd2s.h")]
     return any(os.path.getmtime(p) > t for p in deps)
 
 
@@ -36,7 +36,12 @@ def needs_build():
 # steps, and MachineLICM then hoists every 64-bit constant the body materialises (the float64 polynomial coefficients of sincos,
 # atan, ...) out of that loop and keeps them in registers across it: 200-256 VGPRs and scratch spills in the 16-wave shape,
 # against 82-101 VGPRs (two workgroups per CU) with the pass off.  The single-step kernels have no such loop and do not change.
-EXTRA_FLAGS = {"navsim.hip": ["-mllvm", "-disable-machine-licm"]}
+# ppo_resmlp512.hip: resmlp_bwd2s pins its 32 accumulator tiles to a[0:127] with physical-register asm constraints; with the default
+# priority the greedy allocator still splits one of them through VGPRs right behind an MFMA (a hazard the compiler cannot see inside the
+# asm: tools/verify/mfma_hazard_lint.py, tests/test_isa_lint_cpu.py) and copies 8 more registers per tile; with register-class priority
+# first it does neither.  (The other kernels of the file: same registers, no spills either way.)
+EXTRA_FLAGS = {"navsim.hip": ["-mllvm", "-disable-machine-licm"],
+               "ppo_resmlp512.hip": ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1"]}
 
 _flag_ok = {}
 
@@ -72,7 +77,7 @@ def build_native(force=False, verbose=False, navsim_src=None, out=None, extra=()
     procs, objs = [], []
     srcs = SRCS if navsim_src is None else [navsim_src] + SRCS[1:]
     lib_out = LIB if out is None else out
-    hdrs = [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h", "resmlp_policy.h", "bf16x3.h", "ppo_mlp64_x3s.h")]
+    hdrs = [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h", "resmlp_policy.h", "bf16x3.h", "ppo_mlp64_x3s.h", "ppo_resmlp512_bwd2s.h")]
     for k, src in enumerate(srcs):   # the sources compile side by side
         obj = os.path.join(objdir, os.path.basename(SRCS[k]) + ".o")
         per_src = [] if os.environ.get("NAVSIM_NO_EXTRA_FLAGS") == "1" else EXTRA_FLAGS.get(os.path.basename(SRCS[k]), [])   # (A/B builds)

@@ -46,6 +46,10 @@
 // the f32 MFMA because the count says so or the measurement did: rb1's 16-wide products with a hidden operand (the split costs
 // more than it saves), resmlp_bwd<16> altogether (K = 16 fills half a k-step; both narrow products split: 2208 vs 2269-2308 us,
 // no room in its 256 registers), Q = W1^T dH of resmlp_bwd<32> (dH would need a second, transposed split).
+// Round 6: resmlp_bwd<32> is replaced at the launch by resmlp_bwd2s (csrc/ppo_resmlp512_bwd2s.h: the same products as one hand-placed,
+// half-chunk-pipelined instruction stream; X / dY split once per tile, their transposes and Q's operand through bf16 LDS images and
+// ds_read_b64_tr_b16; Q on the bf16 MFMA): 4304 -> 3204 us, 9.90 -> 8.81 ms per epoch.  resmlp_bwd<32, 2, 4> stays in the file as the
+// compiler-scheduled statement of the same arithmetic (-DRESMLP_BWD2S=0 selects it).
 // Layout ("16-layout"): a [rows, 32 samples] activation lives as f32x4 v[rows / 16][2]: lane
 // (n = lane & 15, q = lane >> 4) holds rows 16 b + 4 q + r (r = 0..3) of sample 16 st + n -- which is both the C/D layout of
 // the MFMA and, register r taken as the B operand of step r, a legal k-pairing when the A operand (weights) is read
@@ -63,6 +67,7 @@
 #include <cmath>
 #include <cstdint>
 #include <string>
+#include <type_traits>
 
 #include "mlp64_policy.h"   // Philox / Box-Muller noise of the rollout policy step (same stream as the mlp64x2 path)
 #include "navppo.h"
@@ -744,6 +749,8 @@ __global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__
     }
 }
 
+#include "ppo_resmlp512_bwd2s.h"   // round 6: resmlp_bwd<32, 2, 4> as one hand-placed, chunk-pipelined instruction stream
+
 // ---------------------------------------------------------------- streaming kernels (element-wise + reductions over samples)
 // block-wide sum of per-thread accumulators over the threads that share (tid & (LPS - 1)); result in row[col0 + 4 * og + k]
 template <int LPS, int NV>
@@ -1048,8 +1055,16 @@ int loss_grad_impl(const char* name, bool adam, float* params, const void* obs, 
     launch_forward(p, params, 0, 2, obs, f16, n, st);
     hipLaunchKernelGGL(resmlp_e2<false>, dim3(p.e_blocks, 2), dim3(kEThreads), 0, st, (const float*)params, 0, obs, (const float*)p.h1,
                        (const float*)p.p2, act, logp_old, rtg, adv, (long long)n, var, clip, inv_n, p.dy2, p.epart, (float*)nullptr, f16);
-    hipLaunchKernelGGL((resmlp_bwd<32, 2, kBwd2Waves>), dim3(p.wgs), dim3(64 * kBwd2Waves), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
-                       (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb, (const float*)nullptr, f16);
+    if constexpr (RESMLP_BWD2S && kBwd2Waves == b2s::SW) {
+        if (f16)
+            hipLaunchKernelGGL(resmlp_bwd2s<true>, dim3(p.wgs), dim3(64 * b2s::SW), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
+                               (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb);
+        else
+            hipLaunchKernelGGL(resmlp_bwd2s<false>, dim3(p.wgs), dim3(64 * b2s::SW), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
+                               (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb);
+    } else
+        hipLaunchKernelGGL((resmlp_bwd<32, 2, kBwd2Waves>), dim3(p.wgs), dim3(64 * kBwd2Waves), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
+                           (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb, (const float*)nullptr, f16);
     hipLaunchKernelGGL((resmlp_bwd<16, 2, kWaves>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
                        (const float*)p.dy2, (long long)n, p.groups, p.wpart, (float*)nullptr, (const float*)p.qb, f16);
     const int rblocks = (rp::P_ACTOR + rp::P_CRITIC + 63) / 64;

@@ -27,6 +27,26 @@ def test_asm_mfma_streams_have_no_unguarded_hazards(tmp_path):
     assert n2 > 100 and not bad2, bad2[:5]
 
 
+def test_asm_mfma_stream_of_the_512_wide_backward_has_no_unguarded_hazards(tmp_path):
+    """csrc/ppo_resmlp512_bwd2s.h: the same kind of stream for rb2's backward (both instantiations: float32 / float16 observation rows).
+    Compiled with the product's per-source flags -- the register-allocation flag of build.EXTRA_FLAGS is what keeps a copy of a pinned
+    accumulator tile from landing right behind the MFMA that writes it."""
+    from mfma_hazard_lint import lint
+    from navbot_ppo_amd import build
+    out = tmp_path / "ppo_resmlp512.s"
+    flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    extra = build.EXTRA_FLAGS.get("ppo_resmlp512.hip", [])
+    if extra and not build.flags_accepted(extra):
+        extra = []
+    subprocess.check_call([build.hipcc()] + flags + list(extra) + ["-I", build.INC, "-I", os.path.join(build.HERE, "csrc"), "-S", "--cuda-device-only",
+                                                                  os.path.join(build.HERE, "csrc", "ppo_resmlp512.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    for key in ("resmlp_bwd2sILb0", "resmlp_bwd2sILb1"):
+        n, bad = lint(str(out), key)
+        assert n >= 450, (key, n)      # 24 (prologue) + 432 per tile
+        assert not bad, (key, bad[:5])
+
+
 def test_lint_flags_the_measured_hazards(tmp_path):
     from mfma_hazard_lint import lint
     src = tmp_path / "k.s"
