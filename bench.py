@@ -451,15 +451,15 @@ def resmlp512_update_roofline(tr, reps=5, tag=None):
         ms = e0.elapsed_time(e1) / reps
     flop = 2 * 2 * 131072 * T * N
     flop_exec = 2 * 2 * 155648 * T * N
-    return dict(bound="mfma", kernel="navppo_resmlp512_update_epoch (resmlp_fwd<16|32>, resmlp_bwd<16|32>, 3 streaming kernels, reduce+Adam)",
+    return dict(bound="mfma", kernel="navppo_resmlp512_update_epoch (resmlp_fwd<16|32>, resmlp_bwd2s, resmlp_bwd<16>, 3 streaming kernels, reduce+Adam)",
                 achieved=round(flop / ms / 1e9, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4),
                 epoch_ms=round(ms, 3), flop_per_epoch=flop, traffic=None,
                 executed=dict(achieved=round(flop_exec / ms / 1e9, 2), frac=round(flop_exec / ms / 1e9 / MFMA_F32_PEAK_TF, 4), flop_per_epoch=flop_exec,
                               note="incl. the hidden layers recomputed in the backward kernels (155,648 instead of 131,072 MACs per sample and net)"),
                 detail="algorithmic float32 FLOP against the f32-input MFMA peak.  The products that fill a k-step of v_mfma_f32_16x16x32_bf16 "
-                       "(H, Y of resmlp_fwd<32>; H^T, dH^T, dW2, dW1 of resmlp_bwd<32> on 4 waves x 512 registers; H of resmlp_fwd<16>) run as "
-                       "float32 products from three-piece bf16 splits, the rest on v_mfma_f32_16x16x4_f32 (f32 MFMA and VALU share the SIMD's FMA "
-                       "lanes, the loop sustains ~2.2 GHz)")
+                       "(H, Y of resmlp_fwd<32>; H^T, dH^T, dW2, dW1, Q of rb2's backward -- resmlp_bwd2s, one hand-placed instruction stream per "
+                       "wave, 4 waves x 512 registers; H of resmlp_fwd<16>) run as float32 products from three-piece bf16 splits, the rest on "
+                       "v_mfma_f32_16x16x4_f32 (f32 MFMA and VALU share the SIMD's FMA lanes, the loop sustains ~2.2 GHz)")
 
 
 def resmlp512_leg(n_envs, rollout, epochs, steps=2, prof=None):

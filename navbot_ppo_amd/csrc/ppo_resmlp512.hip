@@ -93,6 +93,13 @@ constexpr int kWaves = 8, kThreads = 64 * kWaves;
 #ifndef RESMLP_BWD2_WAVES
 #define RESMLP_BWD2_WAVES 4
 #endif
+#ifndef RESMLP_BWD1_STACK
+#define RESMLP_BWD1_STACK 1
+#endif
+#ifndef RESMLP_BWD1_WAVES
+#define RESMLP_BWD1_WAVES 8
+#endif
+constexpr int kBwd1Waves = RESMLP_BWD1_WAVES;   // waves per workgroup of resmlp_bwd<16>
 constexpr int kBwd2Waves = RESMLP_BWD2_WAVES;   // waves per workgroup of resmlp_bwd<32> (4: with its narrow products on the bf16 MFMA)
 constexpr int LT = 36;               // row pitch of the wave tiles (floats): 16-byte rows, conflict-free ds_read_b128
 constexpr int kMaxWG = 256;          // one persistent workgroup per CU
@@ -169,6 +176,11 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma16bf(const uint4 a, const uint4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf16x3::as_bf(a), bf16x3::as_bf(b), c, 0, 0, 0);
 }
+// K16 (rb1: 16 inputs fill HALF a k-step): TWO piece products share one MFMA, stacked along k -- the operands arrive as the three
+// "stacks" (a2 | a1) (a0 | a1) (a0 | a0) of the weights and (b0 | b1) (b2 | b0) (b1 | b0) of the rows, so a2 b0 + a1 b1, a0 b2 + a1 b0,
+// a0 b1 + a0 b0 are THREE instructions instead of six (same six products, same small-to-large order; inside one instruction the MFMA
+// aligns all addends to the largest and rounds once: tools/ubench/bf16_mfma_rounding.hip).
+template <bool K16 = false>
 __device__ __forceinline__ void hidden_chunk_x3(const uint4* W1p /* [3][HS][4] */, const float* b1s, int c, const bf16x3::Pieces (&XP)[2],
                                                 f32x4 (&H)[2][2], int l15, int q) {
     bf16x3::Pieces A[2];
@@ -184,7 +196,11 @@ __device__ __forceinline__ void hidden_chunk_x3(const uint4* W1p /* [3][HS][4] *
     H[0][1] = mfma16bf(A[0].p[ia], XP[1].p[ib], H[0][1]);             \
     H[1][0] = mfma16bf(A[1].p[ia], XP[0].p[ib], H[1][0]);             \
     H[1][1] = mfma16bf(A[1].p[ia], XP[1].p[ib], H[1][1]);
-    RESMLP_X3_TERM(2, 0) RESMLP_X3_TERM(1, 1) RESMLP_X3_TERM(0, 2) RESMLP_X3_TERM(1, 0) RESMLP_X3_TERM(0, 1) RESMLP_X3_TERM(0, 0)
+    if constexpr (K16) {   // (A[jb].p[s], XP[st].p[s] hold stack s)
+        RESMLP_X3_TERM(0, 0) RESMLP_X3_TERM(1, 1) RESMLP_X3_TERM(2, 2)
+    } else {
+        RESMLP_X3_TERM(2, 0) RESMLP_X3_TERM(1, 1) RESMLP_X3_TERM(0, 2) RESMLP_X3_TERM(1, 0) RESMLP_X3_TERM(0, 1) RESMLP_X3_TERM(0, 0)
+    }
 #undef RESMLP_X3_TERM
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -206,7 +222,7 @@ struct FwdSmem {
     // rb2: W2 as pieces in the order the Y product consumes them: [piece][chunk c][output block ob][lane (m, q)] = eight bf16
     // W2[16 ob + m][32 c + 4 q + r], W2[16 ob + m][32 c + 16 + 4 q + r] -- the k-slots in which lane (n, q) holds its own H registers
     uint4 W2p[(IN == 32) ? 3 * NCH * 2 * 64 : 1];
-    uint4 W1p[3 * HS * 4];       // [piece][hidden j][k-group q] = eight bf16: W1[j][4 q + r], then W1[j][16 + 4 q + r] (rb1: zeros)
+    uint4 W1p[3 * HS * 4];       // [piece][hidden j][k-group q] = eight bf16: W1[j][4 q + r], then W1[j][16 + 4 q + r] (rb1: [stack][j][q], two pieces of W1[j][4 q + r])
 };
 
 // pout[net][slice][n][IN] = W2[:, slice] leaky(W1[slice] X + b1[slice])
@@ -229,8 +245,14 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
         const float4 lo = ld4(wr + 4 * kq), hi = (IN == 32) ? ld4(wr + (IN == 32 ? 16 : 0) + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         const bf16x3::Pieces P = bf16x3::split8(v);
+        if constexpr (IN == 16) {   // the stacks (a2 | a1) (a0 | a1) (a0 | a0): see hidden_chunk_x3<true>
+            sm.W1p[(0 * HS + j) * 4 + kq] = make_uint4(P.p[2].x, P.p[2].y, P.p[1].x, P.p[1].y);
+            sm.W1p[(1 * HS + j) * 4 + kq] = make_uint4(P.p[0].x, P.p[0].y, P.p[1].x, P.p[1].y);
+            sm.W1p[(2 * HS + j) * 4 + kq] = make_uint4(P.p[0].x, P.p[0].y, P.p[0].x, P.p[0].y);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) sm.W1p[(i * HS + j) * 4 + kq] = P.p[i];
+            for (int i = 0; i < 3; ++i) sm.W1p[(i * HS + j) * 4 + kq] = P.p[i];
+        }
     }
     if constexpr (IN == 32) {
         for (int k = tid; k < NCH * NB * 64; k += kThreads) {
@@ -296,16 +318,18 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
                 const float v[8] = {X[0][st][0], X[0][st][1], X[0][st][2], X[0][st][3], X[NB - 1][st][0], X[NB - 1][st][1], X[NB - 1][st][2], X[NB - 1][st][3]};
                 XP[st] = bf16x3::split8(v);
             } else {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) XP[st].p[i] = make_uint4(0u, 0u, 0u, 0u);
-                bf16x3::split_pair(X[0][st][0], X[0][st][1], XP[st].p[0].x, XP[st].p[1].x, XP[st].p[2].x);
-                bf16x3::split_pair(X[0][st][2], X[0][st][3], XP[st].p[0].y, XP[st].p[1].y, XP[st].p[2].y);
+                uint32_t w[3][2];   // the stacks (b0 | b1) (b2 | b0) (b1 | b0) of the lane's four values
+                bf16x3::split_pair(X[0][st][0], X[0][st][1], w[0][0], w[1][0], w[2][0]);
+                bf16x3::split_pair(X[0][st][2], X[0][st][3], w[0][1], w[1][1], w[2][1]);
+                XP[st].p[0] = make_uint4(w[0][0], w[0][1], w[1][0], w[1][1]);
+                XP[st].p[1] = make_uint4(w[2][0], w[2][1], w[0][0], w[0][1]);
+                XP[st].p[2] = make_uint4(w[1][0], w[1][1], w[0][0], w[0][1]);
             }
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             f32x4 H[2][2];
-            hidden_chunk_x3(sm.W1p, sm.b1s, c, XP, H, l15, q);
+            hidden_chunk_x3<IN == 16>(sm.W1p, sm.b1s, c, XP, H, l15, q);
             if constexpr (IN == 32) {
                 // Y += W2[:, chunk] leaky(H): the chunk's 32 hidden units are ONE k-step; a lane's eight H registers per sample tile
                 // (units 4 q + r and 16 + 4 q + r) are its k-slots, split here -- 2 x 44 vector instructions against 24 MFMAs of 16
@@ -364,10 +388,14 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
 template <int IN, int NWV>
 struct BwdSmem {
     static constexpr bool X3 = (IN == 32 && NWV == 4);   // rb2 on 4 waves: H^T and dH^T as bf16x3 products (below)
+    // rb1 (round 6): its two narrow products H^T = X W1^T and dH^T = dpre1^T W2 have K = 16 = HALF a k-step of v_mfma_f32_16x16x32_bf16, so
+    // two piece products share an instruction, stacked along k (hidden_chunk_x3<true>): 3 MFMAs of 16 cycles per 16 x 16 tile instead of
+    // 4 float32 MFMAs of 32 (round 5's unstacked six: 2208 vs 2269-2308 us, not kept).  The weight-gradient products stay float32.
+    static constexpr bool KS = (IN == 16) && RESMLP_BWD1_STACK;
     float W1s[HS * (IN + 4)];     // [hidden j][input i]   (X3: still the source of Q's A operand)
     float W2Ts[X3 ? 4 : HS * (IN + 4)];    // [hidden j][output o]
     float b1s[HS];
-    uint4 W1p[X3 ? 3 * HS * 4 : 1], W2Tp[X3 ? 3 * HS * 4 : 1];   // X3: [piece][hidden j][k-group q] = eight bf16 (hidden_chunk_x3's order)
+    uint4 W1p[(X3 || KS) ? 3 * HS * 4 : 1], W2Tp[(X3 || KS) ? 3 * HS * 4 : 1];   // X3: [piece][hidden j][k-group q] = eight bf16 (hidden_chunk_x3's order); KS: [stack][j][q]
     float tiles[NWV * (2 * IN + (IN == 32 ? 32 : 0)) * LT];   // per wave: TX [IN][32] | TDY [IN][32] | TH [32][32] (rb2)
 };
 static_assert(sizeof(BwdSmem<32, 8>) <= 160 * 1024 && sizeof(BwdSmem<32, 4>) <= 160 * 1024, "LDS");
@@ -394,7 +422,7 @@ __global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__
     __shared__ __attribute__((aligned(16))) BwdSmem<IN, NWV> sm;
     constexpr int S1 = IN + 4, NB = IN / 16;
     constexpr int kWaves = NWV, kThreads = 64 * NWV;   // (shadow the 8-wave constants of the file)
-    constexpr bool X3 = BwdSmem<IN, NWV>::X3;
+    constexpr bool X3 = BwdSmem<IN, NWV>::X3, KS = BwdSmem<IN, NWV>::KS;
     constexpr bool NEED_DX = IN == 32;
     constexpr bool PREFETCH = IN == 16;   // rb2 has no registers to spare for the next tile's rows
     constexpr int TILE_F = (2 * IN + (IN == 32 ? 32 : 0)) * LT;
@@ -421,6 +449,25 @@ __global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__
         }
     } else {
         for (int k = tid; k < IN * HS; k += kThreads) sm.W2Ts[(k % HS) * S1 + (k / HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
+    }
+    if constexpr (KS) {   // the weights' stacks (a2 | a1) (a0 | a1) (a0 | a0) of a lane's four k-values
+        for (int k = tid; k < HS * 4; k += kThreads) {
+            const int j = k >> 2, kq = k & 3;
+            const float4 w1 = ld4(pn + Blk<IN>::W1 + (wg.sl * HS + j) * IN + 4 * kq);
+            const float* wc = pn + Blk<IN>::W2 + wg.sl * HS + j;
+            const float w2[4] = {wc[(size_t)(4 * kq) * rp::HID], wc[(size_t)(4 * kq + 1) * rp::HID], wc[(size_t)(4 * kq + 2) * rp::HID], wc[(size_t)(4 * kq + 3) * rp::HID]};
+            uint32_t a[3][2], b[3][2];
+            bf16x3::split_pair(w1.x, w1.y, a[0][0], a[1][0], a[2][0]);
+            bf16x3::split_pair(w1.z, w1.w, a[0][1], a[1][1], a[2][1]);
+            bf16x3::split_pair(w2[0], w2[1], b[0][0], b[1][0], b[2][0]);
+            bf16x3::split_pair(w2[2], w2[3], b[0][1], b[1][1], b[2][1]);
+            sm.W1p[(0 * HS + j) * 4 + kq] = make_uint4(a[2][0], a[2][1], a[1][0], a[1][1]);
+            sm.W1p[(1 * HS + j) * 4 + kq] = make_uint4(a[0][0], a[0][1], a[1][0], a[1][1]);
+            sm.W1p[(2 * HS + j) * 4 + kq] = make_uint4(a[0][0], a[0][1], a[0][0], a[0][1]);
+            sm.W2Tp[(0 * HS + j) * 4 + kq] = make_uint4(b[2][0], b[2][1], b[1][0], b[1][1]);
+            sm.W2Tp[(1 * HS + j) * 4 + kq] = make_uint4(b[0][0], b[0][1], b[1][0], b[1][1]);
+            sm.W2Tp[(2 * HS + j) * 4 + kq] = make_uint4(b[0][0], b[0][1], b[0][0], b[0][1]);
+        }
     }
     if (tid < HS) sm.b1s[tid] = pn[Blk<IN>::B1 + wg.sl * HS + tid];
     __syncthreads();
@@ -513,6 +560,22 @@ __global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__
                 DYP[st] = bf16x3::split8(vd);
             }
         }
+        if constexpr (KS) {   // the stacks (b0 | b1) (b2 | b0) (b1 | b0) of the lane's four values of a row / of an output gradient
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                uint32_t w[3][2], g[3][2];
+                bf16x3::split_pair(X[0][st][0], X[0][st][1], w[0][0], w[1][0], w[2][0]);
+                bf16x3::split_pair(X[0][st][2], X[0][st][3], w[0][1], w[1][1], w[2][1]);
+                bf16x3::split_pair(DY[0][st][0], DY[0][st][1], g[0][0], g[1][0], g[2][0]);
+                bf16x3::split_pair(DY[0][st][2], DY[0][st][3], g[0][1], g[1][1], g[2][1]);
+                XP[st].p[0] = make_uint4(w[0][0], w[0][1], w[1][0], w[1][1]);
+                XP[st].p[1] = make_uint4(w[2][0], w[2][1], w[0][0], w[0][1]);
+                XP[st].p[2] = make_uint4(w[1][0], w[1][1], w[0][0], w[0][1]);
+                DYP[st].p[0] = make_uint4(g[0][0], g[0][1], g[1][0], g[1][1]);
+                DYP[st].p[1] = make_uint4(g[2][0], g[2][1], g[0][0], g[0][1]);
+                DYP[st].p[2] = make_uint4(g[1][0], g[1][1], g[0][0], g[0][1]);
+            }
+        }
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // bf16x3 term order: small terms first, a0 b0 last
         // X3: the weight-gradient products contract over the tile's 32 samples = ONE k-step of v_mfma_f32_16x16x32_bf16.  Their narrow
         // partners -- dY^T (A of dW2) and X^T (B of dW1), lane = unit, k-group q = samples 4 q + r and 16 + 4 q + r -- are split once
@@ -540,7 +603,24 @@ __global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__
                 __builtin_amdgcn_sched_barrier(0);
                 // H^T (R-layout: lane = hidden unit 16 jb + l15 of the chunk, register r = sample 16 st + 4 q + r)
                 f32x4 H[2][NST], dH[2][NST];
-                if constexpr (X3) {
+                if constexpr (KS) {
+                    bf16x3::Pieces Wp[2];
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) Wp[jb].p[i] = sm.W1p[(i * HS + c * 32 + 16 * jb + l15) * 4 + q];
+                        const float bj = sm.b1s[c * 32 + 16 * jb + l15];
+#pragma unroll
+                        for (int k = 0; k < NST; ++k) H[jb][k] = f32x4{bj, bj, bj, bj};
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int k = 0; k < NST; ++k) {
+                            H[0][k] = mfma16bf(XP[s0 + k].p[t], Wp[0].p[t], H[0][k]);
+                            H[1][k] = mfma16bf(XP[s0 + k].p[t], Wp[1].p[t], H[1][k]);
+                        }
+                } else if constexpr (X3) {
                     bf16x3::Pieces Wp[2];
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb)
@@ -590,7 +670,20 @@ __global__ __launch_bounds__(64 * NWV) void resmlp_bwd(const float* __restrict__
                 for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
                     for (int k = 0; k < NST; ++k) dH[jb][k] = zero4();
-                if constexpr (X3) {
+                if constexpr (KS) {
+                    bf16x3::Pieces Wp[2];
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) Wp[jb].p[i] = sm.W2Tp[(i * HS + c * 32 + 16 * jb + l15) * 4 + q];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int k = 0; k < NST; ++k) {
+                            dH[0][k] = mfma16bf(DYP[s0 + k].p[t], Wp[0].p[t], dH[0][k]);
+                            dH[1][k] = mfma16bf(DYP[s0 + k].p[t], Wp[1].p[t], dH[1][k]);
+                        }
+                } else if constexpr (X3) {
                     bf16x3::Pieces Wp[2];
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb)
@@ -1065,16 +1158,16 @@ int loss_grad_impl(const char* name, bool adam, float* params, const void* obs, 
     } else
         hipLaunchKernelGGL((resmlp_bwd<32, 2, kBwd2Waves>), dim3(p.wgs), dim3(64 * kBwd2Waves), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
                            (const float*)p.dy2, (long long)n, p.groups, p.wpart, p.qb, (const float*)nullptr, f16);
-    hipLaunchKernelGGL((resmlp_bwd<16, 2, kWaves>), dim3(p.wgs), dim3(kThreads), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
+    hipLaunchKernelGGL((resmlp_bwd<16, 2, kBwd1Waves>), dim3(p.wgs), dim3(64 * kBwd1Waves), 0, st, (const float*)params, 2, obs, (const float*)p.h1,
                        (const float*)p.dy2, (long long)n, p.groups, p.wpart, (float*)nullptr, (const float*)p.qb, f16);
     const int rblocks = (rp::P_ACTOR + rp::P_CRITIC + 63) / 64;
     if (adam) {
         const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
         const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
-        hipLaunchKernelGGL(resmlp_reduce<true>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kWaves,
+        hipLaunchKernelGGL(resmlp_reduce<true>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kBwd1Waves,
                            p.groups * kBwd2Waves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, params, adam_m, adam_v, lr, beta1, beta2, eps, bc1, bc2_sqrt);
     } else {
-        hipLaunchKernelGGL(resmlp_reduce<false>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kWaves,
+        hipLaunchKernelGGL(resmlp_reduce<false>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kBwd1Waves,
                            p.groups * kBwd2Waves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f,
                            0.f, 0.f, 0.f, 1.f, 1.f);
     }

@@ -14,6 +14,9 @@ objdir = os.path.join(R, "build", "obj_" + name)
 os.makedirs(objdir, exist_ok=True)
 obj = os.path.join(objdir, SRC + ".o")
 cflags = [f for f in build.HIPCC_FLAGS if f != "-shared"]
+per_src = build.EXTRA_FLAGS.get(SRC, [])
+if per_src and build.flags_accepted(per_src):
+    cflags += list(per_src)
 subprocess.check_call([build.hipcc()] + cflags + flags + ["-I", build.INC, "-I", os.path.join(build.HERE, "csrc"), "-c",
                                                          os.path.join(build.HERE, "csrc", SRC), "-o", obj])
 objs = [os.path.join(R, "build", "obj", f) for f in ("navsim.hip.o", "ppo_mlp64.hip.o", "ppo_resmlp512.hip.o") if f != SRC + ".o"] + [obj]
