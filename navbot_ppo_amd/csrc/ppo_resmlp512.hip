@@ -89,6 +89,11 @@ static_assert(rp::P_ACTOR == NAVPPO_RESMLP512_ACTOR_PARAMS && rp::P_CRITIC == NA
 constexpr int NSL = 4;               // hidden slices
 constexpr int HS = rp::HID / NSL;    // 128 hidden units per slice
 constexpr int NCH = HS / 32;         // chunks of 32 hidden units per slice
+// Round 6: a FORWARD workgroup runs FSP = 2 slices of its tile back to back into the same accumulators and writes ONE partial sum for the
+// pair: NSLF = 2 partials per sample and net instead of 4 (resmlp_fwd<32> reads half as many of rb1's, resmlp_e2 -- HBM-bound, 0.69 ms per
+// epoch, two thirds of it the four partials of rb2 -- half as many of rb2's), and a tile's input split is shared by 8 chunks instead of 4.
+// The backward kernels keep one slice per workgroup (their LDS is full).
+constexpr int FSP = 2, NSLF = NSL / FSP;
 constexpr int kWaves = 8, kThreads = 64 * kWaves;
 #ifndef RESMLP_BWD2_WAVES
 #define RESMLP_BWD2_WAVES 4
@@ -124,8 +129,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 struct WG { int net_i, sl, grp; };
 // blockIdx -> (net, slice, group).  With a multiple of 8 groups the 4 (or 8) workgroups that stream the SAME sample tiles
 // (the slices of a group, both nets) get block ids that differ by multiples of 8, i.e. the same XCD and the same L2.
-__device__ __forceinline__ WG decode_block(int b, int n_nets, int groups) {
-    const int nsc = NSL * n_nets;
+__device__ __forceinline__ WG decode_block(int b, int n_nets, int groups, int nsl = NSL) {
+    const int nsc = nsl * n_nets;
     int ns, grp;
     if ((groups & 7) == 0) {
         const int xcd = b & 7, rest = b >> 3;
@@ -135,7 +140,7 @@ __device__ __forceinline__ WG decode_block(int b, int n_nets, int groups) {
         ns = b % nsc;
         grp = b / nsc;
     }
-    return WG{ns >> 2, ns & 3, grp};
+    return WG{ns / nsl, ns % nsl, grp};
 }
 
 // Four consecutive columns of an observation row, element index idx = s * 16 + 4 q: float32 rows, or float16 rows (obs_f16: BASELINE
@@ -217,12 +222,13 @@ __device__ __forceinline__ void hidden_chunk_x3(const uint4* W1p /* [3][HS][4] *
 // ---------------------------------------------------------------- forward partial of one residual block
 template <int IN>
 struct FwdSmem {
-    float W2s[(IN == 32) ? 4 : IN * (HS + 4)];    // [output o][hidden j] (rb1; rb2 holds W2 as bf16 pieces)
-    float b1s[HS];
+    // (every array: FSP slices one behind the other)
+    float W2s[(IN == 32) ? 4 : FSP * IN * (HS + 4)];    // [output o][hidden j] (rb1; rb2 holds W2 as bf16 pieces)
+    float b1s[FSP * HS];
     // rb2: W2 as pieces in the order the Y product consumes them: [piece][chunk c][output block ob][lane (m, q)] = eight bf16
     // W2[16 ob + m][32 c + 4 q + r], W2[16 ob + m][32 c + 16 + 4 q + r] -- the k-slots in which lane (n, q) holds its own H registers
-    uint4 W2p[(IN == 32) ? 3 * NCH * 2 * 64 : 1];
-    uint4 W1p[3 * HS * 4];       // [piece][hidden j][k-group q] = eight bf16: W1[j][4 q + r], then W1[j][16 + 4 q + r] (rb1: [stack][j][q], two pieces of W1[j][4 q + r])
+    uint4 W2p[(IN == 32) ? FSP * 3 * NCH * 2 * 64 : 1];
+    uint4 W1p[FSP * 3 * HS * 4];       // [piece][hidden j][k-group q] = eight bf16: W1[j][4 q + r], then W1[j][16 + 4 q + r] (rb1: [stack][j][q], two pieces of W1[j][4 q + r])
 };
 
 // pout[net][slice][n][IN] = W2[:, slice] leaky(W1[slice] X + b1[slice])
@@ -237,48 +243,55 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
     __shared__ __attribute__((aligned(16))) FwdSmem<IN> sm;
     constexpr int S2 = HS + 4, NB = IN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, q = lane >> 4;
-    const WG wg = decode_block(blockIdx.x, n_nets, groups);
+    const WG wg = decode_block(blockIdx.x, n_nets, groups, NSLF);   // wg.sl: the PAIR of slices FSP wg.sl, FSP wg.sl + 1
     const float* __restrict__ pn = params + ((net_base + wg.net_i) ? rp::P_ACTOR : 0);
-    for (int k = tid; k < HS * 4; k += kThreads) {
-        const int j = k >> 2, kq = k & 3;
-        const float* wr = pn + Blk<IN>::W1 + (wg.sl * HS + j) * IN;
-        const float4 lo = ld4(wr + 4 * kq), hi = (IN == 32) ? ld4(wr + (IN == 32 ? 16 : 0) + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const bf16x3::Pieces P = bf16x3::split8(v);
-        if constexpr (IN == 16) {   // the stacks (a2 | a1) (a0 | a1) (a0 | a0): see hidden_chunk_x3<true>
-            sm.W1p[(0 * HS + j) * 4 + kq] = make_uint4(P.p[2].x, P.p[2].y, P.p[1].x, P.p[1].y);
-            sm.W1p[(1 * HS + j) * 4 + kq] = make_uint4(P.p[0].x, P.p[0].y, P.p[1].x, P.p[1].y);
-            sm.W1p[(2 * HS + j) * 4 + kq] = make_uint4(P.p[0].x, P.p[0].y, P.p[0].x, P.p[0].y);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) sm.W1p[(i * HS + j) * 4 + kq] = P.p[i];
-        }
-    }
-    if constexpr (IN == 32) {
-        for (int k = tid; k < NCH * NB * 64; k += kThreads) {
-            const int ln = k & 63, ob = (k >> 6) % NB, c = k / (64 * NB), m = ln & 15, kq = ln >> 4;
-            const float* wr = pn + Blk<IN>::W2 + (size_t)(16 * ob + m) * rp::HID + wg.sl * HS + 32 * c + 4 * kq;
-            const float4 lo = ld4(wr), hi = ld4(wr + 16);
+    constexpr int W1P_F = 3 * HS * 4, W2P_F = 3 * NCH * 2 * 64, W2S_F = IN * S2;   // one slice's share of the arrays
+    for (int fs = 0; fs < FSP; ++fs) {
+        const int sl = wg.sl * FSP + fs;
+        uint4* const W1p = sm.W1p + fs * W1P_F;
+        for (int k = tid; k < HS * 4; k += kThreads) {
+            const int j = k >> 2, kq = k & 3;
+            const float* wr = pn + Blk<IN>::W1 + (sl * HS + j) * IN;
+            const float4 lo = ld4(wr + 4 * kq), hi = (IN == 32) ? ld4(wr + (IN == 32 ? 16 : 0) + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             const bf16x3::Pieces P = bf16x3::split8(v);
+            if constexpr (IN == 16) {   // the stacks (a2 | a1) (a0 | a1) (a0 | a0): see hidden_chunk_x3<true>
+                W1p[(0 * HS + j) * 4 + kq] = make_uint4(P.p[2].x, P.p[2].y, P.p[1].x, P.p[1].y);
+                W1p[(1 * HS + j) * 4 + kq] = make_uint4(P.p[0].x, P.p[0].y, P.p[1].x, P.p[1].y);
+                W1p[(2 * HS + j) * 4 + kq] = make_uint4(P.p[0].x, P.p[0].y, P.p[0].x, P.p[0].y);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) sm.W2p[((i * NCH + c) * NB + ob) * 64 + ln] = P.p[i];
+                for (int i = 0; i < 3; ++i) W1p[(i * HS + j) * 4 + kq] = P.p[i];
+            }
         }
-    } else {
-        for (int k = tid; k < IN * HS; k += kThreads) sm.W2s[(k / HS) * S2 + (k % HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + wg.sl * HS + (k % HS)];
+        if constexpr (IN == 32) {
+            uint4* const W2p = sm.W2p + fs * W2P_F;
+            for (int k = tid; k < NCH * NB * 64; k += kThreads) {
+                const int ln = k & 63, ob = (k >> 6) % NB, c = k / (64 * NB), m = ln & 15, kq = ln >> 4;
+                const float* wr = pn + Blk<IN>::W2 + (size_t)(16 * ob + m) * rp::HID + sl * HS + 32 * c + 4 * kq;
+                const float4 lo = ld4(wr), hi = ld4(wr + 16);
+                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const bf16x3::Pieces P = bf16x3::split8(v);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) W2p[((i * NCH + c) * NB + ob) * 64 + ln] = P.p[i];
+            }
+        } else {
+            float* const W2s = sm.W2s + fs * W2S_F;
+            for (int k = tid; k < IN * HS; k += kThreads) W2s[(k / HS) * S2 + (k % HS)] = pn[Blk<IN>::W2 + (k / HS) * rp::HID + sl * HS + (k % HS)];
+        }
+        if (tid < HS) sm.b1s[fs * HS + tid] = pn[Blk<IN>::B1 + sl * HS + tid];
     }
-    if (tid < HS) sm.b1s[tid] = pn[Blk<IN>::B1 + wg.sl * HS + tid];
     __syncthreads();
-    float* __restrict__ po = pout + (size_t)(wg.net_i * NSL + wg.sl) * n * IN;
+    float* __restrict__ po = pout + (size_t)(wg.net_i * NSLF + wg.sl) * n * IN;
     const long long n_tiles = (n + 31) / 32, stride = (long long)groups * kWaves;
     // rb2: the four rb1 partials of this net and the output bias of rb1 (rows 4 q .. 4 q + 3 of the lane)
-    const float* __restrict__ pp = IN == 32 ? p1 + (size_t)wg.net_i * NSL * n * 16 : nullptr;
+    const float* __restrict__ pp = IN == 32 ? p1 + (size_t)wg.net_i * NSLF * n * 16 : nullptr;
     float* __restrict__ ho = (IN == 32 && wg.sl == 0) ? h1buf + (size_t)wg.net_i * n * 16 : nullptr;
     f32x4 b2 = zero4();
     if (IN == 32)
 #pragma unroll
         for (int r = 0; r < 4; ++r) b2[r] = pn[rp::B2A + 4 * q + r];
-    f32x4 xn[2], pa[IN == 32 ? NSL : 1][2];   // the next tile's rows, requested one tile ahead
+    f32x4 xn[2], pa[IN == 32 ? NSLF : 1][2];   // the next tile's rows, requested one tile ahead
     auto request = [&](long long t) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
             xn[st] = v ? v4(ldx4(obs, s * 16 + 4 * q, obs_f16)) : zero4();
             if (IN == 32)
 #pragma unroll
-                for (int k = 0; k < NSL; ++k) pa[k][st] = v ? v4(ld4(pp + ((size_t)k * n + s) * 16 + 4 * q)) : zero4();
+                for (int k = 0; k < NSLF; ++k) pa[k][st] = v ? v4(ld4(pp + ((size_t)k * n + s) * 16 + 4 * q)) : zero4();
         }
     };
     long long tile = (long long)wg.grp * kWaves + wave;
@@ -298,8 +311,8 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
         for (int st = 0; st < 2; ++st) {
             X[0][st] = xn[st];
             if (IN == 32) {
-                // the arithmetic (and its order) of net_actor.py:41-53 summed slice by slice: (x + b) + ((p0 + p1) + (p2 + p3))
-                f32x4 h = (xn[st] + b2) + ((pa[0][st] + pa[IN == 32 ? 1 : 0][st]) + (pa[IN == 32 ? 2 : 0][st] + pa[IN == 32 ? 3 : 0][st]));
+                // the arithmetic of net_actor.py:41-53 summed slice pair by slice pair: (x + b) + (p01 + p23)
+                f32x4 h = (xn[st] + b2) + (pa[0][st] + pa[IN == 32 ? 1 : 0][st]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[r] = leaky(h[r]);
                 X[NB - 1][st] = h;
@@ -326,10 +339,14 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
                 XP[st].p[2] = make_uint4(w[1][0], w[1][1], w[0][0], w[0][1]);
             }
         }
+#pragma unroll 1
+        for (int fs = 0; fs < FSP; ++fs) {   // the pair's slices one after the other, into the same Y
+        const uint4* const W1p = sm.W1p + fs * W1P_F;
+        const float* const b1s = sm.b1s + fs * HS;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             f32x4 H[2][2];
-            hidden_chunk_x3<IN == 16>(sm.W1p, sm.b1s, c, XP, H, l15, q);
+            hidden_chunk_x3<IN == 16>(W1p, b1s, c, XP, H, l15, q);
             if constexpr (IN == 32) {
                 // Y += W2[:, chunk] leaky(H): the chunk's 32 hidden units are ONE k-step; a lane's eight H registers per sample tile
                 // (units 4 q + r and 16 + 4 q + r) are its k-slots, split here -- 2 x 44 vector instructions against 24 MFMAs of 16
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
                 for (int t = 0; t < 6; ++t)
 #pragma unroll
                     for (int ob = 0; ob < NB; ++ob) {
-                        const uint4 a = sm.W2p[((TA[t] * NCH + c) * NB + ob) * 64 + lane];
+                        const uint4 a = sm.W2p[(IN == 32 ? fs * W2P_F : 0) + ((TA[t] * NCH + c) * NB + ob) * 64 + lane];
                         Y[ob][0] = mfma16bf(a, HP[0].p[TB[t]], Y[ob][0]);
                         Y[ob][1] = mfma16bf(a, HP[1].p[TB[t]], Y[ob][1]);
                     }
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
             for (int jb = 0; jb < 2; ++jb) {
                 f32x4 a[NB];
 #pragma unroll
-                for (int ob = 0; ob < NB; ++ob) a[ob] = v4(ld4(sm.W2s + (16 * ob + l15) * S2 + c * 32 + 16 * jb + 4 * q));
+                for (int ob = 0; ob < NB; ++ob) a[ob] = v4(ld4(sm.W2s + (IN == 32 ? 0 : fs * W2S_F) + (16 * ob + l15) * S2 + c * 32 + 16 * jb + 4 * q));
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -363,6 +380,7 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
                         Y[ob][1] = mfma16(a[ob][r], H[jb][1][r], Y[ob][1]);
                     }
             }
+        }
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -894,7 +912,7 @@ __global__ __launch_bounds__(kEThreads) void resmlp_e2(const float* __restrict__
     }
     const float bo1 = pn[rp::BO1], bo2 = actor ? pn[rp::BO2] : 0.f;
     const float* __restrict__ hn = h1buf + (size_t)net_i * n * 16;
-    const float* __restrict__ pp = p2 + (size_t)net_i * NSL * n * 32;
+    const float* __restrict__ pp = p2 + (size_t)net_i * NSLF * n * 32;
     float* __restrict__ dyo = HEAD_ONLY ? nullptr : dy2 + (size_t)net_i * n * 32;
     // accumulators: db2b[4] dwo1[4] dwo2[4] dbo1 dbo2 st0 st1 st2   (17 values)
     float acc[17];
@@ -904,13 +922,13 @@ __global__ __launch_bounds__(kEThreads) void resmlp_e2(const float* __restrict__
     for (long long g = (long long)blockIdx.x * kEThreads + threadIdx.x; g < total; g += step) {
         const long long s = g >> 3, o = g * 4;   // o == s * 32 + 4 * og
         const float4 x1 = og < 4 ? ldx4(obs, s * 16 + 4 * og, obs_f16) : ld4(hn + s * 16 + 4 * (og - 4));
-        const float4 a0 = ld4(pp + o), a1 = ld4(pp + (size_t)n * 32 + o), a2 = ld4(pp + (size_t)2 * n * 32 + o),
-                     a3 = ld4(pp + (size_t)3 * n * 32 + o);
+        const float4 a0 = ld4(pp + o), a1 = ld4(pp + (size_t)n * 32 + o);   // the two slice pairs' partials
+        static_assert(NSLF == 2, "two forward partials per sample and net");
         float h[4];
-        h[0] = leaky((x1.x + b[0]) + ((a0.x + a1.x) + (a2.x + a3.x)));
-        h[1] = leaky((x1.y + b[1]) + ((a0.y + a1.y) + (a2.y + a3.y)));
-        h[2] = leaky((x1.z + b[2]) + ((a0.z + a1.z) + (a2.z + a3.z)));
-        h[3] = leaky((x1.w + b[3]) + ((a0.w + a1.w) + (a2.w + a3.w)));
+        h[0] = leaky((x1.x + b[0]) + (a0.x + a1.x));
+        h[1] = leaky((x1.y + b[1]) + (a0.y + a1.y));
+        h[2] = leaky((x1.z + b[2]) + (a0.z + a1.z));
+        h[3] = leaky((x1.w + b[3]) + (a0.w + a1.w));
         float z3 = 0.f, z4 = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1123,10 +1141,11 @@ bool launch_ok(const char* what) {
 
 // forward of `n_nets` nets starting at net_base (0 = actor, 1 = critic) up to the partial sums of rb2
 void launch_forward(const Plan& p, const float* params, int net_base, int n_nets, const void* obs, int obs_f16, int64_t n, hipStream_t st) {
+    // (a forward workgroup = a PAIR of slices: FSP times the groups on the same number of workgroups)
     hipLaunchKernelGGL(resmlp_fwd<16>, dim3(p.wgs), dim3(kThreads), 0, st, params, net_base, n_nets, obs, (const float*)nullptr,
-                       (float*)nullptr, (long long)n, p.groups, p.p1, obs_f16);
+                       (float*)nullptr, (long long)n, p.groups * FSP, p.p1, obs_f16);
     hipLaunchKernelGGL(resmlp_fwd<32>, dim3(p.wgs), dim3(kThreads), 0, st, params, net_base, n_nets, obs, (const float*)p.p1, p.h1,
-                       (long long)n, p.groups, p.p2, obs_f16);
+                       (long long)n, p.groups * FSP, p.p2, obs_f16);
 }
 
 int loss_grad_impl(const char* name, bool adam, float* params, const void* obs, int32_t obs_f16, const float* act, const float* logp_old,
