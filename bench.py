@@ -135,7 +135,8 @@ def rocprof_legs(argv):
         for k, m in enumerate(manifest):
             durs = [dur for name, dur in segs.get(k, []) if any(t in name for t in m["match"])]
             if durs:
-                names = sorted({name.split("(")[0][-70:] for name, dur in segs.get(k, []) if any(t in name for t in m["match"])})
+                names = sorted({name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-70:]
+                                for name, dur in segs.get(k, []) if any(t in name for t in m["match"])})
                 out[m["leg"]] = dict(us=sum(durs) / 1e3 / m["per"], n=len(durs), min_us=min(durs) / 1e3, max_us=max(durs) / 1e3, per=m["per"], kernels=names)
         save = os.environ.get("NAVBOT_BENCH_SAVE_PROF")   # (tools/prof_r06.sh: the per-leg summary the line was computed from, for profiles/)
         if save:
