@@ -37,7 +37,8 @@ def test_asm_mfma_stream_of_the_512_wide_backward_has_no_unguarded_hazards(tmp_p
     flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
     extra = build.EXTRA_FLAGS.get("ppo_resmlp512.hip", [])
     if extra and not build.flags_accepted(extra):
-        extra = []
+        import pytest
+        pytest.skip("hipcc rejects the allocation flag: build.FALLBACK_FLAGS builds the file without resmlp_bwd2s (-DRESMLP_BWD2S=0)")
     subprocess.check_call([build.hipcc()] + flags + list(extra) + ["-I", build.INC, "-I", os.path.join(build.HERE, "csrc"), "-S", "--cuda-device-only",
                                                                   os.path.join(build.HERE, "csrc", "ppo_resmlp512.hip"), "-o", str(out)],
                           stderr=subprocess.DEVNULL)
