@@ -4,7 +4,7 @@
 import json, os, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(R, "gpurun_out", "r06"), os.path.join(R, "profiles")
-for a in ("run_id.txt", "bench_legs.csv", "update_arith_kernel_stats.csv", "update_arith_hip_events.txt", "resmlp_update_kernel_stats.csv",
+for a in ("run_id.txt", "bench_legs.csv", "update_arith_kernel_stats.csv", "update_arith_hip_events.txt", "resmlp_update_kernel_stats.csv", "step_cfg3_kernel_stats.csv",
           "resmlp_update_hip_events.txt", "resmlp_epoch_timeline.txt", "x3s_pmc.txt", "b2s_pmc.txt", "mfma16_stream.txt", "bf16x3_error_kinkfree.txt",
           "ppo_cfg4.json", "ppo_cfg5.json"):
     if os.path.exists(os.path.join(O, a)):

@@ -8,6 +8,8 @@ echo "$PROF_RUN_ID" > $O/run_id.txt
 # counters first: bench.py --with-pmc-file quotes THIS call's file (the file carries the sha256 of csrc/navsim.hip)
 python tools/pmc_traffic.py > $O/pmc_traffic.log 2>&1
 NAVBOT_BENCH_SAVE_PROF=$O/bench_legs.csv python bench.py --with-pmc-file $O/pmc_traffic.json > $O/bench_final.json 2> $O/bench_final.err
+# the step kernel at configs[2] on its own (the stand-alone cross-check of the line's `roofline` leg: same kernel, graph replays of 64)
+tools/prof_stats.sh step_cfg3 -- python tools/time_step.py --cfg3 > $O/step_cfg3_rocprof.log 2>&1
 # the update pass of the timed workload (both arithmetics) and of the 512-wide nets: kernel averages, HIP events, counters, epoch timeline
 tools/prof_stats.sh update_arith -- python tools/time_update_arith.py > $O/update_arith_rocprof.log 2>&1
 python tools/time_update_arith.py 2>&1 | grep -v amdgpu > $O/update_arith_hip_events.txt
