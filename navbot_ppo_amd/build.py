@@ -67,6 +67,16 @@ def flags_accepted(flags):
     return _flag_ok[key]
 
 
+def per_source_flags(base):
+    """the flags one source is compiled with besides HIPCC_FLAGS: its EXTRA_FLAGS if hipcc takes them, else its FALLBACK_FLAGS"""
+    per_src = [] if os.environ.get("NAVSIM_NO_EXTRA_FLAGS") == "1" else EXTRA_FLAGS.get(base, [])   # (A/B builds)
+    if per_src and not flags_accepted(per_src):
+        per_src = []
+    if not per_src and base in EXTRA_FLAGS:
+        per_src = list(FALLBACK_FLAGS.get(base, []))
+    return list(per_src)
+
+
 def build_native(force=False, verbose=False, navsim_src=None, out=None, extra=()):
     """navsim_src / out / extra: dev tools build variants of csrc/navsim.hip (patched copies, instrumented builds) as another
     library with exactly the product's flags."""
@@ -84,12 +94,7 @@ def build_native(force=False, verbose=False, navsim_src=None, out=None, extra=()
     hdrs = [os.path.join(INC, h) for h in HDRS] + [os.path.join(HERE, "csrc", h) for h in ("mlp64_policy.h", "navppo_internal.h", "resmlp_policy.h", "bf16x3.h", "ppo_mlp64_x3s.h", "ppo_resmlp512_bwd2s.h")]
     for k, src in enumerate(srcs):   # the sources compile side by side
         obj = os.path.join(objdir, os.path.basename(SRCS[k]) + ".o")
-        base = os.path.basename(SRCS[k])
-        per_src = [] if os.environ.get("NAVSIM_NO_EXTRA_FLAGS") == "1" else EXTRA_FLAGS.get(base, [])   # (A/B builds)
-        if per_src and not flags_accepted(per_src):
-            per_src = []
-        if not per_src and base in EXTRA_FLAGS:
-            per_src = list(FALLBACK_FLAGS.get(base, []))
+        per_src = per_source_flags(os.path.basename(SRCS[k]))
         cmd = ([hipcc()] + compile_flags + per_src + (list(extra) if k == 0 else []) +
                ["-I", INC, "-I", os.path.join(HERE, "csrc"), "-c", src, "-o", obj])
         objs.append(obj)

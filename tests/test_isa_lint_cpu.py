@@ -66,3 +66,17 @@ def test_lint_flags_the_measured_hazards(tmp_path):
     ]))
     n, bad = lint(str(src), "_Zk")
     assert n == 3 and len(bad) == 3, bad
+
+
+def test_resmlp512_falls_back_to_the_compiler_scheduled_backward_without_its_allocation_flag(monkeypatch):
+    """build.EXTRA_FLAGS gives ppo_resmlp512.hip the register-allocation flag under which resmlp_bwd2s's listing is hazard-free; a hipcc
+    that rejects it (or NAVSIM_NO_EXTRA_FLAGS=1) must not build that stream at all: build.FALLBACK_FLAGS then selects resmlp_bwd<32, 2, 4>."""
+    from navbot_ppo_amd import build
+    monkeypatch.setattr(build, "flags_accepted", lambda flags: False)
+    assert build.per_source_flags("ppo_resmlp512.hip") == ["-DRESMLP_BWD2S=0"]
+    assert build.per_source_flags("navsim.hip") == []          # a flag that only buys speed: built without it
+    assert build.per_source_flags("ppo_mlp64.hip") == []
+    monkeypatch.setattr(build, "flags_accepted", lambda flags: True)
+    assert build.per_source_flags("ppo_resmlp512.hip") == build.EXTRA_FLAGS["ppo_resmlp512.hip"]
+    monkeypatch.setenv("NAVSIM_NO_EXTRA_FLAGS", "1")
+    assert build.per_source_flags("ppo_resmlp512.hip") == ["-DRESMLP_BWD2S=0"]
