@@ -145,8 +145,9 @@ int navppo_mlp64_act(const float* actor_params_dev, const void* obs_dev, int32_t
  * The reference's ACTIVE nets ("resmlp512"): NetActor / NetCritic (project_ppo/src/net_actor.py:56-144, net_critic.py:50-130),
  * two residual blocks ResBlock(16, 16) and ResBlock(32, 32) with 512 hidden units and LeakyReLU(0.2)
  * (net_actor.py:16-53), actor heads sigmoid(out1) / tanh(out2), critic head out.  Fused MFMA kernels (csrc/ppo_resmlp512.hip):
- * float32 in, float32 out, float32 accumulate; the products that fill a k-step of the bf16 MFMA are float32 products rebuilt from three
- * exact bf16 pieces per operand ("bf16x3", as navppo_mlp64_bf16x3_*), the others run on the f32-input MFMA -- ONE arithmetic, also
+ * float32 in, float32 out, float32 accumulate; every matrix product except the weight gradients of the first block runs as float32
+ * products rebuilt from three exact bf16 pieces per operand ("bf16x3", as navppo_mlp64_bf16x3_*; where a product contracts over 16
+ * values only, two piece products share one MFMA), those run on the f32-input MFMA -- ONE arithmetic, also
  * for navppo_resmlp512_value (a caller who needs native float32 products throughout uses PyTorch: PPOConfig.update_arith = "f32").
  * Same contracts as the mlp64 entry points above unless stated.
  *
