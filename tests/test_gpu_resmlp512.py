@@ -546,3 +546,64 @@ def test_persistent_resmlp512_rollout_on_float16_rows_against_the_oracle():
         n_end += int(out["ended"].sum())
     assert n_end >= n_s
     env.close()
+
+
+def _kink_mask_512(net, x, eps=2e-5):
+    """samples (float64) with a LeakyReLU pre-activation of either residual block within eps of its kink (cf. tests/_kinks.py)"""
+    bad = torch.zeros(x.shape[0], dtype=torch.bool, device=x.device)
+    inp = x
+    for rb in (net.rb1, net.rb2):
+        z1 = rb.fc1(inp)
+        z2 = inp + rb.fc2(rb.act(z1))
+        bad |= (z1.abs() < eps).any(1) | (z2.abs() < eps).any(1)
+        inp = torch.cat([x, rb.act(z2)], 1)
+    return bad
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_fused_resmlp512_gradients_on_ragged_batch_sizes(f16):
+    """Round 6's kernels of these nets -- rb2's backward as a hand-placed stream that prefetches rows a tile and a half ahead and carries
+    its pipeline across tiles (csrc/ppo_resmlp512_bwd2s.h), forward workgroups on slice pairs, rb1's stacked products -- on batch sizes
+    around every boundary of their decomposition: one sample, the 32-sample tile, the 4 / 8 waves of a workgroup, the groups of a launch.
+    Against FLOAT64 autograd of the same losses, kink samples replaced (their count bounded), every tensor to 2e-5 of its scale (measured:
+    <= 7e-6 over 90 sizes, tools/verify/resmlp_fuzz.py; a tile handled twice or not at all would be >= 1 / n)."""
+    dev = torch.device("cuda")
+    a, c = _policy(dev, scale=1.0)
+    up = ppo.PPOUpdater(a, c, ppo.PPOConfig(policy="resmlp512"), None, dev)
+    a64, c64 = nets.make_policy("resmlp512")
+    a64.to(dev).double(), c64.to(dev).double()
+    a64.load_state_dict({k: v.double() for k, v in a.state_dict().items()})
+    c64.load_state_dict({k: v.double() for k, v in c.state_dict().items()})
+    var = torch.tensor(0.8, device=dev, dtype=torch.float64)
+    for n in (2, 31, 33, 63, 65, 127, 129, 255, 257, 1023, 1025, 4095, 4097, 8191, 8193, 32767, 32769, 50001):
+        obs, acts, logp, rtg, adv = _batch(n, 100 + n, dev)
+        rtg = rtg * 0.1
+        if f16:
+            obs = obs.half()
+        with torch.no_grad():
+            x64 = obs.double()
+            bad = _kink_mask_512(a64, x64) | _kink_mask_512(c64, x64)
+            ratio = torch.exp(ppo.gaussian_log_prob(a64(x64), acts.double(), var) - logp.double())
+            bad |= ((ratio - 0.8).abs() < 2e-5) | ((ratio - 1.2).abs() < 2e-5)
+            assert int(bad.sum()) <= 2 + n // 8, (n, int(bad.sum()))    # ~1100 kinks per sample and net, each within 2e-5: a few per cent
+            if bool(bad.any()):
+                good = int((~bad).nonzero()[0])
+                for t in (obs, acts, logp, rtg, adv):
+                    t[bad] = t[good].clone()
+        up._fused_loss_grad(obs, acts, logp, rtg, adv, 0.8)
+        got = up.fp.grad.clone().double()
+        for p in list(a64.parameters()) + list(c64.parameters()):
+            p.grad = None
+        la, lc, *_ = ppo.ppo_losses(a64, c64, obs.double(), acts.double(), logp.double(), rtg.double(), adv.double(), var, 0.2)
+        (la + lc).backward()
+        off = 0
+        for net, mod in (("actor", a64), ("critic", c64)):
+            for k, p in mod.named_parameters():
+                if ".bn" in "." + k or k.startswith("bn"):
+                    continue
+                ref = p.grad.reshape(-1)
+                seg = got[off:off + ref.numel()]
+                off += ref.numel()
+                err = float((seg - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+                assert err < 2e-5, (n, net, k, err)
+        assert off == got.numel()
