@@ -244,3 +244,29 @@ def test_prepare_is_redone_for_every_update_and_follows_in_place_writes():
     obs.mul_(0.5)   # a torch write: the version counter moves, loss_grad re-splits by itself
     up._fused_loss_grad(obs, acts, logp, rtg, adv, 0.5)
     assert not torch.equal(up.fp.grad, g1)
+
+
+def test_hand_placed_stream_on_ragged_batch_sizes():
+    """mlp64_pass_both_x3s (csrc/ppo_mlp64_x3s.h) carries state from tile to tile -- the G1 product of a tile runs behind the NEXT tile's
+    MFMAs, rows are requested a tile ahead, a wave's partial sums live in its lanes over all its tiles -- so a batch size decides which wave
+    sees how many tiles, whether its last one is ragged and where the tail G1 runs.  The strict gradient test above on sizes around every
+    such boundary (one sample, the 32-sample tile, the 4 waves of a workgroup, one tile per wave over all 1024 waves, one more), 16
+    columns, against float32 autograd at the suite's bound."""
+    dev = torch.device("cuda")
+    a, c = _nets(dev)
+    from _kinks import replace_kink_samples
+    for n in (1, 2, 31, 32, 33, 63, 65, 127, 129, 4095, 4097, 32 * 1024 - 1, 32 * 1024, 32 * 1024 + 1, 32 * 1024 + 33, 3 * 32 * 1024 + 5):
+        batch = _batch(n, 7 * n + 1, dev)
+        obs, acts, logp, rtg, adv = batch
+        n_kink = replace_kink_samples(a, c, obs, acts, logp, rtg, adv, 0.5)
+        assert n_kink <= 2 + n // 100, (n, n_kink)
+        up, g, st = _grad(a, c, "bf16x3", batch, dev)
+        a2, c2 = copy.deepcopy(a), copy.deepcopy(c)
+        al, cl, ratios, lp, _ = ppo.ppo_losses(a2, c2, obs, acts, logp, rtg, adv, torch.tensor(0.5, device=dev), 0.2)
+        g_ref = torch.cat([t.reshape(-1) for t in torch.autograd.grad(al + cl, list(a2.parameters()) + list(c2.parameters()))])
+        off = 0
+        for prm in up.fp.params:
+            k = prm.numel()
+            scale = g_ref[off:off + k].abs().max().item() + 1e-12
+            assert (g_ref[off:off + k] - g[off:off + k]).abs().max().item() <= 2e-4 * scale + 1e-7, (n, tuple(prm.shape))
+            off += k
