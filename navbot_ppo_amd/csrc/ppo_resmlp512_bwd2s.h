@@ -23,11 +23,11 @@
 //   * the accumulators of H^T start as the bias (one rounding of sum + bias, as in the 64-wide heads: DESIGN 5f), read as one
 //     ds_read_b128 from a four-fold copy of b1 (no vector moves in front of the MFMA that reads them);
 //   * the 32 accumulator tiles of dW2 / dW1 are pinned to a[0:127] (see B2S_ACC_CASES).
-// Where it stands (profiles/r06_b2s_*): 1970 instructions per tile of 32 samples around 432 MFMAs, 3.2 ms per epoch (4.3 before).  One
-// wave per SIMD issues one instruction per ~4 cycles and an MFMA costs ~13 of its own (tools/ubench/gen_mfma16_stream.py: slot =
-// max(19.5, 13 + 4 F) cycles for F instructions behind a 16x16x32 MFMA), so this mix -- 3.6 others per MFMA, most of them the splits --
-// is issue-bound at ~27 cycles per MFMA slot, 60 % of the MFMA pipe; the next step would be 32x32x16 tiles (half the MFMA issue cost),
-// i.e. every operand through an image as in ppo_mlp64_x3s.h.
+// Where it stands (profiles/r06_resmlp_update_kernel_stats.csv, r06_b2s_pmc.txt): 1970 instructions per tile of 32 samples around 432 MFMAs,
+// 3.1-3.2 ms per epoch (4.3 before), MFMA pipe 53 % busy.  One wave per SIMD issues one instruction per ~4 cycles and an MFMA costs ~13 of
+// its own (tools/ubench/gen_mfma16_stream.py), so this mix -- 3.6 others per MFMA, most of them the splits -- is issue-bound at ~27-29
+// cycles per MFMA slot.  32x32x16 tiles would halve the MFMA issue cost but make the whole chunk the pipeline's unit again: written, does
+// not fit the register file (tools/variants/r06_resmlp512_bwd2t.h.txt).
 // MFMA <-> vector hazards the compiler cannot see inside the asm statements: accumulators are read by the vector unit >= 3 MFMAs
 // (>= 12 issue cycles) after their last MFMA or behind an s_nop 7; tools/verify/mfma_hazard_lint.py checks the listing of both
 // instantiations (tests/test_isa_lint_cpu.py).
