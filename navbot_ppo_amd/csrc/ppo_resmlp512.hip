@@ -287,10 +287,16 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
     // rb2: the four rb1 partials of this net and the output bias of rb1 (rows 4 q .. 4 q + 3 of the lane)
     const float* __restrict__ pp = IN == 32 ? p1 + (size_t)wg.net_i * NSLF * n * 16 : nullptr;
     float* __restrict__ ho = (IN == 32 && wg.sl == 0) ? h1buf + (size_t)wg.net_i * n * 16 : nullptr;
-    f32x4 b2 = zero4();
+    f32x4 b2 = zero4(), b2o[NB];   // rb1's output bias (h1 is formed here); rb2's own output bias, rows 16 ob + 4 q + r (pair 0 adds it)
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) b2o[ob] = zero4();
     if (IN == 32)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b2[r] = pn[rp::B2A + 4 * q + r];
+        for (int r = 0; r < 4; ++r) {
+            b2[r] = pn[rp::B2A + 4 * q + r];
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) b2o[ob][r] = pn[rp::B2B + 16 * ob + 4 * q + r];
+        }
     f32x4 xn[2], pa[IN == 32 ? NSLF : 1][2];   // the next tile's rows, requested one tile ahead
     auto request = [&](long long t) {
 #pragma unroll
@@ -381,6 +387,12 @@ __global__ __launch_bounds__(kThreads) void resmlp_fwd(const float* __restrict__
                     }
             }
         }
+        }
+        if (IN == 32 && wg.sl == 0) {   // rb2, pair 0: its partial carries the residual input and the block's output bias (resmlp_e2 reads neither)
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) Y[ob][st] += X[ob][st] + b2o[ob];
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -903,16 +915,14 @@ __global__ __launch_bounds__(kEThreads) void resmlp_e2(const float* __restrict__
     const bool actor = net == 0;
     const float* __restrict__ pn = params + (net ? rp::P_ACTOR : 0);
     const int og = threadIdx.x & 7;
-    float b[4], w1[4], w2[4];
+    float w1[4], w2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        b[k] = pn[rp::B2B + 4 * og + k];
         w1[k] = pn[rp::WO1 + 4 * og + k];
         w2[k] = actor ? pn[rp::WO2 + 4 * og + k] : 0.f;
     }
     const float bo1 = pn[rp::BO1], bo2 = actor ? pn[rp::BO2] : 0.f;
-    const float* __restrict__ hn = h1buf + (size_t)net_i * n * 16;
-    const float* __restrict__ pp = p2 + (size_t)net_i * NSLF * n * 32;
+    const float* __restrict__ pp = p2 + (size_t)net_i * NSLF * n * 32;   // (obs / h1buf: no longer read here -- pair 0's partial carries them)
     float* __restrict__ dyo = HEAD_ONLY ? nullptr : dy2 + (size_t)net_i * n * 32;
     // accumulators: db2b[4] dwo1[4] dwo2[4] dbo1 dbo2 st0 st1 st2   (17 values)
     float acc[17];
@@ -921,14 +931,14 @@ __global__ __launch_bounds__(kEThreads) void resmlp_e2(const float* __restrict__
     const long long total = n * 8, step = (long long)gridDim.x * kEThreads;
     for (long long g = (long long)blockIdx.x * kEThreads + threadIdx.x; g < total; g += step) {
         const long long s = g >> 3, o = g * 4;   // o == s * 32 + 4 * og
-        const float4 x1 = og < 4 ? ldx4(obs, s * 16 + 4 * og, obs_f16) : ld4(hn + s * 16 + 4 * (og - 4));
-        const float4 a0 = ld4(pp + o), a1 = ld4(pp + (size_t)n * 32 + o);   // the two slice pairs' partials
+        // the two slice pairs' partials; pair 0's carries the residual input [x, h1] and the bias b2b (resmlp_fwd<32>)
+        const float4 a0 = ld4(pp + o), a1 = ld4(pp + (size_t)n * 32 + o);
         static_assert(NSLF == 2, "two forward partials per sample and net");
         float h[4];
-        h[0] = leaky((x1.x + b[0]) + (a0.x + a1.x));
-        h[1] = leaky((x1.y + b[1]) + (a0.y + a1.y));
-        h[2] = leaky((x1.z + b[2]) + (a0.z + a1.z));
-        h[3] = leaky((x1.w + b[3]) + (a0.w + a1.w));
+        h[0] = leaky(a0.x + a1.x);
+        h[1] = leaky(a0.y + a1.y);
+        h[2] = leaky(a0.z + a1.z);
+        h[3] = leaky(a0.w + a1.w);
         float z3 = 0.f, z4 = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
