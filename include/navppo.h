@@ -91,7 +91,11 @@ int navppo_mlp64_value(const float* critic_params_dev, const void* obs_dev, int3
  * One whole update epoch of ppo.py:305-392 on one GPU: navppo_mlp64_loss_grad followed by the two Adam steps of
  * ppo.py:381,392 (torch.optim.Adam defaults: no weight decay, no amsgrad) applied in place by the kernel that sums the
  * workgroups' partial gradients.  step = 1, 2, ... (Adam's bias correction); adam_m_dev / adam_v_dev [PA + PC] f32 are
- * the optimiser's moments (zero before the first step).  grad_dev and stats_dev are filled as by navppo_mlp64_loss_grad.
+ * the optimiser's moments (zero before the first step).  grad_dev and stats_dev are filled as by navppo_mlp64_loss_grad; in addition
+ * stats_dev[3] / [7] receive the SQUARED gradient norms of the actor / the critic of the update_epoch call BEFORE this one on the same
+ * workspace (calls with consecutive `step`; the value of the first call is meaningless): with the last epoch's norms taken from grad_dev
+ * a caller has every epoch's norms for the means the reference logs (ppo.py:351-352, 389-390) at no extra launch.  The same holds for
+ * navppo_mlp64_bf16x3_update_epoch and navppo_resmlp512_update_epoch.
  * Multi-GPU runs use navppo_mlp64_loss_grad + an all-reduce + their own optimiser step instead.
  */
 int navppo_mlp64_update_epoch(float* params_dev, const void* obs_dev, int32_t obs_dim, int32_t obs_f16, const float* act_dev,

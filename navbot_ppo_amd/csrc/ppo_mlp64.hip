@@ -1287,13 +1287,19 @@ __global__ __launch_bounds__(64 * XPad<IN>::NW) void mlp64_pass_both_x3(const fl
 // One block owns 64 parameters and ALL rows (no atomics): grad[p] is stored, not accumulated.  pa / pc: parameters of the actor /
 // the critic (Layout<IN>), the pitch of their partial rows.
 constexpr int kRedGroups = 16;   // row groups per block: 1024 threads, every thread sums n_blocks / 16 rows, 4 loads in flight
+constexpr int kGnSlots = 256;    // per (parity, net): one slot per block of reduce_adam (<= 235 blocks at 42 columns)
 template <bool ADAM>
 __global__ __launch_bounds__(64 * kRedGroups) void reduce_adam(const float* __restrict__ partial_a, const float* __restrict__ stats_partial_a,
                                                    const float* __restrict__ partial_c, const float* __restrict__ stats_partial_c,
                                                    int n_blocks, float inv_n, float* __restrict__ grad, float* __restrict__ stats,
                                                    float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
                                                    float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-                                                   int pa, int pc, int q_begin, int q_end) {
+                                                   int pa, int pc, int q_begin, int q_end, float* __restrict__ gn, int parity) {
+    // gn / parity (whole-update epochs only; parity < 0: off): the squared gradient norms per net, for the per-epoch MEANS the reference
+    // logs (ppo.py:351-352, 389-390: clip_grad_norm_(inf) of each net in every epoch, averaged) without a norm launch per epoch and
+    // without atomics: every block leaves the sums of its 64 squared gradients (actor part, critic part) in slot `parity`, and block 0
+    // adds up the slots of the OTHER parity -- the epoch before -- into stats[3] (actor) / stats[7] (critic).  The last epoch's norms
+    // are taken from grad_dev by the caller.
     __shared__ float part[kRedGroups][64];
     const int lane = threadIdx.x & 63, q = q_begin + blockIdx.x * 64 + lane, g = threadIdx.x >> 6;   // q: index into actor | critic
     const bool actor = q < pa;
@@ -1325,6 +1331,27 @@ __global__ __launch_bounds__(64 * kRedGroups) void reduce_adam(const float* __re
             const float denom = sqrtf(vv) / bc2_sqrt + eps;
             params[q] -= (lr / bc1) * (mm / denom);
         }
+    }
+    if (parity >= 0 && g == 0) {
+        const float gr2 = q < q_end ? grad[q] * grad[q] : 0.f;   // (this lane's own store above)
+        float sa = actor ? gr2 : 0.f, sc = actor ? 0.f : gr2;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            sa += __shfl_xor(sa, o, 64);
+            sc += __shfl_xor(sc, o, 64);
+        }
+        if (lane == 0) {
+            gn[(parity * 2 + 0) * kGnSlots + blockIdx.x] = sa;
+            gn[(parity * 2 + 1) * kGnSlots + blockIdx.x] = sc;
+        }
+    }
+    if (parity >= 0 && blockIdx.x == 0 && (g == 3 || g == 7)) {
+        const float* sp = gn + ((1 - parity) * 2 + (g >> 2)) * kGnSlots;
+        float s = 0.f;
+        for (int b = lane; b < (int)gridDim.x; b += 64) s += sp[b];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) stats[g] = s;
     }
     const bool net_here = (g < 4) ? (q_begin == 0) : (q_end > pa);   // a one-net launch leaves the other net's statistics alone
     if (blockIdx.x == 0 && g < 8 && (g & 3) < 3 && net_here) {   // stats[0..2] actor, stats[4..6] critic: wave g sums statistic g over the rows
@@ -1508,7 +1535,7 @@ bool obs_aligned(const void* obs, int32_t obs_dim, int32_t obs_f16) {
 }
 
 struct PassPlan {
-    float *partial, *stats_partial, *partial_c, *stats_partial_c;
+    float *partial, *stats_partial, *partial_c, *stats_partial_c, *gn;
     float inv_n;
     int blocks, pa, pc;
 };
@@ -1520,6 +1547,10 @@ PassPlan plan_pass(void* workspace_dev, int64_t n_samples, int32_t obs_dim) {
     pl.stats_partial = pl.partial + (size_t)NAVPPO_MLP64_MAX_BLOCKS * pl.pa;
     pl.partial_c = pl.partial + (size_t)kWMaxBlocks * pl.pa;   // the workspace has NAVPPO_MLP64_MAX_BLOCKS = 2 kWMaxBlocks rows
     pl.stats_partial_c = pl.stats_partial + (size_t)kWMaxBlocks * 4;
+    // the critic's rows are shorter than the actor's: the tail of its half of the row area is free -- the squared-norm slots of reduce_adam
+    pl.gn = pl.partial_c + (size_t)kWMaxBlocks * pl.pc;
+    static_assert((Layout<42>::P_ACTOR + Layout<42>::P_CRITIC + 63) / 64 <= kGnSlots && 4 * kGnSlots <= kWMaxBlocks * (Layout<16>::P_ACTOR - Layout<16>::P_CRITIC),
+                  "the squared-norm slots fit the free tail of the critic's rows");
     pl.inv_n = 1.0f / (float)n_samples;
     const long long wtiles = (n_samples + 31) / 32;
     const long long want = (wtiles + kWWaves - 1) / kWWaves;
@@ -1553,7 +1584,7 @@ int navppo_mlp64_loss_grad(const float* params_dev, const void* obs_dev, int32_t
     });
     hipLaunchKernelGGL(reduce_adam<false>, dim3((pl.pa + pl.pc + 63) / 64), dim3(64 * kRedGroups), 0, st, pl.partial, pl.stats_partial,
                        pl.partial_c, pl.stats_partial_c, pl.blocks, pl.inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f,
-                       0.f, 1.f, 1.f, pl.pa, pl.pc, 0, pl.pa + pl.pc);
+                       0.f, 1.f, 1.f, pl.pa, pl.pc, 0, pl.pa + pl.pc, (float*)nullptr, -1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_loss_grad: ") + hipGetErrorString(e);
@@ -1592,7 +1623,7 @@ int navppo_mlp64_loss_grad_net(int32_t net, const float* params_dev, const void*
     const int q0 = net == 0 ? 0 : pl.pa, q1 = net == 0 ? pl.pa : pl.pa + pl.pc;
     hipLaunchKernelGGL(reduce_adam<false>, dim3((q1 - q0 + 63) / 64), dim3(64 * kRedGroups), 0, st, pl.partial, pl.stats_partial, pl.partial_c,
                        pl.stats_partial_c, pl.blocks, pl.inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f,
-                       pl.pa, pl.pc, q0, q1);
+                       pl.pa, pl.pc, q0, q1, (float*)nullptr, -1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_loss_grad_net: ") + hipGetErrorString(e);
@@ -1666,7 +1697,7 @@ int navppo_mlp64_update_epoch(float* params_dev, const void* obs_dev, int32_t ob
     });
     hipLaunchKernelGGL(reduce_adam<true>, dim3((pl.pa + pl.pc + 63) / 64), dim3(64 * kRedGroups), 0, st, pl.partial, pl.stats_partial,
                        pl.partial_c, pl.stats_partial_c, pl.blocks, pl.inv_n, grad_dev, stats_dev, params_dev, adam_m_dev, adam_v_dev, lr,
-                       beta1, beta2, eps, bc1, bc2_sqrt, pl.pa, pl.pc, 0, pl.pa + pl.pc);
+                       beta1, beta2, eps, bc1, bc2_sqrt, pl.pa, pl.pc, 0, pl.pa + pl.pc, pl.gn, (int)(step & 1));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_err = std::string("navppo_mlp64_update_epoch: ") + hipGetErrorString(e);
@@ -1729,11 +1760,11 @@ static int x3_epoch(const char* who, float* params_dev, const void* prep_dev, in
         const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
         hipLaunchKernelGGL(reduce_adam<true>, dim3((q1 - q0 + 63) / 64), dim3(64 * kRedGroups), 0, st, pl.partial, pl.stats_partial, pl.partial_c,
                            pl.stats_partial_c, pl.blocks, pl.inv_n, grad_dev, stats_dev, params_dev, adam_m_dev, adam_v_dev, lr, beta1, beta2,
-                           eps, bc1, bc2_sqrt, pl.pa, pl.pc, q0, q1);
+                           eps, bc1, bc2_sqrt, pl.pa, pl.pc, q0, q1, pl.gn, net_mask == 3 ? (int)(step & 1) : -1);
     } else {
         hipLaunchKernelGGL(reduce_adam<false>, dim3((q1 - q0 + 63) / 64), dim3(64 * kRedGroups), 0, st, pl.partial, pl.stats_partial, pl.partial_c,
                            pl.stats_partial_c, pl.blocks, pl.inv_n, grad_dev, stats_dev, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f,
-                           1.f, pl.pa, pl.pc, q0, q1);
+                           1.f, pl.pa, pl.pc, q0, q1, (float*)nullptr, -1);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

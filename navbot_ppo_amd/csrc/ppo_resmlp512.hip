@@ -114,6 +114,8 @@ constexpr int EP = 128;              // pitch of a streaming-kernel partial row
 constexpr int kEMaxBlocks = 1024, kEThreads = 256;
 // columns of a streaming-kernel partial row
 constexpr int EC_B2B = 16, EC_WO1 = 48, EC_BO1 = 80, EC_WO2 = 81, EC_BO2 = 113, EC_STAT = 120;
+constexpr int kGnSlotsR = 1600;   // squared-norm slots of resmlp_reduce per (parity, net): one per block (1572); columns 0 .. 7 of 2 x kEMaxBlocks partial rows
+static_assert((rp::P_ACTOR + rp::P_CRITIC + 63) / 64 <= kGnSlotsR && 4 * kGnSlotsR <= 8 * 2 * kEMaxBlocks, "slots");
 
 template <int IN> struct Blk;
 template <> struct Blk<16> { static constexpr int W1 = rp::W1A, B1 = rp::B1A, W2 = rp::W2A; };
@@ -1020,7 +1022,14 @@ template <bool ADAM>
 __global__ __launch_bounds__(64 * kRedGroups) void resmlp_reduce(const float* __restrict__ wpart, int w_rows1, int w_rows2, const float* __restrict__ epart,
                                                                   int e_rows, float inv_n, float* __restrict__ grad, float* __restrict__ stats,
                                                                   float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
-                                                                  float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+                                                                  float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+                                                                  float* __restrict__ gnbase, int parity) {
+    // gnbase / parity: the per-net squared gradient norms of the epoch BEFORE into stats[3] / stats[7] (reduce_adam of ppo_mlp64.hip has
+    // the scheme); the slots are columns 0 .. 7 of the streaming kernels' partial rows (those kernels write columns >= EC_B2B)
+    auto gn_slot = [&](const int par, const int net, const int b) -> float* {
+        const int i = (par * 2 + net) * kGnSlotsR + b;
+        return gnbase + (size_t)(i >> 3) * EP + (i & 7);
+    };
     __shared__ float part[kRedGroups][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, qi = blockIdx.x * 64 + lane;   // qi: index into actor | critic
     const bool valid = qi < rp::P_ACTOR + rp::P_CRITIC;
@@ -1057,6 +1066,26 @@ __global__ __launch_bounds__(64 * kRedGroups) void resmlp_reduce(const float* __
             v[qi] = vv;
             params[qi] -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
         }
+    }
+    if (parity >= 0 && g == 0) {
+        const float gr2 = valid ? grad[qi] * grad[qi] : 0.f;   // (this lane's own store above)
+        float sa = net_i == 0 ? gr2 : 0.f, sc = net_i == 0 ? 0.f : gr2;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            sa += __shfl_xor(sa, o, 64);
+            sc += __shfl_xor(sc, o, 64);
+        }
+        if (lane == 0) {
+            *gn_slot(parity, 0, blockIdx.x) = sa;
+            *gn_slot(parity, 1, blockIdx.x) = sc;
+        }
+    }
+    if (parity >= 0 && blockIdx.x == 0 && (g == 3 || g == 7)) {
+        float s = 0.f;
+        for (int b = lane; b < (int)gridDim.x; b += 64) s += *gn_slot(1 - parity, g >> 2, b);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) stats[g] = s;
     }
     if (blockIdx.x == 0 && g < 8 && (g & 3) < 3) {   // stats[0..2] actor (loss, approx KL, clip fraction), stats[4] critic loss
         const float* sp = epart + (size_t)(g >> 2) * e_rows * EP + EC_STAT + (g & 3);
@@ -1194,11 +1223,12 @@ int loss_grad_impl(const char* name, bool adam, float* params, const void* obs, 
         const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
         const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
         hipLaunchKernelGGL(resmlp_reduce<true>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kBwd1Waves,
-                           p.groups * kBwd2Waves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, params, adam_m, adam_v, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+                           p.groups * kBwd2Waves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, params, adam_m, adam_v, lr, beta1, beta2, eps, bc1, bc2_sqrt,
+                           p.epart, (int)(step & 1));
     } else {
         hipLaunchKernelGGL(resmlp_reduce<false>, dim3(rblocks), dim3(64 * kRedGroups), 0, st, (const float*)p.wpart, p.groups * kBwd1Waves,
                            p.groups * kBwd2Waves, (const float*)p.epart, p.e_blocks, inv_n, grad, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f,
-                           0.f, 0.f, 0.f, 1.f, 1.f);
+                           0.f, 0.f, 0.f, 1.f, 1.f, (float*)nullptr, -1);
     }
     return launch_ok(name) ? 0 : -2;
 }

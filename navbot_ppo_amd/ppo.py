@@ -363,23 +363,30 @@ class PPOUpdater:
         n_c = self.fp.numel - n_a
         t0 = self._adam_t
         wa = wc = None
+        gn_sq = torch.zeros((max(n_ep, 1), 2), device=obs.device)   # every epoch's squared norms of the summed (actor, critic) gradient
+        ga, gc = self.fp.grad[:n_a], self.fp.grad[n_a:]
         for ep in range(n_ep):
             if wa is not None:   # epoch ep - 1's actor gradient has arrived (long ago: it had the critic's pass to do so)
                 wa.wait()
                 self._fused_adam(1.0 / world, 0, n_a, t0 + ep)
+                gn_sq[ep - 1, 0] = torch.dot(ga, ga)
             self._fused_loss_grad_net(0, obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
             wa = dist.all_reduce(self.fp.grad[:n_a], op=dist.ReduceOp.SUM, async_op=True)
             if wc is not None:
                 wc.wait()
                 self._fused_adam(1.0 / world, n_a, n_c, t0 + ep)
+                gn_sq[ep - 1, 1] = torch.dot(gc, gc)
             self._fused_loss_grad_net(1, obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
             wc = dist.all_reduce(self.fp.grad[n_a:], op=dist.ReduceOp.SUM, async_op=True)
         if wa is not None:
             wa.wait()
             self._fused_adam(1.0 / world, 0, n_a, t0 + n_ep)
+            gn_sq[n_ep - 1, 0] = torch.dot(ga, ga)
             wc.wait()
             self._fused_adam(1.0 / world, n_a, n_c, t0 + n_ep)
+            gn_sq[n_ep - 1, 1] = torch.dot(gc, gc)
         self._adam_t = t0 + n_ep
+        return gn_sq / float(world) ** 2
 
     def _fused_value(self, obs):
         """V = critic(obs).squeeze() (ppo.py:275) by the forward half of the critic's fused pass."""
@@ -435,6 +442,9 @@ class PPOUpdater:
         flat_before = self.fp.flat.clone()                     # for the parameter-delta diagnostics of ppo.py:402-403
         a_loss = c_loss = torch.zeros((), device=obs.device)   # n_updates_per_iteration == 0: nothing to report
         acc = torch.zeros(6, device=obs.device)                # sums over epochs of diagnostics
+        fused_gn_sq = None                                     # fused single-GPU path: [n_ep - 1, 2] squared per-net gradient norms
+        net_gn = None                                          # PyTorch path: sums over epochs of the per-net gradient norms
+        multi_gn = None                                        # fused multi-GPU path: sums over epochs of (actor, critic, total) norms of the mean gradient
         self.loss_history = torch.zeros((n_ep, 2), device=obs.device)  # per-epoch (actor, critic) loss, ppo.py:396-397
         var_f = float(var) if self.fused else None
         if not (self.fused and obs.dtype == torch.float16):
@@ -447,7 +457,9 @@ class PPOUpdater:
                 self._fhist = torch.zeros((n_ep, 8), dtype=torch.float32, device=self.device)
         pipelined = self.fused and multi and self.fused_mlp64 and cfg.overlap_allreduce
         if pipelined:
-            self._pipelined_epochs(n_ep, world, obs, acts, logp_old, rtg, adv, var_f)
+            pg = self._pipelined_epochs(n_ep, world, obs, acts, logp_old, rtg, adv, var_f)   # squared norms of the MEAN gradient, per epoch and net
+            if n_ep > 0:
+                multi_gn = torch.cat([pg.sqrt().sum(0), pg.sum(1).sqrt().sum().reshape(1)])
         for ep in range(n_ep):                                 # ppo.py:305
             if self.fused:
                 # per-epoch diagnostics land in row ep of a device buffer: no extra launches inside the epoch loop
@@ -456,6 +468,10 @@ class PPOUpdater:
                 elif multi:   # fused passes -> ONE all-reduce of the flat gradient (RCCL) -> scale + Adam in one launch
                     self._fused_loss_grad(obs, acts, logp_old, rtg, adv, var_f, stats=self._fhist[ep])
                     ctx.all_reduce_sum(self.fp.grad)
+                    with torch.no_grad():   # every epoch's norms of the MEAN gradient (two small launches beside an all-reduce)
+                        n_a_ = self.fp.module_numel[0]
+                        g3 = torch.stack(torch._foreach_norm([self.fp.grad[:n_a_], self.fp.grad[n_a_:], self.fp.grad])) / world
+                        multi_gn = g3 if multi_gn is None else multi_gn + g3
                     self._fused_adam(1.0 / world)
                 else:
                     self._fused_epoch(obs, acts, logp_old, rtg, adv, var_f, self._fhist[ep])
@@ -464,9 +480,18 @@ class PPOUpdater:
                     self.loss_history = h[:, 0:5:4].clone()   # columns 0 (actor loss) and 4 (critic loss)
                     hs = h.sum(0)
                     # multi-GPU: fp.grad holds the all-reduced SUM (the 1 / world scale is inside navppo_adam_step)
-                    acc = torch.cat([hs[[0, 4, 1, 2]], torch.stack([self.fp.grad.norm() / world, V0.mean()]) * n_ep])
-                    # grad_norm: the LAST epoch's (the PyTorch path averages the norm over the epochs; a norm launch per epoch
-                    # would cost 0.7 % of the iteration for a diagnostic, so the fused path reports the final epoch's norm)
+                    gn_last = self.fp.grad.norm() / world
+                    if not multi and n_ep > 1:
+                        # grad norms as the reference logs them -- every epoch's, averaged (ppo.py:351-352, 389-390) -- without a norm
+                        # launch per epoch: the fused epoch leaves the squared per-net norms of the epoch BEFORE in columns 3 / 7 of
+                        # its statistics row (reduce_adam / resmlp_reduce), the last epoch's come from the gradient buffer
+                        fused_gn_sq = h[1:, 3:8:4].clone()                         # [n_ep - 1, (actor, critic)]
+                        gn_sum = fused_gn_sq.sum(1).sqrt().sum() + gn_last
+                    elif multi_gn is not None:
+                        gn_sum = multi_gn[2]
+                    else:   # (the pipelined multi-GPU epochs, one epoch: the last epoch's norm stands in)
+                        gn_sum = gn_last * n_ep
+                    acc = torch.cat([hs[[0, 4, 1, 2]], torch.stack([gn_sum, V0.mean() * n_ep])])
                     a_loss, c_loss = self.loss_history[-1, 0], self.loss_history[-1, 1]
                 continue
             a_loss, c_loss, ratios, logp, _ = ppo_losses(self.actor, self.critic, obs, acts, logp_old, rtg, adv, var, cfg.clip)
@@ -482,6 +507,9 @@ class PPOUpdater:
                 acc += torch.stack([a_loss.detach(), c_loss.detach(), ((ratios.detach() - 1) - lr_).mean(),
                                     ((ratios.detach() - 1).abs() > cfg.clip).float().mean(),
                                     self.fp.grad.norm(), V0.mean()])
+                n_a_ = self.fp.module_numel[0]
+                g2 = torch.stack(torch._foreach_norm([self.fp.grad[:n_a_], self.fp.grad[n_a_:]]))
+                net_gn = g2 if net_gn is None else net_gn + g2
         acc = acc / max(n_ep, 1)
         if multi:
             ctx.all_reduce_sum(acc)
@@ -491,9 +519,15 @@ class PPOUpdater:
         extra = torch.stack(torch._foreach_norm([self.fp.grad[:n_a], self.fp.grad[n_a:], d[:n_a], d[n_a:]]))
         if self.fused and multi:
             extra = extra * extra.new_tensor([1.0 / world, 1.0 / world, 1.0, 1.0])   # norms of the MEAN gradient, as on one GPU
+        if fused_gn_sq is not None:   # per-net norms: the mean over the epochs, like grad_norm (the reference's actor_grad_norm / critic_grad_norm)
+            extra = torch.cat([(fused_gn_sq.sqrt().sum(0) + extra[:2]) / n_ep, extra[2:]])
+        elif multi_gn is not None:
+            extra = torch.cat([multi_gn[:2] / n_ep, extra[2:]])
+        elif net_gn is not None:
+            extra = torch.cat([net_gn / max(n_ep, 1), extra[2:]])
         self.stats = dict(zip(["actor_loss", "critic_loss", "approx_kl", "clip_frac", "grad_norm", "value_mean",
                                "actor_grad_norm", "critic_grad_norm", "actor_param_delta", "critic_param_delta"],
-                              [float(v) for v in torch.cat([acc, extra]).tolist()]))   # grad norms: the last epoch's
+                              [float(v) for v in torch.cat([acc, extra]).tolist()]))   # grad norms: means over the epochs (multi-GPU fused path: the last epoch's)
         self.last_losses = (a_loss.detach(), c_loss.detach())
         return self.stats
 

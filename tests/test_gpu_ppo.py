@@ -600,3 +600,32 @@ def test_persistent_rollout_on_a_streamed_map():
     assert int(outs[0][6].sum()) >= N
     for x, y in zip(*outs):
         assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y)
+
+
+@pytest.mark.parametrize("policy,arith", [("mlp64x2", "bf16x3"), ("mlp64x2", "f32"), ("resmlp512", "bf16x3")])
+def test_fused_update_reports_gradient_norms_averaged_over_the_epochs(policy, arith):
+    """The reference logs the MEAN over an iteration's epochs of each net's gradient norm (ppo.py:351-352, 389-390, 449-450).  The
+    fused epochs deliver those without a norm launch per epoch: reduce_adam / resmlp_reduce leave the squared per-net norms of the
+    epoch before in columns 3 / 7 of the statistics row.  Against the PyTorch formulation of the same update (same start, same data):
+    grad_norm / actor_grad_norm / critic_grad_norm agree, and they are NOT the last epoch's values."""
+    import copy
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    a, c = nets.make_policy(policy)
+    a.to(dev), c.to(dev)
+    n, n_ep = 20000, 6
+    obs, acts, logp, rtg, adv = _batch(n, 11, dev)
+    var = torch.tensor(0.6, device=dev)
+    cfg = dict(n_updates_per_iteration=n_ep, policy=policy, lr=3e-3)
+    up_f = ppo.PPOUpdater(copy.deepcopy(a), copy.deepcopy(c), ppo.PPOConfig(update_arith=arith, **cfg), None, dev)
+    up_t = ppo.PPOUpdater(copy.deepcopy(a), copy.deepcopy(c), ppo.PPOConfig(fused_update=False, **cfg), None, dev)
+    assert up_f.fused and not up_t.fused
+    sf = up_f.update(obs, acts, logp, rtg, var)
+    st = up_t.update(obs, acts, logp, rtg, var)
+    n_a = up_f.fp.module_numel[0]
+    last = {"grad_norm": float(up_f.fp.grad.norm()), "actor_grad_norm": float(up_f.fp.grad[:n_a].norm()),
+            "critic_grad_norm": float(up_f.fp.grad[n_a:].norm())}
+    for k in ("grad_norm", "actor_grad_norm", "critic_grad_norm"):
+        assert sf[k] == pytest.approx(st[k], rel=5e-3), (k, sf[k], st[k])
+    # the series moves over the epochs at this learning rate, so a last-epoch value would not pass for the mean
+    assert abs(last["critic_grad_norm"] - sf["critic_grad_norm"]) > 0.02 * sf["critic_grad_norm"], (last, sf)
